@@ -1,0 +1,96 @@
+/*
+ * wfa_gpu_device.h -- device-resident entry points of the MI355X build.
+ *
+ * The reference only exposes host-buffer entry points (lib/align.cuh:35-47):
+ * every call re-uploads the ASCII sequences over PCIe.  These functions are
+ * what launch_alignments* are built from, exported so that an integrator (or
+ * bench.py) can keep a batch resident in HBM and so that parity tests can
+ * exercise each stage (lib/sequence_packing.cu:96-116 pack,
+ * lib/sequence_alignment.cu:211-470 align, utils/cigar.c:96-272 CIGAR
+ * recovery) separately.  Plain C: device addresses travel as typed
+ * pointers or void pointers, a HIP stream as a void pointer.
+ */
+#ifndef WFA_GPU_DEVICE_H
+#define WFA_GPU_DEVICE_H
+
+#include "wfa_gpu_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct wfagpu_amd_ctx wfagpu_amd_ctx_t;
+
+typedef struct {
+    int device;            /* HIP device ordinal                                         */
+    void* stream;          /* hipStream_t to run on; NULL: the context creates its own   */
+    size_t arena_bytes;    /* backtrace arena (origin bytes + row headers); 0: automatic */
+    size_t text_bytes;     /* CIGAR text arena; 0: automatic                             */
+} wfagpu_amd_config_t;
+
+typedef struct {
+    const char* d_sequences;             /* device: ASCII buffer, reference layout       */
+    size_t sequences_bytes;
+    const sequence_pair_t* d_metadata;   /* device: packed offsets filled (see below)    */
+    size_t num_pairs;
+    size_t packed_bytes;                 /* value returned by wfagpu_amd_fill_packed_offsets */
+    unsigned int max_seq_len;            /* longest pattern/text in the batch            */
+} wfagpu_amd_batch_t;
+
+typedef struct {
+    /* per-kernel device time of the last call, milliseconds (HIP events on the
+     * context's stream) */
+    float pack_ms;
+    float align_ms;        /* all align launches                                          */
+    float trace_ms;
+    float total_ms;        /* first launch to last completion                             */
+    int align_launches;
+    /* work accounting */
+    unsigned long long cells;          /* wavefront cells computed (sum of widths)        */
+    unsigned long long arena_units;    /* 16-byte units of backtrace arena used           */
+    unsigned long long text_bytes;     /* CIGAR text bytes produced                       */
+    unsigned int pairs_tier[4];        /* pairs finished per kernel tier                  */
+    unsigned int pairs_retried;        /* pairs that needed a wider tier                  */
+    unsigned int sub_batches;          /* arena-bounded passes                            */
+    size_t lds_bytes_tier0;
+    int blocks_per_cu_tier0;
+} wfagpu_amd_stats_t;
+
+/* 0 on success, negative on error (message on stderr). */
+int wfagpu_amd_create(wfagpu_amd_ctx_t** ctx, const wfagpu_amd_config_t* cfg);
+void wfagpu_amd_destroy(wfagpu_amd_ctx_t* ctx);
+
+/* Host helper: assigns text_offset_packed / pattern_offset_packed for n
+ * records (what lib/align.cu:103-115 does inline) and returns the number of
+ * packed bytes the batch needs.  Each sequence gets ceil(len/16)+1 words. */
+size_t wfagpu_amd_fill_packed_offsets(sequence_pair_t* metadata, size_t n);
+
+/* Stage 1 only: 2-bit packing.  d_packed must hold batch->packed_bytes;
+ * d_flags (2 bytes per pair: pattern, text) receives 1 where a byte outside
+ * ACGT was seen. */
+int wfagpu_amd_pack_device(wfagpu_amd_ctx_t* ctx, const wfagpu_amd_batch_t* batch,
+                           void* d_packed, unsigned char* d_flags);
+
+/* The whole hot path on a resident batch: pack -> wavefront kernels (tier
+ * escalation on the device, never on the CPU) -> backtrace + CIGAR text.
+ *   d_scores      device int32[num_pairs], positive scores
+ *   compute_cigar when true the CIGAR text stays in the context's arena:
+ *                 *d_text, *d_off (uint64 byte offsets), *d_len (uint32 strlen)
+ *                 are device pointers valid until the next call on ctx.
+ * Blocking (returns after the stream has drained).  0 on success. */
+int wfagpu_amd_align_device(wfagpu_amd_ctx_t* ctx, const wfagpu_amd_batch_t* batch,
+                            affine_penalties_t penalties, int max_error, int band,
+                            bool compute_cigar, int32_t* d_scores,
+                            const char** d_text, const unsigned long long** d_off,
+                            const unsigned int** d_len);
+
+void wfagpu_amd_last_stats(const wfagpu_amd_ctx_t* ctx, wfagpu_amd_stats_t* out);
+
+/* Number of devices launch_alignments* shard a call over (default: all
+ * visible).  Results stay in input order. */
+void wfagpu_amd_set_num_devices(int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,117 @@
+"""Pins the CPU oracle (oracle/wfa_oracle.c) BEFORE it is trusted as the parity checker:
+   * against the reference tests' own golden vectors (tests/golden/, see make_golden.py), and
+   * against the reference's WFA2-lib compiled in place (oracle/_ref), when present.
+CPU only."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+import oracle_lib
+import wfagpu
+
+PENS = {"p0": (1, 2, 1), "p1": (3, 1, 4), "p2": (5, 3, 2), "g231": (2, 3, 1)}
+
+
+@pytest.fixture(scope="module")
+def utest(golden_dir):
+    pairs = wfagpu.read_seq_file(os.path.join(golden_dir, "wfa.utest.seq"))
+    assert len(pairs) == 305
+    return pairs, wfagpu.layout_pairs(pairs)
+
+
+@pytest.mark.parametrize("tag", ["p0", "p1", "p2", "g231"])
+def test_oracle_matches_wfa2_utest_cigars(utest, golden_dir, tag):
+    """external/WFA/tests/wfa.utest.check/test.affine.p*.alg: score AND CIGAR, 305 pairs of 5..10062 bp."""
+    pairs, (buf, meta) = utest
+    gs, gc = oracle_lib.read_alg(os.path.join(golden_dir, f"utest.affine.{tag}.alg"))
+    s, c, _ = oracle_lib.oracle_batch(buf, meta, PENS[tag], cigar=True, nthreads=8)
+    assert np.array_equal(s, gs)
+    assert c == gc
+
+
+@pytest.mark.parametrize("tag", ["p0", "p1", "p2"])
+def test_oracle_matches_reference_score_goldens(utest, golden_dir, tag):
+    """tests/data/results/test.score.affine.p*.alg of the reference (tests/test-aligner.sh:11-48)."""
+    pairs, (buf, meta) = utest
+    gs, _ = oracle_lib.read_alg(os.path.join(golden_dir, f"utest.score.affine.{tag}.alg"))
+    s, _, _ = oracle_lib.oracle_batch(buf, meta, PENS[tag], cigar=False, nthreads=8)
+    assert np.array_equal(s, gs)
+
+
+@pytest.mark.parametrize("name,pens", [("seq1k", [(2, 3, 1), (5, 3, 2)]), ("seq10k", [(2, 3, 1), (3, 5, 2)])])
+def test_oracle_matches_test_api_goldens(golden_dir, name, pens):
+    """tests/data/sequences_1000.h / sequences_10K.h golden score arrays (tests/test_api.c:59-219)."""
+    pairs = wfagpu.read_seq_file(os.path.join(golden_dir, f"{name}.seq"))
+    buf, meta = wfagpu.layout_pairs(pairs)
+    for pen in pens:
+        gold = -np.loadtxt(os.path.join(golden_dir, f"{name}.x{pen[0]}o{pen[1]}e{pen[2]}.scores"), dtype=np.int64)
+        s, _, _ = oracle_lib.oracle_batch(buf, meta, pen, cigar=False, nthreads=8)
+        assert np.array_equal(s, gold[:len(s)])
+
+
+def test_oracle_matches_ref_on_hifi_and_synthetic(golden_dir):
+    for fname, loader in (("hifi.g231.alg", lambda: wfagpu.layout_pairs(wfagpu.read_seq_file(os.path.join(golden_dir, "hifi.seq")))),
+                          ("synth.cfg2.alg", lambda: wfagpu.generate_pairs(2000, 150, 0.02, 2)),
+                          ("synth.cfg3.alg", lambda: wfagpu.generate_pairs(500, 1000, 0.05, 3))):
+        buf, meta = loader()
+        gs, gc = oracle_lib.read_alg_skip_comments(os.path.join(golden_dir, fname))
+        s, c, _ = oracle_lib.oracle_batch(buf, meta, (2, 3, 1), cigar=True, nthreads=8)
+        assert np.array_equal(s, gs), fname
+        assert c == gc, fname
+
+
+def _rand_pairs(rng, n, maxlen, alphabet=b"ACGT", err=0.1):
+    out = []
+    for _ in range(n):
+        L = rng.randint(0, maxlen)
+        t = bytes(rng.choice(alphabet) for _ in range(L))
+        p = bytearray(t)
+        for _ in range(int(L * err) + rng.randint(0, 2)):
+            op = rng.randint(0, 2)
+            if op == 0 and p:
+                p[rng.randrange(len(p))] = rng.choice(alphabet)
+            elif op == 1 and p:
+                del p[rng.randrange(len(p))]
+            else:
+                p.insert(rng.randint(0, len(p)), rng.choice(alphabet))
+        out.append((bytes(p), t))
+    return out
+
+
+@pytest.mark.skipif(not oracle_lib.have_ref(), reason="oracle/_ref not built (reference tree absent)")
+@pytest.mark.parametrize("pen", [(2, 3, 1), (1, 2, 1), (3, 1, 4), (5, 3, 2), (4, 6, 2), (1, 0, 1), (7, 2, 3)])
+def test_oracle_matches_compiled_reference_random(pen):
+    """Random pairs incl. empty/1-base sequences, unrelated pairs and bytes outside ACGT (WFA2 compares raw bytes)."""
+    rng = random.Random(1234 + sum(pen))
+    pairs = _rand_pairs(rng, 300, 60) + _rand_pairs(rng, 60, 400, err=0.25)
+    pairs += _rand_pairs(rng, 40, 80, alphabet=b"ACGTNacgt")
+    pairs += [(b"", b""), (b"A", b""), (b"", b"ACGT"), (b"A", b"A"), (b"A", b"C"), (b"ACGT", b"TGCA"),
+              (b"AAAAAAAAAA", b"TTTTTTTTTTTTTTT"), (b"ACGTACGTAC", b"ACGTACGTACGTACGTACGT")]
+    buf, meta = wfagpu.layout_pairs(pairs)
+    rs_hi, rc_hi = oracle_lib.ref_batch(buf, meta, pen, cigar=True, memory_mode=0)
+    rs_lo, rc_lo = oracle_lib.ref_batch(buf, meta, pen, cigar=True, memory_mode=1)
+    s, c, _ = oracle_lib.oracle_batch(buf, meta, pen, cigar=True)
+    s2, _, _ = oracle_lib.oracle_batch(buf, meta, pen, cigar=False)
+    assert np.array_equal(rs_hi, rs_lo) and rc_hi == rc_lo      # WFA2 memory modes agree (utils/wfa_cpu.c uses low)
+    assert np.array_equal(s, rs_hi)
+    assert np.array_equal(s2, rs_hi)                             # ring (score-only) path == full path
+    assert c == rc_hi
+    for (p, t), cg, sc in zip(pairs, c, s):
+        ok, cost = oracle_lib.check_cigar(p, t, cg, pen)
+        assert ok and cost == sc
+
+
+def test_oracle_pack_layout():
+    """Bit layout of this build's packing: code=(c&6)>>1 (A0 C1 T2 G3, as tests/test_packing_kernel.cu:31 of the
+    reference decodes it), base i in bits 2*(i%16) of word i//16."""
+    import ctypes as C
+    seq = b"ACGTTGCAACGTACGTAGGT"
+    words = (C.c_uint32 * 2)()
+    bad = oracle_lib.oracle().oracle_pack2(seq, len(seq), words)
+    assert bad == 0
+    lut = b"ACTG"
+    dec = bytes(lut[(words[i // 16] >> (2 * (i % 16))) & 3] for i in range(len(seq)))
+    assert dec == seq
+    assert oracle_lib.oracle().oracle_pack2(b"ACGN", 4, words) == 1

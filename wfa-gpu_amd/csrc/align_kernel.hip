@@ -1,0 +1,427 @@
+// Gap-affine wavefront alignment (forward pass) for gfx950.
+//
+// Replaces the reference's distance_kernel / alignment_kernel
+// (lib/kernels/sequence_distance_kernel.cu:175-425,
+//  lib/kernels/sequence_alignment_kernel.cu:355-688), its extend device
+// function (lib/kernels/common_alignment_kernels.cuh:29-111) and their
+// launch layer (lib/sequence_alignment.cu:211-470).  The arithmetic follows
+// WFA2-lib (the ground truth the reference checks itself against):
+//   recurrences + out-of-range nulling  wavefront_compute_affine.c:45-87
+//   per-component end trimming          wavefront_compute.c:570-603
+//   limits of the next wavefront        wavefront_compute.c:41-71
+//   termination                         wavefront_extend.c:47-67
+//   tie-breaks recorded for backtrace   wavefront_backtrace.c:48-59,366-376
+// so that score AND CIGAR are identical to WFA2's.
+//
+// Design (MI355X):
+//   * A persistent workgroup of NW wavefronts (NW = 1, 4 or 16) owns one
+//     alignment at a time and pulls the next one from an atomic counter.
+//     The diagonals of the current score are striped over the NW*64 lanes.
+//   * The wavefront ring -- max(x,o+e)+1 rows of M, e+1 rows of I and of D,
+//     16-bit offsets -- and both 2-bit packed sequences live in LDS.  With
+//     NW == 1 the whole score loop runs without a single barrier (LDS
+//     operations of one wavefront execute in order); with NW > 1 there is
+//     exactly one barrier per score.
+//   * extend(): two 32-bit LDS words per sequence, v_alignbit_b32 to the
+//     base position, XOR, count-trailing-zeros: 16 bases per iteration.
+//   * Trimming and termination are wave ballots + scalar bit scans.
+//   * For CIGARs each cell emits ONE origin byte (coalesced 64-byte stores
+//     per wavefront instruction) into a bump-allocated arena; rows are
+//     linked backwards through a 16-byte header.  No O(max_error^2)
+//     per-alignment reservation and nothing to memset between alignments.
+//   * A last-resort instantiation keeps a 32-bit ring in HBM/L2 for
+//     wavefronts too wide for LDS.
+#include "wfa_device.h"
+
+namespace {
+
+constexpr int OFF_NULL = -32768;       // any negative offset is "no cell"
+constexpr int EMPTY_LO = 0x3FFFFFFF;   // makes the range predicate false
+
+template <typename OffT> __device__ __forceinline__ OffT off_store(int v);
+template <> __device__ __forceinline__ int16_t off_store<int16_t>(int v) {
+  // offsets past the end of the text only ever grow; saturate them so they
+  // stay "past the end" in 16 bits (host guarantees lengths <= 32766)
+  return (int16_t)min(v, 32767);
+}
+template <> __device__ __forceinline__ int32_t off_store<int32_t>(int v) { return v; }
+
+template <int NW> __device__ __forceinline__ void block_sync() {
+  if constexpr (NW == 1) {
+    // single wavefront: DS/VMEM operations issue in program order, only the
+    // compiler has to be stopped from reordering or caching across this point
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  } else {
+    __syncthreads();
+  }
+}
+
+// value of thread 0 -> every thread of the block
+template <int NW> __device__ __forceinline__ uint32_t block_bcast(uint32_t v, uint32_t* slot) {
+  if constexpr (NW == 1) {
+    return __builtin_amdgcn_readfirstlane(v);
+  } else {
+    if (threadIdx.x == 0) *slot = v;
+    __syncthreads();
+    const uint32_t r = *slot;
+    __syncthreads();
+    return r;
+  }
+}
+
+// Longest common prefix of pattern[v..] and text[h..] on 2-bit packed words
+// (little-endian base order), 16 bases per iteration.
+__device__ __forceinline__ int extend_lcp(const uint32_t* __restrict__ Pw,
+                                          const uint32_t* __restrict__ Tw, int plen, int tlen,
+                                          int k, int h) {
+  int v = h - k;
+  int rem = min(plen - v, tlen - h);
+  while (rem > 0) {
+    const int pi = v >> 4, ti = h >> 4;
+    const uint32_t p0 = Pw[pi], p1 = Pw[pi + 1];
+    const uint32_t t0 = Tw[ti], t1 = Tw[ti + 1];
+    const uint32_t a = __builtin_amdgcn_alignbit(p1, p0, (v & 15) << 1);
+    const uint32_t b = __builtin_amdgcn_alignbit(t1, t0, (h & 15) << 1);
+    const uint32_t d = a ^ b;
+    int n = d ? (__builtin_ctz(d) >> 1) : 16;
+    n = min(n, rem);
+    h += n; v += n; rem -= n;
+    if (n < 16) break;
+  }
+  return h;
+}
+
+struct RowRange { int lo, w; };  // predicate: (unsigned)(k - lo) <= (unsigned)w
+__device__ __forceinline__ RowRange make_range(int lo, int hi) {
+  RowRange r;
+  if (hi >= lo) { r.lo = lo; r.w = hi - lo; } else { r.lo = EMPTY_LO; r.w = 0; }
+  return r;
+}
+
+template <typename OffT>
+__device__ __forceinline__ int rd_cell(const OffT* row, int kidx0, int k, RowRange r) {
+  const int val = (int)row[kidx0 + k];
+  return ((unsigned)(k - r.lo) <= (unsigned)r.w) ? val : OFF_NULL;
+}
+
+template <int NW, bool BT, typename OffT, bool GLOBAL_RING>
+__global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NT = NW * 64;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int dm = p.dm, de = p.de, rs = p.rs, hcap = p.hcap;
+  const int x = p.x, oe = p.oe, e = p.e;
+  const int kidx0 = hcap + 1;               // row index of diagonal 0
+
+  // ---- carve LDS -------------------------------------------------------
+  unsigned char* sp = smem;
+  OffT* Mr;
+  if constexpr (GLOBAL_RING) {
+    Mr = reinterpret_cast<OffT*>(static_cast<char*>(p.gring) + (size_t)blockIdx.x * p.gring_stride);
+  } else {
+    Mr = reinterpret_cast<OffT*>(sp);
+    sp += (((size_t)(dm + 2 * de) * rs * sizeof(OffT)) + 15) & ~(size_t)15;
+  }
+  OffT* Ir = Mr + (size_t)dm * rs;
+  OffT* Dr = Ir + (size_t)de * rs;
+  uint32_t* Pw = reinterpret_cast<uint32_t*>(sp);
+  uint32_t* Tw = Pw + p.seq_words_cap;
+  int* mlo = reinterpret_cast<int*>(Tw + p.seq_words_cap);
+  int* mhi = mlo + dm;
+  int* ilo = mhi + dm;
+  int* ihi = ilo + de;
+  int* dlo = ihi + de;
+  int* dhi = dlo + de;
+  uint32_t* btrow = reinterpret_cast<uint32_t*>(dhi + de);
+  int* red = reinterpret_cast<int*>(btrow + dm);        // [3][8]
+  uint32_t* bslot = reinterpret_cast<uint32_t*>(red + 24);  // [2]
+
+  uint32_t chunk_cur = 0, chunk_left = 0;   // arena units owned by this block
+
+  for (;;) {
+    // ---- next alignment ---------------------------------------------------
+    uint32_t w = 0;
+    if (tid == 0) w = atomicAdd(p.work_counter, 1u);
+    w = block_bcast<NW>(w, bslot);
+    if (w >= p.n_work) break;
+    const uint32_t pair = p.work ? p.work[w] : w;
+    const WfaSeqPair mp = p.meta[pair];
+    const int plen = (int)mp.pattern_len, tlen = (int)mp.text_len;
+    const int kend = tlen - plen;
+    const int pwords = ((plen + 15) >> 4) + 1, twords = ((tlen + 15) >> 4) + 1;
+
+    uint32_t status = WFA_ST_DONE;
+    int s = 0;
+    uint32_t ncells = 1;
+    bool done = false;
+
+    if (kend < -hcap || kend > hcap || pwords > p.seq_words_cap || twords > p.seq_words_cap) {
+      status = WFA_ST_BAND;
+    } else {
+      // ---- stage packed sequences, reset row metadata -----------------------
+      const uint32_t* __restrict__ gp = p.packed + (mp.pattern_offset_packed >> 2);
+      const uint32_t* __restrict__ gt = p.packed + (mp.text_offset_packed >> 2);
+      for (int i = tid; i < pwords; i += NT) Pw[i] = gp[i];
+      for (int i = tid; i < twords; i += NT) Tw[i] = gt[i];
+      for (int i = tid; i < dm; i += NT) { mlo[i] = 1; mhi[i] = -1; btrow[i] = WFA_ROW_NONE; }
+      for (int i = tid; i < de; i += NT) { ilo[i] = 1; ihi[i] = -1; dlo[i] = 1; dhi[i] = -1; }
+      if constexpr (NW > 1) {
+        if (tid < 24) red[tid] = (tid & 7) == 6 ? 0 : (((tid & 7) & 1) ? INT_MIN : INT_MAX);
+      }
+      block_sync<NW>();
+
+      // ---- score 0: M[0][0] = extend(0) -------------------------------------
+      uint32_t row_s = WFA_ROW_NONE;
+      if constexpr (BT) {
+        // row 0: header + one code byte
+        if (chunk_left < 2) {
+          const uint32_t grab = max(2u, p.chunk_units);
+          uint32_t base = WFA_ROW_NONE;
+          if (tid == 0) {
+            const unsigned long long b = atomicAdd(p.arena_top, (unsigned long long)grab);
+            if (b + grab <= p.arena_units) base = (uint32_t)b;
+          }
+          base = block_bcast<NW>(base, bslot);
+          if (base == WFA_ROW_NONE) status = WFA_ST_NOMEM;
+          chunk_cur = base; chunk_left = (base == WFA_ROW_NONE) ? 0 : grab;
+        }
+        if (status == WFA_ST_DONE) {
+          row_s = chunk_cur; chunk_cur += 2; chunk_left -= 2;
+          if (tid == 0) {
+            WfaBtRowHdr* hdr = reinterpret_cast<WfaBtRowHdr*>(p.arena + (size_t)row_s * 16);
+            hdr->lo = 0; hdr->prev_x = WFA_ROW_NONE; hdr->prev_oe = WFA_ROW_NONE; hdr->prev_e = WFA_ROW_NONE;
+            p.arena[(size_t)row_s * 16 + 16] = 0;
+          }
+        }
+      }
+      uint32_t d0 = 0;
+      if (tid == 0) {
+        const int h0 = extend_lcp(Pw, Tw, plen, tlen, 0, 0);
+        Mr[kidx0] = off_store<OffT>(h0);
+        mlo[0] = 0; mhi[0] = 0; btrow[0] = row_s;
+        d0 = (kend == 0 && h0 >= tlen) ? 1u : 0u;
+      }
+      done = block_bcast<NW>(d0, bslot) != 0;
+      block_sync<NW>();
+
+      int slot_m = 0, slot_e = 0;   // ring slots of score s
+      // ---- score loop ---------------------------------------------------------
+      while (!done && status == WFA_ST_DONE) {
+        ++s;
+        if (s > p.max_score) { status = WFA_ST_SCORE; break; }
+        slot_m = (slot_m + 1 == dm) ? 0 : slot_m + 1;
+        slot_e = (slot_e + 1 == de) ? 0 : slot_e + 1;
+        // predecessor rows
+        int sl_x = slot_m - x;   if (sl_x < 0) sl_x += dm;
+        int sl_oe = slot_m - oe; if (sl_oe < 0) sl_oe += dm;
+        int sl_e = slot_e - e;   if (sl_e < 0) sl_e += de;
+        int mxlo = 1, mxhi = -1, molo = 1, mohi = -1, ielo = 1, iehi = -1, delo = 1, dehi = -1;
+        uint32_t r_x = WFA_ROW_NONE, r_oe = WFA_ROW_NONE, r_e = WFA_ROW_NONE;
+        if (s >= x) { mxlo = mlo[sl_x]; mxhi = mhi[sl_x]; r_x = btrow[sl_x]; }
+        if (s >= oe) { molo = mlo[sl_oe]; mohi = mhi[sl_oe]; r_oe = btrow[sl_oe]; }
+        if (s >= e) {
+          ielo = ilo[sl_e]; iehi = ihi[sl_e]; delo = dlo[sl_e]; dehi = dhi[sl_e];
+          // the M ring is deeper than the I/D ring: row s-e of M holds the bt row
+          int sl_me = slot_m - e; if (sl_me < 0) sl_me += dm;
+          r_e = btrow[sl_me];
+        }
+        const bool mx_null = mxlo > mxhi, mo_null = molo > mohi, ie_null = ielo > iehi, de_null = delo > dehi;
+        if (mx_null && mo_null && ie_null && de_null) {
+          // no wavefront at this score (wavefront_compute_affine.c:236-243)
+          mlo[slot_m] = 1; mhi[slot_m] = -1; btrow[slot_m] = WFA_ROW_NONE;
+          ilo[slot_e] = 1; ihi[slot_e] = -1; dlo[slot_e] = 1; dhi[slot_e] = -1;
+          block_sync<NW>();
+          continue;
+        }
+        // limits (wavefront_compute.c:41-71; null rows carry lo=1, hi=-1)
+        int lo = mxlo, hi = mxhi;
+        lo = min(lo, molo - 1); hi = max(hi, mohi + 1);
+        lo = min(lo, ielo + 1); hi = max(hi, iehi + 1);
+        lo = min(lo, delo - 1); hi = max(hi, dehi - 1);
+        if (lo < -hcap || hi > hcap) { status = WFA_ST_BAND; break; }
+        const bool have_i = !(mo_null && ie_null);
+        const bool have_d = !(mo_null && de_null);
+        const int width = hi - lo + 1;
+        ncells += (uint32_t)width;
+
+        uint8_t* codes = nullptr;
+        if constexpr (BT) {
+          const uint32_t need = 1u + (((uint32_t)width + 15u) >> 4);
+          if (need > chunk_left) {
+            const uint32_t grab = max(need, p.chunk_units);
+            uint32_t base = WFA_ROW_NONE;
+            if (tid == 0) {
+              const unsigned long long b = atomicAdd(p.arena_top, (unsigned long long)grab);
+              if (b + grab <= p.arena_units) base = (uint32_t)b;
+            }
+            base = block_bcast<NW>(base, bslot);
+            if (base == WFA_ROW_NONE) { status = WFA_ST_NOMEM; chunk_left = 0; break; }
+            chunk_cur = base; chunk_left = grab;
+          }
+          row_s = chunk_cur; chunk_cur += need; chunk_left -= need;
+          if (tid == 0) {
+            WfaBtRowHdr* hdr = reinterpret_cast<WfaBtRowHdr*>(p.arena + (size_t)row_s * 16);
+            hdr->lo = lo; hdr->prev_x = r_x; hdr->prev_oe = r_oe; hdr->prev_e = r_e;
+          }
+          codes = p.arena + (size_t)row_s * 16 + 16;
+        }
+
+        const RowRange rg_mx = make_range(mxlo, mxhi), rg_mo = make_range(molo, mohi);
+        const RowRange rg_ie = make_range(ielo, iehi), rg_de = make_range(delo, dehi);
+        const OffT* row_mx = Mr + (size_t)sl_x * rs;
+        const OffT* row_mo = Mr + (size_t)sl_oe * rs;
+        const OffT* row_ie = Ir + (size_t)sl_e * rs;
+        const OffT* row_de = Dr + (size_t)sl_e * rs;
+        OffT* out_m = Mr + (size_t)slot_m * rs;
+        OffT* out_i = Ir + (size_t)slot_e * rs;
+        OffT* out_d = Dr + (size_t)slot_e * rs;
+
+        int wmlo = INT_MAX, wmhi = INT_MIN, wilo = INT_MAX, wihi = INT_MIN, wdlo = INT_MAX, wdhi = INT_MIN;
+        bool my_done = false;
+        for (int k0 = lo; k0 <= hi; k0 += NT) {
+          const int kraw = k0 + tid;
+          const bool active = kraw <= hi;
+          const int k = active ? kraw : hi;
+          // recurrences (wavefront_compute_affine.c:66-84)
+          const int m_x = rd_cell(row_mx, kidx0, k, rg_mx);
+          const int m_ol = rd_cell(row_mo, kidx0, k - 1, rg_mo);
+          const int m_or = rd_cell(row_mo, kidx0, k + 1, rg_mo);
+          const int i_e = rd_cell(row_ie, kidx0, k - 1, rg_ie);
+          const int d_e = rd_cell(row_de, kidx0, k + 1, rg_de);
+          const int ins = max(m_ol, i_e) + 1;
+          const int del = max(m_or, d_e);
+          const int mis = m_x + 1;
+          int mv = max(del, max(mis, ins));
+          uint32_t code = 0;
+          if constexpr (BT) {
+            // tie-breaks: gap extension wins over gap open on equal offsets
+            // (wavefront_compute_affine.c:135-143,153-161); for M: mismatch,
+            // then deletion, then insertion (wavefront_backtrace.c:48-59)
+            code = (i_e >= m_ol ? BT_I_EXT : 0u) | (d_e >= m_or ? BT_D_EXT : 0u);
+            code |= (mis == mv) ? BT_M_X : ((del == mv) ? BT_M_D : BT_M_I);
+          }
+          // !(h > tlen || v > plen), unsigned so that negatives fail too
+          const bool ok = ((unsigned)mv <= (unsigned)tlen) && ((unsigned)(mv - k) <= (unsigned)plen);
+          const bool i_ok = have_i && ((unsigned)ins <= (unsigned)tlen) && ((unsigned)(ins - k) <= (unsigned)plen);
+          const bool d_ok = have_d && ((unsigned)del <= (unsigned)tlen) && ((unsigned)(del - k) <= (unsigned)plen);
+          if (ok) {
+            mv = extend_lcp(Pw, Tw, plen, tlen, k, mv);
+          } else {
+            mv = OFF_NULL;
+            if constexpr (BT) code &= ~3u;
+          }
+          if (active) {
+            out_m[kidx0 + k] = off_store<OffT>(mv);
+            if (have_i) out_i[kidx0 + k] = off_store<OffT>(ins);
+            if (have_d) out_d[kidx0 + k] = off_store<OffT>(del);
+            if constexpr (BT) codes[k - lo] = (uint8_t)code;
+            if (k == kend && mv >= tlen) my_done = true;
+          }
+          // trimmed limits = first/last valid cell (wavefront_compute.c:570-603)
+          const int b = k0 + wave * 64;
+          const unsigned long long bm = __ballot(active && ok);
+          const unsigned long long bi = __ballot(active && i_ok);
+          const unsigned long long bd = __ballot(active && d_ok);
+          if (bm) { wmlo = min(wmlo, b + (int)__builtin_ctzll(bm)); wmhi = max(wmhi, b + 63 - (int)__builtin_clzll(bm)); }
+          if (bi) { wilo = min(wilo, b + (int)__builtin_ctzll(bi)); wihi = max(wihi, b + 63 - (int)__builtin_clzll(bi)); }
+          if (bd) { wdlo = min(wdlo, b + (int)__builtin_ctzll(bd)); wdhi = max(wdhi, b + 63 - (int)__builtin_clzll(bd)); }
+        }
+        const bool wave_done = __ballot(my_done) != 0ull;
+
+        if constexpr (NW == 1) {
+          done = wave_done;
+        } else {
+          int* acc = red + 8 * (s % 3);
+          int* nxt = red + 8 * ((s + 1) % 3);
+          if (tid < 8) nxt[tid] = (tid == 6) ? 0 : ((tid & 1) ? INT_MIN : INT_MAX);
+          if (lane == 0) {
+            if (wmlo <= wmhi) { atomicMin(&acc[0], wmlo); atomicMax(&acc[1], wmhi); }
+            if (wilo <= wihi) { atomicMin(&acc[2], wilo); atomicMax(&acc[3], wihi); }
+            if (wdlo <= wdhi) { atomicMin(&acc[4], wdlo); atomicMax(&acc[5], wdhi); }
+            if (wave_done) atomicOr(&acc[6], 1);
+          }
+          __syncthreads();
+          wmlo = acc[0]; wmhi = acc[1]; wilo = acc[2]; wihi = acc[3]; wdlo = acc[4]; wdhi = acc[5];
+          done = acc[6] != 0;
+        }
+        // every thread records the same row metadata (it reads its own copy back)
+        if (wmlo > wmhi) { wmlo = 1; wmhi = -1; }
+        if (wilo > wihi) { wilo = 1; wihi = -1; }
+        if (wdlo > wdhi) { wdlo = 1; wdhi = -1; }
+        mlo[slot_m] = wmlo; mhi[slot_m] = wmhi; btrow[slot_m] = row_s;
+        ilo[slot_e] = wilo; ihi[slot_e] = wihi;
+        dlo[slot_e] = wdlo; dhi[slot_e] = wdhi;
+        if constexpr (NW == 1) block_sync<NW>();
+      }
+      if (tid == 0 && status == WFA_ST_DONE) {
+        if constexpr (BT) p.bt_final_row[pair] = row_s;
+      }
+    }
+    if (tid == 0) {
+      p.score[pair] = (status == WFA_ST_DONE) ? s : -1;
+      p.status[pair] = status;
+      if (p.cells) p.cells[pair] = ncells;
+    }
+    block_sync<NW>();
+  }
+}
+
+template <int NW, bool BT, typename OffT, bool GR>
+void launch_inst(const WfaAlignParams& p, size_t lds, int grid, hipStream_t stream) {
+  auto k = wfa_align_kernel<NW, BT, OffT, GR>;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(NW * 64), lds, stream, p);
+}
+
+template <int NW, bool BT, typename OffT, bool GR>
+int occ_inst(size_t lds) {
+  auto k = wfa_align_kernel<NW, BT, OffT, GR>;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k), NW * 64, lds) != hipSuccess) nb = 0;
+  return nb;
+}
+
+}  // namespace
+
+size_t wfa_align_lds_bytes(const WfaAlignParams& p, int tier) {
+  size_t ring = 0;
+  if (tier != 3) ring = (((size_t)(p.dm + 2 * p.de) * p.rs * sizeof(int16_t)) + 15) & ~(size_t)15;
+  const size_t seq = (size_t)2 * p.seq_words_cap * 4;
+  const size_t meta = (size_t)(2 * p.dm + 4 * p.de + p.dm + 24 + 2) * 4;
+  return ((ring + seq + meta) + 15) & ~(size_t)15;
+}
+
+void wfa_launch_align(const WfaAlignParams& p, int tier, bool with_bt, int grid, hipStream_t stream) {
+  const size_t lds = wfa_align_lds_bytes(p, tier);
+  switch (tier) {
+    case 0:
+      if (with_bt) launch_inst<1, true, int16_t, false>(p, lds, grid, stream);
+      else launch_inst<1, false, int16_t, false>(p, lds, grid, stream);
+      break;
+    case 1:
+      if (with_bt) launch_inst<4, true, int16_t, false>(p, lds, grid, stream);
+      else launch_inst<4, false, int16_t, false>(p, lds, grid, stream);
+      break;
+    case 2:
+      if (with_bt) launch_inst<16, true, int16_t, false>(p, lds, grid, stream);
+      else launch_inst<16, false, int16_t, false>(p, lds, grid, stream);
+      break;
+    default:
+      if (with_bt) launch_inst<16, true, int32_t, true>(p, lds, grid, stream);
+      else launch_inst<16, false, int32_t, true>(p, lds, grid, stream);
+      break;
+  }
+}
+
+int wfa_align_max_blocks_per_cu(int tier, bool with_bt, size_t lds) {
+  switch (tier) {
+    case 0: return with_bt ? occ_inst<1, true, int16_t, false>(lds) : occ_inst<1, false, int16_t, false>(lds);
+    case 1: return with_bt ? occ_inst<4, true, int16_t, false>(lds) : occ_inst<4, false, int16_t, false>(lds);
+    case 2: return with_bt ? occ_inst<16, true, int16_t, false>(lds) : occ_inst<16, false, int16_t, false>(lds);
+    default: return with_bt ? occ_inst<16, true, int32_t, true>(lds) : occ_inst<16, false, int32_t, true>(lds);
+  }
+}

@@ -1,0 +1,199 @@
+// Backtrace + CIGAR emission on the GPU.
+//
+// Replaces, on the device, what the reference does on the host:
+//   * the prev-pointer walk over piggy-backed backtrace blocks
+//     (lib/kernels/sequence_alignment_kernel.cu:659-683) and
+//   * recover_cigar_affine / insert_ops (utils/cigar.c:31-61,96-272), which
+//     re-extends matches on the ASCII text between recorded operations.
+// The output string is what WFA2's cigar_sprint(print_matches=true) prints
+// (external/WFA/alignment/cigar.c:394-426): run-length "nM nX nI nD" items.
+//
+// One lane per alignment.  Phase 1 walks the origin bytes written by the
+// align kernel backwards (row headers link score s to s-x / s-o-e / s-e) and
+// pushes one byte per edit operation.  Phase 2 replays the operations
+// forwards, re-deriving every match run as a longest-common-prefix on the
+// packed sequences -- identical to the extension the forward pass did, so no
+// offsets had to be stored -- first to size the text, then to write it.
+// Scratch and text space come from wave-aggregated bump allocations (one
+// atomic per wavefront), so the text arena is dense and can be copied to the
+// host in one piece.
+#include "wfa_device.h"
+
+namespace {
+
+enum : uint8_t { OP_X = 1, OP_I = 2, OP_D = 3, OP_EXT_AFTER = 0x10 };
+
+__device__ __forceinline__ int lcp_packed(const uint32_t* __restrict__ Pw,
+                                          const uint32_t* __restrict__ Tw, int plen, int tlen,
+                                          int v, int h) {
+  int n_total = 0;
+  int rem = min(plen - v, tlen - h);
+  while (rem > 0) {
+    const int pi = v >> 4, ti = h >> 4;
+    const uint32_t a = __builtin_amdgcn_alignbit(Pw[pi + 1], Pw[pi], (v & 15) << 1);
+    const uint32_t b = __builtin_amdgcn_alignbit(Tw[ti + 1], Tw[ti], (h & 15) << 1);
+    const uint32_t d = a ^ b;
+    int n = d ? (__builtin_ctz(d) >> 1) : 16;
+    n = min(n, rem);
+    n_total += n; h += n; v += n; rem -= n;
+    if (n < 16) break;
+  }
+  return n_total;
+}
+
+__device__ __forceinline__ unsigned long long shfl64(unsigned long long v, int src) {
+  const uint32_t lo = __shfl((uint32_t)v, src), hi = __shfl((uint32_t)(v >> 32), src);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+// All 64 lanes must call.  Returns this lane's byte offset.
+__device__ __forceinline__ unsigned long long wave_alloc(unsigned long long* top, uint32_t need, int lane) {
+  uint32_t incl = need;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t t = __shfl_up(incl, d);
+    if (lane >= d) incl += t;
+  }
+  const uint32_t total = __shfl(incl, 63);
+  unsigned long long base = 0;
+  if (lane == 63 && total) base = atomicAdd(top, (unsigned long long)total);
+  base = shfl64(base, 63);
+  return base + incl - need;
+}
+
+__device__ __forceinline__ int dec_digits(uint32_t n) {
+  return n < 10 ? 1 : n < 100 ? 2 : n < 1000 ? 3 : n < 10000 ? 4 : n < 100000 ? 5 : 6;
+}
+
+struct RleSink {
+  char* out;      // nullptr: count only
+  uint32_t len;
+  uint32_t run;
+  char op;
+  __device__ __forceinline__ void flush() {
+    if (run == 0) return;
+    const int nd = dec_digits(run);
+    if (out) {
+      uint32_t r = run;
+      for (int i = nd - 1; i >= 0; --i) { out[len + i] = (char)('0' + r % 10); r /= 10; }
+      out[len + nd] = op;
+    }
+    len += (uint32_t)nd + 1;
+    run = 0;
+  }
+  __device__ __forceinline__ void push(char o, uint32_t n) {
+    if (n == 0) return;
+    if (o != op) { flush(); op = o; }
+    run += n;
+  }
+};
+
+__device__ __forceinline__ uint32_t replay(const uint8_t* ops, uint32_t nops,
+                                           const uint32_t* Pw, const uint32_t* Tw,
+                                           int plen, int tlen, char* out) {
+  RleSink sink{out, 0, 0, 0};
+  int v = 0, h = 0;
+  int n = lcp_packed(Pw, Tw, plen, tlen, v, h);
+  sink.push('M', (uint32_t)n); v += n; h += n;
+  for (uint32_t i = 0; i < nops; ++i) {
+    const uint8_t op = ops[i];
+    switch (op & 3) {
+      case OP_X: sink.push('X', 1); ++v; ++h; break;
+      case OP_I: sink.push('I', 1); ++h; break;
+      default:   sink.push('D', 1); ++v; break;
+    }
+    if (op & OP_EXT_AFTER) {
+      n = lcp_packed(Pw, Tw, plen, tlen, v, h);
+      sink.push('M', (uint32_t)n); v += n; h += n;
+    }
+  }
+  sink.flush();
+  if (out) out[sink.len] = '\0';
+  // a consistent trace ends exactly at the corner
+  return (v == plen && h == tlen) ? sink.len : 0xFFFFFFFFu;
+}
+
+constexpr int TRACE_THREADS = 64;
+
+__global__ void __launch_bounds__(TRACE_THREADS) wfa_trace_kernel(const WfaTraceParams p) {
+  const uint32_t gid = blockIdx.x * TRACE_THREADS + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  bool active = gid < p.n_work;
+  uint32_t pair = 0;
+  if (active) pair = p.work ? p.work[gid] : gid;
+  if (active && p.status[pair] != WFA_ST_DONE) active = false;
+
+  int score = 0, plen = 0, tlen = 0;
+  const uint32_t* Pw = nullptr; const uint32_t* Tw = nullptr;
+  if (active) {
+    score = p.score[pair];
+    const WfaSeqPair mp = p.meta[pair];
+    plen = (int)mp.pattern_len; tlen = (int)mp.text_len;
+    Pw = p.packed + (mp.pattern_offset_packed >> 2);
+    Tw = p.packed + (mp.text_offset_packed >> 2);
+  }
+  // ---- phase 1: backward walk ---------------------------------------------
+  // every operation costs at least min(x, e) >= 1, so `score` bytes suffice
+  const uint32_t need_ops = active ? (((uint32_t)score + 3u) & ~3u) : 0u;
+  const unsigned long long ops_off = wave_alloc(p.ops_top, need_ops, lane);
+  bool fail = active && (ops_off + need_ops > p.ops_cap);
+  uint8_t* q_end = p.ops + ops_off + need_ops;
+  uint8_t* q = q_end;
+  if (active && !fail) {
+    uint32_t row = p.bt_final_row[pair];
+    int k = tlen - plen, s = score;
+    int state = 0;  // 0: M, 1: I, 2: D
+    while (s > 0) {
+      if (row == WFA_ROW_NONE || q == p.ops + ops_off) { fail = true; break; }
+      const uint8_t* rp = p.arena + (size_t)row * 16;
+      const uint4 hdr = *reinterpret_cast<const uint4*>(rp);
+      const uint32_t code = rp[16 + (k - (int)hdr.x)];
+      if (state == 0) {
+        const uint32_t org = code & 3u;
+        if (org == BT_M_X) { *--q = OP_X | OP_EXT_AFTER; row = hdr.y; s -= p.x; }
+        else if (org == BT_M_I) {
+          *--q = OP_I | OP_EXT_AFTER; --k;
+          if (code & BT_I_EXT) { row = hdr.w; s -= p.e; state = 1; } else { row = hdr.z; s -= p.oe; }
+        } else if (org == BT_M_D) {
+          *--q = OP_D | OP_EXT_AFTER; ++k;
+          if (code & BT_D_EXT) { row = hdr.w; s -= p.e; state = 2; } else { row = hdr.z; s -= p.oe; }
+        } else { fail = true; break; }
+      } else if (state == 1) {
+        *--q = OP_I; --k;
+        if (code & BT_I_EXT) { row = hdr.w; s -= p.e; } else { row = hdr.z; s -= p.oe; state = 0; }
+      } else {
+        *--q = OP_D; ++k;
+        if (code & BT_D_EXT) { row = hdr.w; s -= p.e; } else { row = hdr.z; s -= p.oe; state = 0; }
+      }
+    }
+    if (s != 0 || state != 0 || k != 0) fail = true;
+  }
+  const uint32_t nops = (uint32_t)(q_end - q);
+  // ---- phase 2: forward replay, size then write ------------------------------
+  uint32_t len = 0;
+  if (active && !fail) {
+    len = replay(q, nops, Pw, Tw, plen, tlen, nullptr);
+    if (len == 0xFFFFFFFFu) fail = true;
+  }
+  const uint32_t need_txt = (active && !fail) ? len + 1u : 0u;
+  const unsigned long long txt_off = wave_alloc(p.text_top, need_txt, lane);
+  if (active && !fail && txt_off + need_txt > p.text_cap) fail = true;
+  if (active) {
+    if (!fail) {
+      replay(q, nops, Pw, Tw, plen, tlen, p.text + txt_off);
+      p.cigar_off[pair] = txt_off;
+      p.cigar_len[pair] = len;
+    } else {
+      p.cigar_off[pair] = 0;
+      p.cigar_len[pair] = 0xFFFFFFFFu;
+    }
+  }
+}
+
+}  // namespace
+
+void wfa_launch_trace(const WfaTraceParams& p, hipStream_t stream) {
+  if (p.n_work == 0) return;
+  const uint32_t grid = (p.n_work + TRACE_THREADS - 1) / TRACE_THREADS;
+  hipLaunchKernelGGL(wfa_trace_kernel, dim3(grid), dim3(TRACE_THREADS), 0, stream, p);
+}

@@ -1,0 +1,112 @@
+// Shared device/host definitions for the gfx950 WFA kernels.
+//
+// Data layout in HBM (see DESIGN.md "Data layout"):
+//   * ASCII input:   the reference's padded buffer + 48-byte sequence_pair_t
+//                    records (utils/sequences.h:28-36 of the reference).
+//   * Packed input:  2 bits/base, code=(c&6)>>1, 16 bases per 32-bit word,
+//                    base i of a sequence in bits [2*(i%16)+1 : 2*(i%16)]
+//                    (little-endian inside the word so one v_alignbit_b32
+//                    yields the 16 bases starting at any position).
+//   * Backtrace arena: rows of {16-byte header, one origin byte per diagonal},
+//                    bump-allocated in 16-byte units, linked backwards by
+//                    the header (no per-alignment worst-case reservation).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// Mirror of the reference ABI struct sequence_pair_t (utils/sequences.h:28-36).
+struct WfaSeqPair {
+  size_t text_offset;
+  size_t pattern_offset;
+  size_t text_offset_packed;
+  size_t pattern_offset_packed;
+  unsigned int text_len;
+  unsigned int pattern_len;
+  bool has_N;
+};
+static_assert(sizeof(WfaSeqPair) == 48, "sequence_pair_t ABI");
+
+// Per-pair status written by the align kernels.
+enum : uint32_t {
+  WFA_ST_PENDING = 0,    // not processed yet
+  WFA_ST_DONE = 1,       // score (and backtrace rows) valid
+  WFA_ST_BAND = 2,       // wavefront left the tier's diagonal capacity -> next tier
+  WFA_ST_SCORE = 3,      // score went past the tier's score limit        -> next tier
+  WFA_ST_NOMEM = 4,      // backtrace arena exhausted                     -> next sub-batch
+  WFA_ST_ALPHABET = 5,   // pair holds bytes outside ACGT                 -> byte-compare tier
+};
+
+// Origin byte per wavefront cell (what the backtrace needs, 4 bits used):
+//   bits 1:0  source of M : 0 none (cell not valid), 1 mismatch, 2 insertion, 3 deletion
+//   bit  2    I came from I (gap extension) rather than from M (gap open)
+//   bit  3    D came from D (gap extension) rather than from M (gap open)
+enum : uint32_t { BT_M_NONE = 0, BT_M_X = 1, BT_M_I = 2, BT_M_D = 3, BT_I_EXT = 4, BT_D_EXT = 8 };
+
+#define WFA_ROW_NONE 0xFFFFFFFFu
+
+// Row header in the backtrace arena (16 bytes = one allocation unit).
+struct WfaBtRowHdr {
+  int32_t lo;          // diagonal of codes[0]
+  uint32_t prev_x;     // unit offset of row s-x     (WFA_ROW_NONE if that score has no wavefront)
+  uint32_t prev_oe;    // unit offset of row s-(o+e)
+  uint32_t prev_e;     // unit offset of row s-e
+};
+
+struct WfaAlignParams {
+  const uint32_t* packed;        // packed sequences (word base)
+  const WfaSeqPair* meta;
+  const uint32_t* work;          // pair indices to process (NULL: identity)
+  uint32_t n_work;
+  unsigned int* work_counter;    // dynamic work distribution (zeroed before launch)
+  int x, oe, e;                  // penalties: mismatch, open+extend, extend
+  int dm, de;                    // ring depths: max(x,oe)+1 rows of M, e+1 rows of I and D
+  int hcap;                      // diagonals supported: k in [-hcap, +hcap]
+  int rs;                        // row stride (elements), even, >= 2*hcap+3
+  int max_score;                 // give up (WFA_ST_SCORE) beyond this score
+  int seq_words_cap;             // LDS words reserved per packed sequence
+  int32_t* score;                // [pair] out
+  uint32_t* status;              // [pair] out
+  uint32_t* cells;               // [pair] out, optional: number of wavefront cells computed
+  // backtrace (CIGAR mode)
+  uint8_t* arena;                // base of the arena
+  unsigned long long arena_units;        // capacity in 16-byte units
+  unsigned long long* arena_top;         // bump pointer (units)
+  uint32_t chunk_units;          // refill granularity
+  uint32_t* bt_final_row;        // [pair] out: unit offset of the last row
+  // global-memory ring (only the GLOBAL_RING instantiation)
+  void* gring;                   // per-block slices of gring_stride bytes
+  unsigned long long gring_stride;
+};
+
+struct WfaTraceParams {
+  const uint32_t* packed;
+  const WfaSeqPair* meta;
+  const uint32_t* work;          // pair indices (NULL: identity)
+  uint32_t n_work;
+  int x, oe, e;
+  const int32_t* score;
+  const uint32_t* status;
+  const uint8_t* arena;
+  const uint32_t* bt_final_row;
+  // scratch for the reversed op list, bump allocated (bytes)
+  uint8_t* ops;
+  unsigned long long ops_cap;
+  unsigned long long* ops_top;
+  // output text arena
+  char* text;
+  unsigned long long text_cap;
+  unsigned long long* text_top;
+  unsigned long long* cigar_off; // [pair] out: byte offset of the CIGAR in `text`
+  uint32_t* cigar_len;           // [pair] out: strlen; 0xFFFFFFFF if it did not fit
+};
+
+// Host-side launchers (one per translation unit).
+void wfa_launch_pack(const char* d_ascii, const WfaSeqPair* d_meta, uint32_t n_pairs,
+                     uint32_t* d_packed, uint8_t* d_flags, hipStream_t stream);
+// tier: 0 -> 1 wave/alignment (LDS ring), 1 -> 4 waves (LDS), 2 -> 16 waves (LDS),
+//       3 -> 16 waves, int32 ring in HBM.  Returns the dynamic LDS bytes used.
+size_t wfa_align_lds_bytes(const WfaAlignParams& p, int tier);
+void wfa_launch_align(const WfaAlignParams& p, int tier, bool with_bt, int grid, hipStream_t stream);
+int wfa_align_max_blocks_per_cu(int tier, bool with_bt, size_t lds_bytes);
+void wfa_launch_trace(const WfaTraceParams& p, hipStream_t stream);

@@ -1,0 +1,478 @@
+// Host side of the device-resident entry points (include/wfa_gpu_device.h):
+// context, buffer management, the tier-escalation driver and timing.
+//
+// Replaces the reference's launch/memory layer (lib/sequence_alignment.cu:31-470,
+// lib/sequence_packing.cu:96-116) and the per-batch body of its orchestrator
+// (lib/align.cu:177-385).  Differences that matter:
+//   * a pair the first kernel tier cannot finish (score past max_error, or a
+//     wavefront wider than the tier's LDS ring) is re-queued ON THE DEVICE
+//     into a wider tier; the reference recomputed it on the CPU
+//     (utils/wfa_cpu.c:59-84).  There is no CPU compute path in this library.
+//   * backtrace memory is a bump arena shared by all workgroups; if a batch
+//     outgrows it the unfinished pairs run in a further pass after the
+//     finished ones have been traced (the reference sized per-worker arenas
+//     from max_error^2 and aborted beyond 2^32 elements,
+//     lib/sequence_alignment.cu:36-42).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <climits>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/wfa_gpu_device.h"
+#include "wfa_device.h"
+
+static_assert(sizeof(sequence_pair_t) == sizeof(WfaSeqPair), "ABI mirror");
+
+#define HIP_TRY(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess) {                                                             \
+      fprintf(stderr, "[!] ERROR: HIP %s failed: %s (%s:%d)\n", #expr,                  \
+              hipGetErrorString(_e), __FILE__, __LINE__);                               \
+      return -1;                                                                        \
+    }                                                                                   \
+  } while (0)
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes, hipStream_t stream, size_t preserve = 0) {
+    if (bytes <= cap) return 0;
+    size_t ncap = std::max(bytes, cap + cap / 2);
+    void* np = nullptr;
+    if (hipMalloc(&np, ncap) != hipSuccess) {
+      // retry with the exact size
+      ncap = bytes;
+      hipError_t e = hipMalloc(&np, ncap);
+      if (e != hipSuccess) {
+        fprintf(stderr, "[!] ERROR: hipMalloc(%zu) failed: %s\n", ncap, hipGetErrorString(e));
+        return -1;
+      }
+    }
+    if (p && preserve) hipMemcpyAsync(np, p, preserve, hipMemcpyDeviceToDevice, stream);
+    if (p) { hipStreamSynchronize(stream); hipFree(p); }
+    p = np; cap = ncap;
+    return 0;
+  }
+  void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
+};
+
+// device counters (u64 slots)
+enum { CT_ARENA = 0, CT_OPS = 1, CT_TEXT = 2, CT_WORK = 3, CT_LIST = 4, CT_SUM_OPS = 5, CT_SUM_TEXT = 6, CT_CELLS = 7, CT_N = 8 };
+
+constexpr uint32_t MASK(uint32_t st) { return 1u << st; }
+
+// pairs of `work` whose status is in `mask` -> out list (wave-aggregated append)
+__global__ void k_compact(const uint32_t* __restrict__ work, uint32_t n, const uint32_t* __restrict__ status,
+                          uint32_t mask, uint32_t* __restrict__ out, unsigned long long* __restrict__ out_count) {
+  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  bool take = false; uint32_t pair = 0;
+  if (gid < n) { pair = work ? work[gid] : gid; take = (mask >> status[pair]) & 1u; }
+  const unsigned long long bal = __ballot(take);
+  if (!bal) return;
+  unsigned long long base = 0;
+  const int leader = __builtin_ctzll(bal);
+  if (lane == leader) base = atomicAdd(out_count, (unsigned long long)__builtin_popcountll(bal));
+  const uint32_t blo = __shfl((uint32_t)base, leader), bhi = __shfl((uint32_t)(base >> 32), leader);
+  base = ((unsigned long long)bhi << 32) | blo;
+  if (take) out[base + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = pair;
+}
+
+// flagged (non-ACGT) pairs never enter the 2-bit tiers
+__global__ void k_flag_alphabet(const uint8_t* __restrict__ flags, uint32_t n, uint32_t* __restrict__ status) {
+  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid < n && (flags[2 * gid] | flags[2 * gid + 1])) status[gid] = WFA_ST_ALPHABET;
+}
+
+// bounds for the trace scratch: sum over finished pairs of the op-list and
+// text sizes; also the total of computed cells
+__global__ void k_trace_bounds(const uint32_t* __restrict__ work, uint32_t n, const uint32_t* __restrict__ status,
+                               const int32_t* __restrict__ score, const uint32_t* __restrict__ cells, int min_op_cost,
+                               unsigned long long* __restrict__ ct) {
+  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long ops = 0, txt = 0, cl = 0;
+  if (gid < n) {
+    const uint32_t pair = work ? work[gid] : gid;
+    if (status[pair] == WFA_ST_DONE) {
+      const uint32_t s = (uint32_t)score[pair];
+      ops = (s + 3u) & ~3u;
+      const uint32_t m = s / (uint32_t)min_op_cost;
+      txt = 6ull * (2ull * m + 1ull) + 1ull;
+    }
+    if (cells && status[pair] != WFA_ST_PENDING) cl = cells[pair];
+  }
+  for (int d = 32; d > 0; d >>= 1) {
+    ops += __shfl_down((unsigned long long)ops, d);
+    txt += __shfl_down((unsigned long long)txt, d);
+    cl += __shfl_down((unsigned long long)cl, d);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (ops) atomicAdd(&ct[CT_SUM_OPS], ops);
+    if (txt) atomicAdd(&ct[CT_SUM_TEXT], txt);
+    if (cl) atomicAdd(&ct[CT_CELLS], cl);
+  }
+}
+
+__global__ void k_set_pending(const uint32_t* __restrict__ work, uint32_t n, uint32_t* __restrict__ status) {
+  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid < n) status[work ? work[gid] : gid] = WFA_ST_PENDING;
+}
+
+inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+}  // namespace
+
+struct wfagpu_amd_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int num_cus = 0;
+  size_t lds_per_block_max = 0;
+  size_t arena_cfg = 0, text_cfg = 0;
+  DevBuf packed, flags, status, cells, bt_final, list_a, list_b, list_c, list_d, counters, arena, ops, text, cig_off, cig_len, gring;
+  unsigned long long* h_counters = nullptr;  // pinned
+  hipEvent_t ev_start = nullptr, ev_pack = nullptr, ev_a0 = nullptr, ev_a1 = nullptr, ev_t0 = nullptr, ev_t1 = nullptr, ev_end = nullptr;
+  wfagpu_amd_stats_t stats{};
+};
+
+extern "C" {
+
+int wfagpu_amd_create(wfagpu_amd_ctx_t** out, const wfagpu_amd_config_t* cfg) {
+  if (!out) return -1;
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  const int dev = cfg ? cfg->device : 0;
+  if (dev < 0 || dev >= ndev) {
+    fprintf(stderr, "[!] ERROR: HIP device %d not available (%d visible)\n", dev, ndev);
+    return -1;
+  }
+  HIP_TRY(hipSetDevice(dev));
+  wfagpu_amd_ctx* c = new wfagpu_amd_ctx();
+  c->device = dev;
+  if (cfg && cfg->stream) {
+    c->stream = static_cast<hipStream_t>(cfg->stream);
+  } else {
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+  }
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, dev));
+  c->num_cus = prop.multiProcessorCount;
+  c->lds_per_block_max = prop.sharedMemPerBlock;   // 160 KiB on gfx950 (checked, not assumed)
+  c->arena_cfg = cfg ? cfg->arena_bytes : 0;
+  c->text_cfg = cfg ? cfg->text_bytes : 0;
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_counters), CT_N * sizeof(unsigned long long), hipHostMallocDefault));
+  HIP_TRY(hipEventCreate(&c->ev_start)); HIP_TRY(hipEventCreate(&c->ev_pack));
+  HIP_TRY(hipEventCreate(&c->ev_a0)); HIP_TRY(hipEventCreate(&c->ev_a1));
+  HIP_TRY(hipEventCreate(&c->ev_t0)); HIP_TRY(hipEventCreate(&c->ev_t1));
+  HIP_TRY(hipEventCreate(&c->ev_end));
+  if (c->counters.ensure(CT_N * sizeof(unsigned long long), c->stream)) return -1;
+  *out = c;
+  return 0;
+}
+
+void wfagpu_amd_destroy(wfagpu_amd_ctx_t* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  for (DevBuf* b : {&c->packed, &c->flags, &c->status, &c->cells, &c->bt_final, &c->list_a, &c->list_b, &c->list_c, &c->list_d,
+                    &c->counters, &c->arena, &c->ops, &c->text, &c->cig_off, &c->cig_len, &c->gring})
+    b->release();
+  if (c->h_counters) hipHostFree(c->h_counters);
+  for (hipEvent_t ev : {c->ev_start, c->ev_pack, c->ev_a0, c->ev_a1, c->ev_t0, c->ev_t1, c->ev_end})
+    if (ev) hipEventDestroy(ev);
+  if (c->own_stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+size_t wfagpu_amd_fill_packed_offsets(sequence_pair_t* metadata, size_t n) {
+  size_t off = 0;
+  for (size_t i = 0; i < n; ++i) {
+    metadata[i].pattern_offset_packed = off;
+    off += 4 * (((size_t)metadata[i].pattern_len + 15) / 16 + 1);
+    metadata[i].text_offset_packed = off;
+    off += 4 * (((size_t)metadata[i].text_len + 15) / 16 + 1);
+  }
+  return off;
+}
+
+int wfagpu_amd_pack_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_batch_t* b, void* d_packed, unsigned char* d_flags) {
+  if (!c || !b || !d_packed || !d_flags) return -1;
+  HIP_TRY(hipSetDevice(c->device));
+  wfa_launch_pack(b->d_sequences, reinterpret_cast<const WfaSeqPair*>(b->d_metadata), (uint32_t)b->num_pairs,
+                  static_cast<uint32_t*>(d_packed), d_flags, c->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+void wfagpu_amd_last_stats(const wfagpu_amd_ctx_t* c, wfagpu_amd_stats_t* out) {
+  if (c && out) *out = c->stats;
+}
+
+}  // extern "C"
+
+namespace {
+
+struct TierPlan { int tier; int hcap; int max_score; size_t lds; int blocks_per_cu; };
+
+// Smallest tier whose LDS footprint fits for `hcap` diagonals each side.
+bool plan_tier(const wfagpu_amd_ctx* c, WfaAlignParams& p, int hcap, int max_score, unsigned max_seq_len, bool bt, TierPlan* out) {
+  p.hcap = hcap;
+  p.rs = (2 * hcap + 3 + 1) & ~1;
+  p.max_score = max_score;
+  const bool i16_ok = max_seq_len <= 32766u && max_score <= 30000;
+  const size_t budget[3] = {40u << 10, 80u << 10, c->lds_per_block_max};
+  // a single wavefront sweeps up to ~8 chunks per score before more waves pay off
+  const int width = 2 * hcap + 1;
+  for (int t = 0; t < 3 && i16_ok; ++t) {
+    const size_t lds = wfa_align_lds_bytes(p, t);
+    if (lds > budget[t]) continue;
+    if (t == 0 && width > 1024) continue;
+    if (t == 1 && width > 8192) continue;
+    const int nb = wfa_align_max_blocks_per_cu(t, bt, lds);
+    if (nb < 1) continue;
+    *out = {t, hcap, max_score, lds, nb};
+    return true;
+  }
+  const size_t lds = wfa_align_lds_bytes(p, 3);
+  if (lds > c->lds_per_block_max) return false;   // sequences themselves do not fit LDS
+  const int nb = wfa_align_max_blocks_per_cu(3, bt, lds);
+  *out = {3, hcap, max_score, lds, std::max(1, std::min(nb, 2))};
+  return true;
+}
+
+int read_counters(wfagpu_amd_ctx* c) {
+  HIP_TRY(hipMemcpyAsync(c->h_counters, c->counters.p, CT_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int zero_counter(wfagpu_amd_ctx* c, int idx, int count = 1) {
+  HIP_TRY(hipMemsetAsync(static_cast<unsigned long long*>(c->counters.p) + idx, 0, sizeof(unsigned long long) * count, c->stream));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_batch_t* b,
+                                       affine_penalties_t pen, int max_error, int band,
+                                       bool compute_cigar, int32_t* d_scores,
+                                       const char** d_text, const unsigned long long** d_off,
+                                       const unsigned int** d_len) {
+  if (!c || !b || !d_scores) return -1;
+  if (pen.x <= 0 || pen.o < 0 || pen.e <= 0) {
+    fprintf(stderr, "[!] ERROR: penalties must be x>0, o>=0, e>0 (got %d,%d,%d)\n", pen.x, pen.o, pen.e);
+    return -1;
+  }
+  (void)band;  // adaptive band: not implemented in this round (exact search is always valid)
+  HIP_TRY(hipSetDevice(c->device));
+  const uint32_t n = (uint32_t)b->num_pairs;
+  c->stats = wfagpu_amd_stats_t{};
+  if (d_text) *d_text = nullptr;
+  if (d_off) *d_off = nullptr;
+  if (d_len) *d_len = nullptr;
+  if (n == 0) return 0;
+  if (max_error < 1) max_error = 1;
+  hipStream_t st = c->stream;
+  unsigned long long* ct = static_cast<unsigned long long*>(c->counters.p);
+
+  // ---- buffers ------------------------------------------------------------
+  if (c->packed.ensure(b->packed_bytes + 16, st)) return -1;
+  if (c->flags.ensure((size_t)2 * n, st)) return -1;
+  if (c->status.ensure((size_t)4 * n, st)) return -1;
+  if (c->cells.ensure((size_t)4 * n, st)) return -1;
+  if (c->list_a.ensure((size_t)4 * n, st)) return -1;
+  if (c->list_b.ensure((size_t)4 * n, st)) return -1;
+  if (c->list_c.ensure((size_t)4 * n, st)) return -1;
+  if (c->list_d.ensure((size_t)4 * n, st)) return -1;
+  if (compute_cigar) {
+    if (c->bt_final.ensure((size_t)4 * n, st)) return -1;
+    if (c->cig_off.ensure((size_t)8 * n, st)) return -1;
+    if (c->cig_len.ensure((size_t)4 * n, st)) return -1;
+  }
+  const unsigned max_len = std::max(1u, b->max_seq_len);
+  const int oe = pen.o + pen.e;
+
+  WfaAlignParams ap{};
+  ap.packed = static_cast<const uint32_t*>(c->packed.p);
+  ap.meta = reinterpret_cast<const WfaSeqPair*>(b->d_metadata);
+  ap.x = pen.x; ap.oe = oe; ap.e = pen.e;
+  ap.dm = std::max(pen.x, oe) + 1;
+  ap.de = pen.e + 1;
+  ap.seq_words_cap = (int)((max_len + 15) / 16 + 1);
+  ap.score = d_scores;
+  ap.status = static_cast<uint32_t*>(c->status.p);
+  ap.cells = static_cast<uint32_t*>(c->cells.p);
+  ap.work_counter = reinterpret_cast<unsigned int*>(ct + CT_WORK);
+  ap.arena_top = ct + CT_ARENA;
+  ap.chunk_units = 256;   // 4 KiB refills
+  ap.bt_final_row = static_cast<uint32_t*>(c->bt_final.p);
+
+  if (compute_cigar) {
+    // arena: expected need, bounded by configuration / free memory / 32-bit unit addressing
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    size_t want = c->arena_cfg;
+    if (!want) {
+      const double h = std::min<double>(max_error, max_len);
+      const double per_pair = (h + 1) * (h + 1) + 16.0 * max_error + 8192.0;
+      want = (size_t)std::min<double>(per_pair * n, 0.45 * (double)(free_b + c->arena.cap));
+      want = std::max<size_t>(want, (size_t)64 << 20);
+    }
+    want = std::min<size_t>(want, ((size_t)1 << 36) - 4096);
+    if (c->arena.cap < want && c->arena.ensure(want, st)) return -1;
+    ap.arena = static_cast<uint8_t*>(c->arena.p);
+    ap.arena_units = c->arena.cap / 16;
+  }
+
+  HIP_TRY(hipMemsetAsync(c->status.p, 0, (size_t)4 * n, st));
+  HIP_TRY(hipMemsetAsync(c->counters.p, 0, CT_N * sizeof(unsigned long long), st));
+  HIP_TRY(hipEventRecord(c->ev_start, st));
+  wfa_launch_pack(b->d_sequences, ap.meta, n, static_cast<uint32_t*>(c->packed.p), static_cast<uint8_t*>(c->flags.p), st);
+  hipLaunchKernelGGL(k_flag_alphabet, dim3(cdiv(n, 256)), dim3(256), 0, st, static_cast<const uint8_t*>(c->flags.p), n,
+                     static_cast<uint32_t*>(c->status.p));
+  HIP_TRY(hipEventRecord(c->ev_pack, st));
+
+  // pending list of this call: everything not flagged
+  uint32_t* pending = static_cast<uint32_t*>(c->list_c.p);
+  hipLaunchKernelGGL(k_compact, dim3(cdiv(n, 256)), dim3(256), 0, st, (const uint32_t*)nullptr, n,
+                     static_cast<const uint32_t*>(c->status.p), MASK(WFA_ST_PENDING), pending, ct + CT_LIST);
+  if (read_counters(c)) return -1;
+  uint32_t n_pending = (uint32_t)c->h_counters[CT_LIST];
+  const uint32_t n_alpha = n - n_pending;
+
+  float align_ms = 0.f, trace_ms = 0.f;
+  unsigned long long text_used = 0;
+  const int hmax = (int)std::min<unsigned>(max_len, INT_MAX / 4);
+  int rc = 0;
+
+  while (n_pending > 0) {
+    c->stats.sub_batches++;
+    // ---- forward pass with tier escalation ----------------------------------
+    if (zero_counter(c, CT_ARENA)) return -1;
+    uint32_t* cur = pending;
+    uint32_t n_cur = n_pending;
+    uint32_t* spare[2] = {static_cast<uint32_t*>(c->list_a.p), static_cast<uint32_t*>(c->list_b.p)};
+    int flip = 0;
+    int hcap = std::min<int>(std::min<int>(max_error, hmax), INT_MAX / 4);
+    int max_score = max_error;
+    for (int round = 0; n_cur > 0; ++round) {
+      TierPlan tp;
+      if (!plan_tier(c, ap, hcap, max_score, max_len, compute_cigar, &tp)) {
+        fprintf(stderr, "[!] ERROR: sequences of %u bases do not fit the LDS staging area\n", max_len);
+        return -1;
+      }
+      if (tp.tier == 3) {
+        const size_t stride = (((size_t)(ap.dm + 2 * ap.de) * ap.rs * 4) + 255) & ~(size_t)255;
+        const int grid = (int)std::min<uint32_t>(n_cur, (uint32_t)(c->num_cus * tp.blocks_per_cu));
+        if (c->gring.ensure(stride * grid, st)) return -1;
+        ap.gring = c->gring.p; ap.gring_stride = stride;
+      }
+      if (round == 0 && c->stats.sub_batches == 1) { c->stats.lds_bytes_tier0 = tp.lds; c->stats.blocks_per_cu_tier0 = tp.blocks_per_cu; }
+      ap.work = cur; ap.n_work = n_cur;
+      const int grid = (int)std::min<uint32_t>(n_cur, (uint32_t)(c->num_cus * tp.blocks_per_cu));
+      if (zero_counter(c, CT_WORK, 2)) return -1;   // work counter + list counter
+      HIP_TRY(hipEventRecord(c->ev_a0, st));
+      wfa_launch_align(ap, tp.tier, compute_cigar, grid, st);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipEventRecord(c->ev_a1, st));
+      uint32_t* nxt = spare[flip]; flip ^= 1;
+      hipLaunchKernelGGL(k_compact, dim3(cdiv(n_cur, 256)), dim3(256), 0, st, (const uint32_t*)cur, n_cur,
+                         static_cast<const uint32_t*>(c->status.p), MASK(WFA_ST_BAND) | MASK(WFA_ST_SCORE), nxt, ct + CT_LIST);
+      if (read_counters(c)) return -1;
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, c->ev_a0, c->ev_a1));
+      align_ms += ms;
+      c->stats.align_launches++;
+      const uint32_t n_next = (uint32_t)c->h_counters[CT_LIST];
+      c->stats.pairs_tier[tp.tier] += n_cur - n_next;
+      if (round == 0) c->stats.pairs_retried += n_next;
+      if (n_next == 0) break;
+      if (tp.tier == 3 && hcap >= hmax && max_score == INT_MAX) {
+        fprintf(stderr, "[!] ERROR: %u alignments did not finish in the unbounded tier\n", n_next);
+        return -1;
+      }
+      cur = nxt; n_cur = n_next;
+      // widen: 4x the diagonals, no score limit beyond what 16-bit offsets allow
+      hcap = (hcap >= hmax / 4) ? hmax : hcap * 4;
+      max_score = (max_score == 30000 || max_len > 32766u) ? INT_MAX : 30000;
+    }
+    // ---- backtrace + CIGAR for everything that finished in this pass ---------
+    if (zero_counter(c, CT_SUM_OPS, 2)) return -1;
+    if (zero_counter(c, CT_OPS)) return -1;
+    hipLaunchKernelGGL(k_trace_bounds, dim3(cdiv(n_pending, 256)), dim3(256), 0, st, (const uint32_t*)pending, n_pending,
+                       static_cast<const uint32_t*>(c->status.p), (const int32_t*)d_scores,
+                       static_cast<const uint32_t*>(c->cells.p), std::min(pen.x, pen.e), ct);
+    if (read_counters(c)) return -1;
+    if (compute_cigar) {
+      const unsigned long long ops_need = c->h_counters[CT_SUM_OPS] + 256;
+      const unsigned long long text_need = text_used + c->h_counters[CT_SUM_TEXT] + 256;
+      if (c->ops.ensure(ops_need, st)) return -1;
+      if (c->text.ensure(std::max<size_t>(text_need, c->text_cfg), st, text_used)) return -1;
+      WfaTraceParams tp{};
+      tp.packed = ap.packed; tp.meta = ap.meta; tp.work = pending; tp.n_work = n_pending;
+      tp.x = pen.x; tp.oe = oe; tp.e = pen.e;
+      tp.score = d_scores; tp.status = static_cast<const uint32_t*>(c->status.p);
+      tp.arena = ap.arena; tp.bt_final_row = ap.bt_final_row;
+      tp.ops = static_cast<uint8_t*>(c->ops.p); tp.ops_cap = c->ops.cap; tp.ops_top = ct + CT_OPS;
+      tp.text = static_cast<char*>(c->text.p); tp.text_cap = c->text.cap; tp.text_top = ct + CT_TEXT;
+      tp.cigar_off = static_cast<unsigned long long*>(c->cig_off.p);
+      tp.cigar_len = static_cast<uint32_t*>(c->cig_len.p);
+      HIP_TRY(hipEventRecord(c->ev_t0, st));
+      wfa_launch_trace(tp, st);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipEventRecord(c->ev_t1, st));
+    }
+    // ---- pairs that ran out of arena go into the next pass --------------------
+    if (zero_counter(c, CT_LIST)) return -1;
+    uint32_t* nxt_pending = (pending == static_cast<uint32_t*>(c->list_c.p)) ? static_cast<uint32_t*>(c->list_d.p)
+                                                                             : static_cast<uint32_t*>(c->list_c.p);
+    hipLaunchKernelGGL(k_compact, dim3(cdiv(n_pending, 256)), dim3(256), 0, st, (const uint32_t*)pending, n_pending,
+                       static_cast<const uint32_t*>(c->status.p), MASK(WFA_ST_NOMEM), nxt_pending, ct + CT_LIST);
+    if (read_counters(c)) return -1;
+    if (compute_cigar) {
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1));
+      trace_ms += ms;
+      text_used = c->h_counters[CT_TEXT];
+    }
+    const uint32_t n_nomem = (uint32_t)c->h_counters[CT_LIST];
+    if (n_nomem == n_pending) {
+      fprintf(stderr, "[!] ERROR: backtrace arena (%zu bytes) too small for a single pass\n", c->arena.cap);
+      return -1;
+    }
+    if (n_nomem) {
+      hipLaunchKernelGGL(k_set_pending, dim3(cdiv(n_nomem, 256)), dim3(256), 0, st, (const uint32_t*)nxt_pending, n_nomem,
+                         static_cast<uint32_t*>(c->status.p));
+    }
+    c->stats.arena_units = std::max<unsigned long long>(c->stats.arena_units, c->h_counters[CT_ARENA]);
+    c->stats.cells = c->h_counters[CT_CELLS];
+    pending = nxt_pending; n_pending = n_nomem;
+  }
+  HIP_TRY(hipEventRecord(c->ev_end, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, c->ev_start, c->ev_pack)); c->stats.pack_ms = ms;
+  HIP_TRY(hipEventElapsedTime(&ms, c->ev_start, c->ev_end)); c->stats.total_ms = ms;
+  c->stats.align_ms = align_ms;
+  c->stats.trace_ms = trace_ms;
+  c->stats.text_bytes = text_used;
+  if (compute_cigar) {
+    if (d_text) *d_text = static_cast<const char*>(c->text.p);
+    if (d_off) *d_off = static_cast<const unsigned long long*>(c->cig_off.p);
+    if (d_len) *d_len = static_cast<const unsigned int*>(c->cig_len.p);
+  }
+  if (n_alpha) {
+    fprintf(stderr, "[!] ERROR: %u pairs contain bytes outside ACGT; the byte-compare tier is not built yet\n", n_alpha);
+    rc = -2;
+  }
+  return rc;
+}

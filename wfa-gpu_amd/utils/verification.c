@@ -1,0 +1,113 @@
+/* See verification.h.  Used only when check_correctness is set. */
+#include "verification.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+static const char* next_item(const char* c, long* n, char* op) {
+    long v = 0;
+    if (*c < '0' || *c > '9') return NULL;
+    while (*c >= '0' && *c <= '9') { v = v * 10 + (*c - '0'); ++c; }
+    if (!*c || v <= 0) return NULL;
+    *n = v; *op = *c;
+    return c + 1;
+}
+
+bool check_cigar_edit(const char* text, const char* pattern, size_t tlen, size_t plen,
+                      const char* cigar) {
+    size_t v = 0, h = 0;
+    const char* c = cigar;
+    while (*c) {
+        long n; char op;
+        c = next_item(c, &n, &op);
+        if (!c) return false;
+        for (long i = 0; i < n; ++i) {
+            switch (op) {
+                case 'M': if (v >= plen || h >= tlen || pattern[v] != text[h]) return false; ++v; ++h; break;
+                case 'X': if (v >= plen || h >= tlen || pattern[v] == text[h]) return false; ++v; ++h; break;
+                case 'I': if (h >= tlen) return false; ++h; break;
+                case 'D': if (v >= plen) return false; ++v; break;
+                default: return false;
+            }
+        }
+    }
+    return v == plen && h == tlen;
+}
+
+bool check_affine_distance(const char* text, const char* pattern, size_t tlen, size_t plen,
+                           int distance, int x, int o, int e, const char* cigar) {
+    (void)text; (void)pattern; (void)tlen; (void)plen;
+    long cost = 0;
+    char prev = 0;
+    const char* c = cigar;
+    while (*c) {
+        long n; char op;
+        c = next_item(c, &n, &op);
+        if (!c) return false;
+        if (op == 'X') cost += n * x;
+        else if (op == 'I' || op == 'D') cost += (prev == op ? 0 : o) + n * e;
+        else if (op != 'M') return false;
+        prev = op;
+    }
+    return cost == distance;
+}
+
+/* Furthest-reaching points per (score, diagonal), full-width rows indexed by
+ * k + plen, three score-indexed tables kept whole.  Deliberately the plain
+ * textbook formulation (no trimming, no ring) so that it shares nothing with
+ * the kernels it checks. */
+int verification_cpu_score(const char* pattern, const char* text, size_t plen_, size_t tlen_,
+                           int x, int o, int e) {
+    const int plen = (int)plen_, tlen = (int)tlen_;
+    const int W = plen + tlen + 3, K0 = plen + 1;
+    const int NONE = -(1 << 28);
+    const int oe = o + e;
+    const int depth = (x > oe ? x : oe) + 1;
+    int* buf = (int*)malloc(sizeof(int) * (size_t)W * 3 * (size_t)depth);
+    if (!buf) return -1;
+    int* M = buf; int* I = M + (size_t)W * depth; int* D = I + (size_t)W * depth;
+    for (size_t i = 0; i < (size_t)W * 3 * depth; ++i) buf[i] = NONE;
+    int lo = 0, hi = 0;     /* diagonal span that can be non-empty at the current score */
+    const int kend = tlen - plen;
+    int s = 0;
+    /* score 0 */
+    {
+        int h = 0;
+        while (h < plen && h < tlen && pattern[h] == text[h]) ++h;
+        M[K0] = h;
+        if (kend == 0 && h >= tlen) { free(buf); return 0; }
+    }
+    for (s = 1;; ++s) {
+        int* Ms = M + (size_t)(s % depth) * W; int* Is = I + (size_t)(s % depth) * W; int* Ds = D + (size_t)(s % depth) * W;
+        const int* Mx = s >= x ? M + (size_t)((s - x) % depth) * W : NULL;
+        const int* Mo = s >= oe ? M + (size_t)((s - oe) % depth) * W : NULL;
+        const int* Ie = s >= e ? I + (size_t)((s - e) % depth) * W : NULL;
+        const int* De = s >= e ? D + (size_t)((s - e) % depth) * W : NULL;
+        if (lo > -plen) --lo;
+        if (hi < tlen) ++hi;
+        for (int k = -plen - 1; k <= tlen + 1; ++k) { Ms[K0 + k] = NONE; Is[K0 + k] = NONE; Ds[K0 + k] = NONE; }
+        for (int k = lo; k <= hi; ++k) {
+            int ins = NONE, del = NONE, mis = NONE;
+            if (Mo && Mo[K0 + k - 1] > ins) ins = Mo[K0 + k - 1];
+            if (Ie && Ie[K0 + k - 1] > ins) ins = Ie[K0 + k - 1];
+            if (ins >= 0) ++ins;
+            if (Mo && Mo[K0 + k + 1] > del) del = Mo[K0 + k + 1];
+            if (De && De[K0 + k + 1] > del) del = De[K0 + k + 1];
+            if (Mx && Mx[K0 + k] >= 0) mis = Mx[K0 + k] + 1;
+            if (ins >= 0 && (ins > tlen || ins - k > plen)) ins = NONE;
+            if (del >= 0 && (del > tlen || del - k > plen)) del = NONE;
+            if (mis >= 0 && (mis > tlen || mis - k > plen)) mis = NONE;
+            Is[K0 + k] = ins; Ds[K0 + k] = del;
+            int m = mis > ins ? mis : ins; if (del > m) m = del;
+            if (m >= 0) {
+                int h = m, v = m - k;
+                while (v < plen && h < tlen && pattern[v] == text[h]) { ++v; ++h; }
+                m = h;
+            }
+            Ms[K0 + k] = m;
+        }
+        if (kend >= lo && kend <= hi && Ms[K0 + kend] >= tlen) break;
+    }
+    free(buf);
+    return s;
+}

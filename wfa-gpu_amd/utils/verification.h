@@ -1,0 +1,32 @@
+/* Checkers behind the CLI's -c flag.  They restate what the reference's -c
+ * path verifies (lib/align.cu:258-326, utils/verification.c:27-146): the
+ * CIGAR replays onto both sequences, its gap-affine cost equals the reported
+ * score, and the score equals an independent CPU computation.  Checker
+ * only: nothing here ever produces a result the library returns. */
+#ifndef WFAGPU_VERIFICATION_H
+#define WFAGPU_VERIFICATION_H
+
+#include <stdbool.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* RLE CIGAR ("12M1X3I...") replays exactly onto pattern and text. */
+bool check_cigar_edit(const char* text, const char* pattern, size_t tlen, size_t plen,
+                      const char* cigar);
+
+/* Sum of penalties of the CIGAR equals `distance`. */
+bool check_affine_distance(const char* text, const char* pattern, size_t tlen, size_t plen,
+                           int distance, int x, int o, int e, const char* cigar);
+
+/* Optimal gap-affine score by a scalar dynamic program over (score,
+ * diagonal); O(score * width) time.  Independent of the GPU kernels. */
+int verification_cpu_score(const char* pattern, const char* text, size_t plen, size_t tlen,
+                           int x, int o, int e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,113 @@
+"""CPU-side checks of the boundary: the shared library loads, exports every symbol include/*.h declares,
+struct layouts match the reference ABI, host-side helpers behave.  No GPU calls."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import wfagpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(wfagpu.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return wfagpu.load()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    declared = set()
+    for hdr in ("wfa_gpu_abi.h", "wfa_gpu_device.h"):
+        txt = open(os.path.join(ROOT, "include", hdr)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        txt = txt.split("header-level helpers")[0]
+        for m in re.finditer(r"^\s*(?:[\w\*]+\s+)+\**(\w+)\s*\(", txt, flags=re.M):
+            name = m.group(1)
+            if name not in ("defined",) and not name.isupper():
+                declared.add(name)
+    static_inline = {"wfa_get_threads_per_alignment", "get_num_workers", "wfagpu_set_default_options"}
+    declared -= static_inline
+    assert set(wfagpu.ABI_SYMBOLS) <= declared | set(wfagpu.ABI_SYMBOLS)
+    for name in sorted(declared | set(wfagpu.ABI_SYMBOLS)):
+        assert hasattr(lib, name), f"{name} not exported"
+
+
+def test_struct_layouts_match_reference_abi():
+    """SURVEY.md Appendix B (measured on the reference with gcc x86-64)."""
+    assert C.sizeof(wfagpu.SeqPair) == 48 and wfagpu.SeqPair.has_N.offset == 40
+    assert C.sizeof(wfagpu.Penalties) == 12
+    assert C.sizeof(wfagpu.Cigar) == 24
+    assert C.sizeof(wfagpu.AlignmentResult) == 32 and wfagpu.AlignmentResult.cigar.offset == 8
+    assert C.sizeof(wfagpu.Options) == 48 and wfagpu.Options.penalties.offset == 32 and wfagpu.Options.compute_cigar.offset == 44
+    assert C.sizeof(wfagpu.Aligner) == 104 and wfagpu.Aligner.alignment_options.offset == 56
+    # and as the C compiler sees include/wfa_gpu_abi.h
+    src = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "wfa_gpu_abi.h"
+int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu\n",sizeof(sequence_pair_t),sizeof(affine_penalties_t),
+ sizeof(wfa_backtrace_t),sizeof(alignment_result_t),sizeof(wfa_cigar_t),sizeof(wfa_alignment_result_t),
+ sizeof(wfa_alignment_options_t),sizeof(wfagpu_aligner_t));return 0;}'''
+    exe = "/tmp/wfagpu_abi_probe"
+    subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe, "-L", os.path.dirname(wfagpu.LIB_PATH)],
+                   input=src.encode(), check=True)
+    out = subprocess.run([exe], capture_output=True, check=True).stdout.split()
+    assert [int(v) for v in out] == [48, 12, 8, 20, 24, 32, 48, 104]
+
+
+def test_aligner_object_host_side(lib):
+    """tests/test_api.c:30-57 of the reference: NULL and bad-penalty rejection; buffer layout of add_sequences."""
+    al = wfagpu.Aligner()
+    assert not lib.wfagpu_initialize_aligner(None)
+    assert lib.wfagpu_initialize_aligner(C.byref(al))
+    assert not lib.wfagpu_add_sequences(None, b"A", b"A")
+    assert not lib.wfagpu_add_sequences(C.byref(al), None, b"A")
+    assert not lib.wfagpu_add_sequences(C.byref(al), b"A", None)
+    assert lib.wfagpu_add_sequences(C.byref(al), b"GATTACA", b"GATACA")
+    assert lib.wfagpu_add_sequences(C.byref(al), b"ACGT" * 300000, b"A") is False  # >= 2^15
+    big = b"ACGT" * 5000
+    for _ in range(120):  # forces both grow paths (1 MiB buffer steps)
+        assert lib.wfagpu_add_sequences(C.byref(al), big, big)
+    assert al.num_sequence_pairs == 121
+    m0, m1 = al.sequences_metadata[0], al.sequences_metadata[1]
+    assert (m0.pattern_offset, m0.pattern_len, m0.text_offset, m0.text_len) == (0, 7, 12, 6)  # WFA_ALIGN_32_BITS(8) == 12: always at least one pad byte
+    assert m1.pattern_offset == 20 and m1.pattern_offset % 4 == 0 and m1.text_offset % 4 == 0
+    raw = C.string_at(al.sequences_buffer, 20)
+    assert raw == b"GATTACA\0\0\0\0\0GATACA\0\0"
+    assert not lib.wfagpu_initialize_parameters(None, wfagpu.Penalties(2, 3, 1))
+    assert not lib.wfagpu_initialize_parameters(C.byref(al), wfagpu.Penalties(-1, 3, 1))
+    assert not lib.wfagpu_initialize_parameters(C.byref(al), wfagpu.Penalties(0, 0, 0))
+    assert not lib.wfagpu_set_batch_size(None, 10)
+    assert not lib.wfagpu_align(None)
+    lib.wfagpu_destroy_aligner(C.byref(al))
+
+
+def test_packed_offsets_helper(lib):
+    meta = np.zeros(3, dtype=wfagpu.META_DTYPE)
+    meta["pattern_len"] = [0, 16, 17]
+    meta["text_len"] = [1, 32, 1000]
+    total = lib.wfagpu_amd_fill_packed_offsets(meta.ctypes.data, 3)
+    words = lambda n: (n + 15) // 16 + 1
+    exp, off = [], 0
+    for pl, tl in zip(meta["pattern_len"], meta["text_len"]):
+        exp.append((off, off + 4 * words(int(pl))))
+        off += 4 * (words(int(pl)) + words(int(tl)))
+    assert total == off
+    assert [(int(m["pattern_offset_packed"]), int(m["text_offset_packed"])) for m in meta] == exp
+
+
+def test_generator_is_seeded_and_valid():
+    b1, m1 = wfagpu.generate_pairs(50, 200, 0.05, 9)
+    b2, m2 = wfagpu.generate_pairs(50, 200, 0.05, 9, nthreads=1)
+    b3, _ = wfagpu.generate_pairs(50, 200, 0.05, 10)
+    assert np.array_equal(b1, b2) and np.array_equal(m1, m2) and not np.array_equal(b1, b3)
+    assert (m1["pattern_offset"] % 4 == 0).all() and (m1["text_offset"] % 4 == 0).all()
+    assert (m1["text_len"] == 200).all() and (abs(m1["pattern_len"].astype(int) - 200) <= 10).all()
+    for p, t in wfagpu.pairs_from_layout(b1, m1):
+        assert set(p) <= set(b"ACGT") and set(t) <= set(b"ACGT")

@@ -1,0 +1,157 @@
+"""GPU parity: every stage of the hot path, called through the C-ABI, against the oracle and the
+committed golden vectors.  Bit-exact (integer scores, byte-identical CIGAR strings)."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+import oracle_lib
+import wfagpu
+from test_oracle import PENS, _rand_pairs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def aligner():
+    al = wfagpu.DeviceAligner(0)
+    yield al
+    al.close()
+
+
+def _run(aligner, buf, meta, pen, max_error, cigar=True):
+    batch = aligner.upload(buf, meta)
+    return aligner.align(batch, pen, max_error=max_error, compute_cigar=cigar)
+
+
+def test_pack_literals_and_random(aligner):
+    """tests/test_packing_kernel.cu of the reference: literal pairs + bit layout; here every 2-bit field is
+    compared with the oracle's packer (little-endian word layout of this build)."""
+    import ctypes as C
+    rng = random.Random(5)
+    pairs = [(b"GATTACA", b"GATACA"), (b"ACGT" * 9, b"ACGT" * 9 + b"A"), (b"T" * 33, b"C" * 16), (b"A", b"G")]
+    pairs += _rand_pairs(rng, 200, 300) + [(b"ACGNACGT", b"acgt"), (b"", b"A")]
+    buf, meta = wfagpu.layout_pairs(pairs)
+    batch = aligner.upload(buf, meta)
+    packed, flags = aligner.pack(batch)
+    hm = batch._meta_host
+    o = oracle_lib.oracle()
+    for i, (p, t) in enumerate(pairs):
+        for which, (seq, off) in enumerate(((p, int(hm[i]["pattern_offset_packed"])), (t, int(hm[i]["text_offset_packed"])))):
+            nw = (len(seq) + 15) // 16
+            words = (C.c_uint32 * (nw + 1))()
+            bad = o.oracle_pack2(seq, len(seq), words)
+            got = packed[off // 4: off // 4 + nw + 1]
+            assert flags[2 * i + which] == bad, (i, which)
+            if not bad:
+                assert list(got[:nw]) == list(words)[:nw], (i, which)
+            assert got[nw] == 0  # spare word
+
+
+@pytest.mark.parametrize("tag", ["p0", "p1", "p2", "g231"])
+def test_utest_goldens_cigar(aligner, golden_dir, tag):
+    """WFA2's own unit-test goldens (score + CIGAR) for the reference's wfa.utest.seq; -e small on purpose so
+    that the long pairs go through every escalation tier (the reference sends them to the CPU, tests/test-aligner.sh:27)."""
+    pairs = wfagpu.read_seq_file(os.path.join(golden_dir, "wfa.utest.seq"))
+    buf, meta = wfagpu.layout_pairs(pairs)
+    gs, gc = oracle_lib.read_alg(os.path.join(golden_dir, f"utest.affine.{tag}.alg"))
+    s, c = _run(aligner, buf, meta, PENS[tag], max_error=25)
+    assert np.array_equal(s, gs)
+    assert c == gc
+
+
+@pytest.mark.parametrize("tag", ["p0", "p1", "p2"])
+def test_utest_goldens_score_only(aligner, golden_dir, tag):
+    """tests/test-aligner.sh of the reference: -g 1,2,1 / 3,1,4 / 5,3,2 with -e 10000, score-only."""
+    pairs = wfagpu.read_seq_file(os.path.join(golden_dir, "wfa.utest.seq"))
+    buf, meta = wfagpu.layout_pairs(pairs)
+    gs, _ = oracle_lib.read_alg(os.path.join(golden_dir, f"utest.score.affine.{tag}.alg"))
+    s, _ = _run(aligner, buf, meta, PENS[tag], max_error=10000, cigar=False)
+    assert np.array_equal(s, gs)
+
+
+@pytest.mark.parametrize("name,pens", [("seq1k", [(2, 3, 1), (5, 3, 2)]), ("seq10k", [(2, 3, 1), (3, 5, 2)])])
+def test_api_goldens(aligner, golden_dir, name, pens):
+    """tests/test_api.c golden score arrays, CIGAR and distance-only modes."""
+    pairs = wfagpu.read_seq_file(os.path.join(golden_dir, f"{name}.seq"))
+    buf, meta = wfagpu.layout_pairs(pairs)
+    for pen in pens:
+        gold = -np.loadtxt(os.path.join(golden_dir, f"{name}.x{pen[0]}o{pen[1]}e{pen[2]}.scores"), dtype=np.int64)
+        for cigar in (False, True):
+            max_len = 1000 if name == "seq1k" else 10000
+            s, c = _run(aligner, buf, meta, pen, max_error=int(0.1 * max_len * max(pen)), cigar=cigar)
+            assert np.array_equal(s, gold[:len(s)])
+            if cigar:
+                for (p, t), cg, sc in zip(pairs, c, s):
+                    ok, cost = oracle_lib.check_cigar(p, t, cg, pen)
+                    assert ok and cost == sc
+
+
+@pytest.mark.parametrize("fname,n,length,err,seed", [("synth.cfg2.alg", 2000, 150, 0.02, 2), ("synth.cfg3.alg", 500, 1000, 0.05, 3)])
+def test_synthetic_config_goldens(aligner, golden_dir, fname, n, length, err, seed):
+    """Seeded synthetic sets shaped like BASELINE.json configs[1]/[2]; expected output from the compiled reference."""
+    buf, meta = wfagpu.generate_pairs(n, length, err, seed)
+    gs, gc = oracle_lib.read_alg_skip_comments(os.path.join(golden_dir, fname))
+    s, c = _run(aligner, buf, meta, (2, 3, 1), max_error=max(50, int(0.1 * length * 3)))
+    assert np.array_equal(s, gs)
+    assert c == gc
+
+
+def test_hifi_goldens(aligner, golden_dir):
+    pairs = wfagpu.read_seq_file(os.path.join(golden_dir, "hifi.seq"))
+    buf, meta = wfagpu.layout_pairs(pairs)
+    gs, gc = oracle_lib.read_alg(os.path.join(golden_dir, "hifi.g231.alg"))
+    s, c = _run(aligner, buf, meta, (2, 3, 1), max_error=3000)
+    assert np.array_equal(s, gs)
+    assert c == gc
+
+
+@pytest.mark.parametrize("pen", [(2, 3, 1), (1, 2, 1), (3, 1, 4), (5, 3, 2), (4, 6, 2), (1, 0, 1), (7, 2, 3)])
+def test_random_vs_oracle(aligner, pen):
+    """Ragged random pairs incl. empty and 1-base sequences and unrelated pairs."""
+    rng = random.Random(99 + sum(pen))
+    pairs = _rand_pairs(rng, 400, 80) + _rand_pairs(rng, 80, 500, err=0.25) + _rand_pairs(rng, 10, 3000, err=0.15)
+    pairs += [(b"", b""), (b"A", b""), (b"", b"ACGT"), (b"A", b"A"), (b"A", b"C"), (b"ACGT", b"TGCA"),
+              (b"AAAAAAAAAA", b"TTTTTTTTTTTTTTT"), (b"ACGTACGTAC", b"ACGTACGTACGTACGTACGT")]
+    buf, meta = wfagpu.layout_pairs(pairs)
+    so, co, cells = oracle_lib.oracle_batch(buf, meta, pen, cigar=True, nthreads=8)
+    for max_error in (8, 200):
+        s, c = _run(aligner, buf, meta, pen, max_error=max_error)
+        assert np.array_equal(s, so)
+        assert c == co
+        s2, _ = _run(aligner, buf, meta, pen, max_error=max_error, cigar=False)
+        assert np.array_equal(s2, so)
+
+
+def test_small_arena_forces_multiple_passes(golden_dir):
+    """Backtrace arena smaller than the batch needs: pairs are re-queued for a further pass, results identical."""
+    al = wfagpu.DeviceAligner(0, arena_bytes=8 << 20)
+    try:
+        buf, meta = wfagpu.generate_pairs(3000, 1000, 0.05, 11)
+        so, co, _ = oracle_lib.oracle_batch(buf, meta, (2, 3, 1), cigar=True, nthreads=8)
+        batch = al.upload(buf, meta)
+        s, c = al.align(batch, (2, 3, 1), max_error=300, compute_cigar=True)
+        assert al.stats().sub_batches > 1
+        assert np.array_equal(s, so)
+        assert c == co
+    finally:
+        al.close()
+
+
+def test_full_size_properties(aligner):
+    """BASELINE configs[1] at full size (100k x 150 bp): size-independent properties -- every CIGAR replays onto
+    its pair, its gap-affine cost equals the reported score, and a 2000-pair sample equals the oracle."""
+    n = 100000
+    buf, meta = wfagpu.generate_pairs(n, 150, 0.02, 21)
+    s, c = _run(aligner, buf, meta, (2, 3, 1), max_error=45)
+    pairs = wfagpu.pairs_from_layout(buf, meta)
+    idx = np.random.RandomState(0).choice(n, 2000, replace=False)
+    sub = [pairs[i] for i in idx]
+    sb, sm = wfagpu.layout_pairs(sub)
+    so, co, _ = oracle_lib.oracle_batch(sb, sm, (2, 3, 1), cigar=True, nthreads=8)
+    assert np.array_equal(s[idx], so)
+    assert [c[i] for i in idx] == co
+    for i in range(0, n, 7):
+        ok, cost = oracle_lib.check_cigar(pairs[i][0], pairs[i][1], c[i], (2, 3, 1))
+        assert ok and cost == s[i]

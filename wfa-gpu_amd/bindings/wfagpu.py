@@ -83,6 +83,12 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: build it with __graft_entry__.build() or `make -C wfa-gpu_amd`")
+    try:
+        # PyTorch-ROCm bundles its own HIP runtime; it must be the first (and only) one in the process,
+        # otherwise device discovery fails.  Standalone C programs simply use /opt/rocm's.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     lib.wfagpu_amd_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(Config)]
     lib.wfagpu_amd_create.restype = C.c_int

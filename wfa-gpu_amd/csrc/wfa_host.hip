@@ -350,6 +350,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   const uint32_t n_alpha = n - n_pending;
 
   float align_ms = 0.f, trace_ms = 0.f;
+  uint32_t grid_cap = UINT32_MAX;   // lowered when a pass makes no progress for lack of arena
   unsigned long long text_used = 0;
   const int hmax = (int)std::min<unsigned>(max_len, INT_MAX / 4);
   int rc = 0;
@@ -378,7 +379,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       }
       if (round == 0 && c->stats.sub_batches == 1) { c->stats.lds_bytes_tier0 = tp.lds; c->stats.blocks_per_cu_tier0 = tp.blocks_per_cu; }
       ap.work = cur; ap.n_work = n_cur;
-      const int grid = (int)std::min<uint32_t>(n_cur, (uint32_t)(c->num_cus * tp.blocks_per_cu));
+      const int grid = (int)std::min<uint32_t>(std::min<uint32_t>(n_cur, grid_cap), (uint32_t)(c->num_cus * tp.blocks_per_cu));
       if (zero_counter(c, CT_WORK, 2)) return -1;   // work counter + list counter
       HIP_TRY(hipEventRecord(c->ev_a0, st));
       wfa_launch_align(ap, tp.tier, compute_cigar, grid, st);
@@ -445,9 +446,27 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       text_used = c->h_counters[CT_TEXT];
     }
     const uint32_t n_nomem = (uint32_t)c->h_counters[CT_LIST];
-    if (n_nomem == n_pending) {
-      fprintf(stderr, "[!] ERROR: backtrace arena (%zu bytes) too small for a single pass\n", c->arena.cap);
-      return -1;
+    if (n_nomem) {
+      // grow the arena for the next pass if memory allows; if a pass made no
+      // progress at all, also halve the number of alignments in flight
+      size_t free_b = 0, total_b = 0;
+      HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+      const size_t limit = std::min<size_t>((size_t)(0.6 * (double)(free_b + c->arena.cap)), ((size_t)1 << 36) - 4096);
+      const size_t grown = std::min<size_t>(limit, std::max<size_t>(2 * c->arena.cap, c->arena.cap + ((size_t)256 << 20)));
+      const bool can_grow = !c->arena_cfg && grown > c->arena.cap;
+      if (can_grow) {
+        if (c->arena.ensure(grown, st)) return -1;
+        ap.arena = static_cast<uint8_t*>(c->arena.p);
+        ap.arena_units = c->arena.cap / 16;
+      }
+      if (n_nomem == n_pending && !can_grow) {
+        if (grid_cap == 1) {
+          fprintf(stderr, "[!] ERROR: backtrace arena (%zu bytes) too small for one alignment\n", c->arena.cap);
+          return -1;
+        }
+        const uint32_t cur_cap = std::min<uint32_t>(grid_cap, std::min<uint32_t>(n_pending, (uint32_t)c->num_cus * 32u));
+        grid_cap = std::max<uint32_t>(1u, cur_cap / 2);
+      }
     }
     if (n_nomem) {
       hipLaunchKernelGGL(k_set_pending, dim3(cdiv(n_nomem, 256)), dim3(256), 0, st, (const uint32_t*)nxt_pending, n_nomem,

@@ -104,17 +104,13 @@ def main():
     import torch
     import wfagpu
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import shardlib
+    rank, local_rank, world = shardlib.env_rank_world()
     dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank) if torch.cuda.is_available() else None
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
-    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist = shardlib.init_distributed("nccl", device=torch.device("cuda", local_rank))   # "nccl" is RCCL on ROCm
 
     n_pairs, length, err, cigar, max_error, desc = WORKLOADS[args.workload]
     if args.pairs:
@@ -123,36 +119,32 @@ def main():
         max_error = args.max_error
 
     # synthetic data (seeded; every rank its own shard), resident in HBM before the clock starts
-    buf, meta = wfagpu.generate_pairs(n_pairs, length, err, seed=1000 + rank, nthreads=min(16, usable_cores()))
+    buf, meta = wfagpu.generate_pairs(n_pairs, length, err, seed=shardlib.shard_seed(1000, rank),
+                                      nthreads=min(16, usable_cores()))
     al = wfagpu.DeviceAligner(local_rank)
     batch = al.upload(buf, meta)
     dptt = int((meta["pattern_len"].astype(np.int64) * meta["text_len"].astype(np.int64)).sum())
+    acc = {"align_ms": 0.0, "pack_ms": 0.0, "trace_ms": 0.0, "launches": 0, "steps": 0}
+    last = {}
 
     def step():
-        return al.align(batch, PEN, max_error=max_error, compute_cigar=cigar, fetch=False)
-
-    for _ in range(args.warmup):
-        step()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    acc = {"align_ms": 0.0, "pack_ms": 0.0, "trace_ms": 0.0, "launches": 0}
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        d_scores, ptrs = step()
+        last["out"] = al.align(batch, PEN, max_error=max_error, compute_cigar=cigar, fetch=False)
         st = al.stats()
         acc["align_ms"] += st.align_ms
         acc["pack_ms"] += st.pack_ms
         acc["trace_ms"] += st.trace_ms
         acc["launches"] += st.align_launches
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        acc["steps"] += 1
+
+    def reset_acc():
+        for k in acc:
+            acc[k] = 0
+
+    for _ in range(args.warmup):
+        step()
+    reset_acc()
+    elapsed = shardlib.timed_steps(step, args.steps, 0, dist=dist, sync=torch.cuda.synchronize, device="cuda")
+    d_scores, ptrs = last["out"]
 
     st = al.stats()
     total_pairs = n_pairs * args.steps * world

@@ -111,3 +111,15 @@ def test_generator_is_seeded_and_valid():
     assert (m1["text_len"] == 200).all() and (abs(m1["pattern_len"].astype(int) - 200) <= 10).all()
     for p, t in wfagpu.pairs_from_layout(b1, m1):
         assert set(p) <= set(b"ACGT") and set(t) <= set(b"ACGT")
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/examples"), reason="reference tree absent")
+@pytest.mark.parametrize("src,cc", [("auto_example.c", "gcc"), ("manual_example.c", "gcc"), ("auto_example.cpp", "g++")])
+def test_reference_examples_compile_unchanged(lib, src, cc):
+    """the reference's example programs, read where they lie, compile and link
+    against this library with the reference's own include convention (-I lib -I .)."""
+    pkg = os.path.dirname(wfagpu.LIB_PATH)
+    exe = f"/tmp/wfagpu_refexample_{src.replace('.', '_')}"
+    subprocess.run([cc, f"/root/reference/examples/{src}", "-o", exe, f"-I{pkg}/lib", f"-I{pkg}", f"-L{pkg}",
+                    "-lwfagpu", f"-Wl,-rpath,{pkg}"], check=True)
+    assert os.path.exists(exe)

@@ -1,0 +1,121 @@
+"""GPU tests of the host-facing layers: the wfagpu_* C API (tests/test_api.c of the reference), the
+launch_alignments* seam, the wfa.affine.gpu CLI (tests/test-aligner.sh, tests/test-fasta.sh) and the examples."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib
+import wfagpu
+
+pytestmark = pytest.mark.gpu
+PKG = os.path.dirname(wfagpu.LIB_PATH)
+CLI = os.path.join(PKG, "bin", "wfa.affine.gpu")
+
+
+def _api_align(pairs, pen, cigar, batch=None, max_error=None):
+    lib = wfagpu.load()
+    al = wfagpu.Aligner()
+    assert lib.wfagpu_initialize_aligner(C.byref(al))
+    for p, t in pairs:
+        assert lib.wfagpu_add_sequences(C.byref(al), p, t)
+    assert lib.wfagpu_initialize_parameters(C.byref(al), wfagpu.Penalties(*pen))
+    if batch:
+        assert lib.wfagpu_set_batch_size(C.byref(al), batch)
+    if max_error:
+        al.alignment_options.max_error = max_error
+    al.alignment_options.compute_cigar = cigar
+    assert lib.wfagpu_align(C.byref(al))
+    n = al.num_sequence_pairs
+    scores = np.array([al.results[i].error for i in range(n)], dtype=np.int64)
+    cigars = [C.string_at(al.results[i].cigar.buffer).decode() for i in range(n)] if cigar else None
+    lib.wfagpu_destroy_aligner(C.byref(al))
+    return scores, cigars
+
+
+@pytest.mark.parametrize("batch", [None, 100, 37])
+def test_api_golden_scores_1k(golden_dir, batch):
+    """tests/test_api.c:167-219: 1 kbp pairs, penalties (2,3,1) and (5,3,2), several batch sizes, both modes."""
+    pairs = wfagpu.read_seq_file(os.path.join(golden_dir, "seq1k.seq"))
+    for pen in ((2, 3, 1), (5, 3, 2)):
+        gold = -np.loadtxt(os.path.join(golden_dir, f"seq1k.x{pen[0]}o{pen[1]}e{pen[2]}.scores"), dtype=np.int64)
+        s, _ = _api_align(pairs, pen, cigar=False, batch=batch)
+        assert np.array_equal(s, gold[:len(s)])
+        s, c = _api_align(pairs, pen, cigar=True, batch=batch)
+        assert np.array_equal(s, gold[:len(s)])
+        buf, meta = wfagpu.layout_pairs(pairs)
+        _, co, _ = oracle_lib.oracle_batch(buf, meta, pen, cigar=True, nthreads=8)
+        assert c == co
+
+
+def test_api_golden_scores_10k(golden_dir):
+    """tests/test_api.c:59-165: 10 kbp pairs at 10 % error, (2,3,1) and (3,5,2); default max_error is 0.1*len*max(x,o,e)."""
+    pairs = wfagpu.read_seq_file(os.path.join(golden_dir, "seq10k.seq"))
+    for pen in ((2, 3, 1), (3, 5, 2)):
+        gold = -np.loadtxt(os.path.join(golden_dir, f"seq10k.x{pen[0]}o{pen[1]}e{pen[2]}.scores"), dtype=np.int64)
+        s, c = _api_align(pairs, pen, cigar=True, batch=10)
+        assert np.array_equal(s, gold[:len(s)])
+        for (p, t), cg, sc in zip(pairs, c, s):
+            ok, cost = oracle_lib.check_cigar(p, t, cg, pen)
+            assert ok and cost == sc
+
+
+def test_api_small_max_error_is_still_exact():
+    """tests/test-aligner.sh:27 (-e 25 'test CPU recovery'): here the recovery is a wider GPU tier."""
+    buf, meta = wfagpu.generate_pairs(300, 1000, 0.05, 77)
+    pairs = wfagpu.pairs_from_layout(buf, meta)
+    so, co, _ = oracle_lib.oracle_batch(buf, meta, (2, 3, 1), cigar=True, nthreads=8)
+    s, c = _api_align(pairs, (2, 3, 1), cigar=True, max_error=25)
+    assert np.array_equal(s, so) and c == co
+
+
+def _run_cli(args):
+    r = subprocess.run([CLI] + args, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return r
+
+
+@pytest.mark.parametrize("tag,pen,e", [("p0", "1,2,1", "10000"), ("p0", "1,2,1", "25"), ("p1", "3,1,4", "10000"), ("p2", "5,3,2", "10000")])
+def test_cli_score_goldens(golden_dir, tmp_path, tag, pen, e):
+    """tests/test-aligner.sh of the reference, same command lines, diff against its golden files."""
+    out = tmp_path / "res.out"
+    r = _run_cli(["-i", os.path.join(golden_dir, "wfa.utest.seq"), "-g", pen, "-e", e, "-o", str(out)])
+    assert "Alignment computed. Wall time:" in r.stdout
+    got = [line.split("\t")[0] for line in open(out).read().splitlines()]
+    gold = open(os.path.join(golden_dir, f"utest.score.affine.{tag}.alg")).read().split()
+    assert got == gold
+
+
+def test_cli_cigar_check_and_fasta(golden_dir, tmp_path):
+    """tests/test-fasta.sh: paired FASTA input, -x -c, 'correct=N' on stderr; output equals the .seq run."""
+    pairs = wfagpu.read_seq_file(os.path.join(golden_dir, "hifi.seq"))
+    q, t = tmp_path / "q.fasta", tmp_path / "t.fasta"
+    with open(q, "w") as fq, open(t, "w") as ft:
+        for i, (p, x) in enumerate(pairs):
+            fq.write(f">q{i}\n")
+            ft.write(f">t{i}\n")
+            for j in range(0, len(p), 70):   # multi-line records
+                fq.write(p[j:j + 70].decode() + "\n")
+            for j in range(0, len(x), 61):
+                ft.write(x[j:j + 61].decode() + "\n")
+    out1, out2 = tmp_path / "a.out", tmp_path / "b.out"
+    r = _run_cli(["-Q", str(q), "-T", str(t), "-x", "-c", "-b", "5", "-o", str(out1)])
+    assert f"correct=5 Incorrect=0" in r.stderr and "Incorrect=1" not in r.stderr
+    _run_cli(["-i", os.path.join(golden_dir, "hifi.seq"), "-x", "-o", str(out2)])
+    assert open(out1).read() == open(out2).read() == open(os.path.join(golden_dir, "hifi.g231.alg")).read()
+
+
+def test_examples_run():
+    subprocess.run(["make", "-C", os.path.join(PKG, "examples")], check=True, capture_output=True)
+    out = subprocess.run([os.path.join(PKG, "examples", "quickstart")], capture_output=True, text=True, check=True).stdout
+    lines = out.strip().splitlines()
+    assert len(lines) == 3 and lines[2].startswith("pair 2: score 0 cigar 21M")
+    pairs = [(b"GATTACAGATTACAGATTACATTTGACCA", b"GATTACAGATACAGATTACATTTGGACCA"),
+             (b"ACGTACGTACGTACGTTTTTACGTACGT", b"ACGTACGAACGTACGTACGTACGT")]
+    for (p, t), line in zip(pairs, lines):
+        s, cg, _ = oracle_lib.oracle_pair(p, t, (2, 3, 1))
+        assert line.endswith(f"score {s} cigar {cg}")
+    subprocess.run([os.path.join(PKG, "examples", "tuned")], check=True, capture_output=True)
+    subprocess.run([os.path.join(PKG, "examples", "quickstart-cpp")], check=True, capture_output=True)

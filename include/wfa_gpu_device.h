@@ -51,6 +51,7 @@ typedef struct {
     unsigned long long text_bytes;     /* CIGAR text bytes produced                       */
     unsigned int pairs_tier[4];        /* pairs finished per kernel tier                  */
     unsigned int pairs_retried;        /* pairs that needed a wider tier                  */
+    unsigned int pairs_raw;            /* pairs with bytes outside ACGT (byte-compare kernels) */
     unsigned int sub_batches;          /* arena-bounded passes                            */
     size_t lds_bytes_tier0;
     int blocks_per_cu_tier0;

@@ -124,6 +124,27 @@ def test_random_vs_oracle(aligner, pen):
         assert np.array_equal(s2, so)
 
 
+@pytest.mark.parametrize("pen", [(2, 3, 1), (5, 3, 2)])
+def test_non_acgt_pairs_use_byte_compare_kernels(aligner, pen):
+    """Pairs with N / lower case / IUPAC bytes: WFA2 compares raw bytes (N==N matches, 'a' != 'A'); the reference
+    sends such pairs to the CPU (sequence_alignment_kernel.cu:474-482), here they run in the byte-compare kernels.
+    Mixed with ACGT-only pairs in one batch; also long enough to need tier escalation."""
+    rng = random.Random(4242)
+    pairs = _rand_pairs(rng, 150, 120, alphabet=b"ACGTN") + _rand_pairs(rng, 60, 200, alphabet=b"ACGTacgtNRY")
+    pairs += _rand_pairs(rng, 100, 150) + _rand_pairs(rng, 8, 2500, alphabet=b"ACGTN", err=0.12)
+    pairs += [(b"N", b"N"), (b"NNNN", b"NNAN"), (b"acgt", b"ACGT"), (b"ACGTN", b""), (b"", b"N")]
+    rng.shuffle(pairs)
+    buf, meta = wfagpu.layout_pairs(pairs)
+    so, co, _ = oracle_lib.oracle_batch(buf, meta, pen, cigar=True, nthreads=8)
+    for max_error in (10, 300):
+        s, c = _run(aligner, buf, meta, pen, max_error=max_error)
+        assert np.array_equal(s, so)
+        assert c == co
+        assert aligner.stats().pairs_raw > 200
+        s2, _ = _run(aligner, buf, meta, pen, max_error=max_error, cigar=False)
+        assert np.array_equal(s2, so)
+
+
 def test_small_arena_forces_multiple_passes(golden_dir):
     """Backtrace arena smaller than the batch needs: pairs are re-queued for a further pass, results identical."""
     al = wfagpu.DeviceAligner(0, arena_bytes=8 << 20)

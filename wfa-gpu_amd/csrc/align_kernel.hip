@@ -70,24 +70,30 @@ template <int NW> __device__ __forceinline__ uint32_t block_bcast(uint32_t v, ui
   }
 }
 
-// Longest common prefix of pattern[v..] and text[h..] on 2-bit packed words
-// (little-endian base order), 16 bases per iteration.
+// Longest common prefix of pattern[v..] and text[h..].
+//   RAW == false: 2-bit packed words (little-endian base order), 16 bases per iteration;
+//   RAW == true : the ASCII bytes themselves, 4 per iteration -- for pairs with bytes outside
+//                 ACGT, which must compare as raw bytes like WFA2 does (wavefront_extend.c:174-199).
+template <bool RAW>
 __device__ __forceinline__ int extend_lcp(const uint32_t* __restrict__ Pw,
                                           const uint32_t* __restrict__ Tw, int plen, int tlen,
                                           int k, int h) {
+  constexpr int SH = RAW ? 2 : 4;            // log2(symbols per word)
+  constexpr int PER = 1 << SH;
+  constexpr int BITS = RAW ? 3 : 1;          // log2(bits per symbol)
   int v = h - k;
   int rem = min(plen - v, tlen - h);
   while (rem > 0) {
-    const int pi = v >> 4, ti = h >> 4;
+    const int pi = v >> SH, ti = h >> SH;
     const uint32_t p0 = Pw[pi], p1 = Pw[pi + 1];
     const uint32_t t0 = Tw[ti], t1 = Tw[ti + 1];
-    const uint32_t a = __builtin_amdgcn_alignbit(p1, p0, (v & 15) << 1);
-    const uint32_t b = __builtin_amdgcn_alignbit(t1, t0, (h & 15) << 1);
+    const uint32_t a = __builtin_amdgcn_alignbit(p1, p0, (v & (PER - 1)) << BITS);
+    const uint32_t b = __builtin_amdgcn_alignbit(t1, t0, (h & (PER - 1)) << BITS);
     const uint32_t d = a ^ b;
-    int n = d ? (__builtin_ctz(d) >> 1) : 16;
+    int n = d ? (__builtin_ctz(d) >> BITS) : PER;
     n = min(n, rem);
     h += n; v += n; rem -= n;
-    if (n < 16) break;
+    if (n < PER) break;
   }
   return h;
 }
@@ -105,7 +111,7 @@ __device__ __forceinline__ int rd_cell(const OffT* row, int kidx0, int k, RowRan
   return ((unsigned)(k - r.lo) <= (unsigned)r.w) ? val : OFF_NULL;
 }
 
-template <int NW, bool BT, typename OffT, bool GLOBAL_RING>
+template <int NW, bool BT, typename OffT, bool GLOBAL_RING, bool RAW>
 __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NT = NW * 64;
@@ -151,7 +157,8 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
     const WfaSeqPair mp = p.meta[pair];
     const int plen = (int)mp.pattern_len, tlen = (int)mp.text_len;
     const int kend = tlen - plen;
-    const int pwords = ((plen + 15) >> 4) + 1, twords = ((tlen + 15) >> 4) + 1;
+    const int pwords = RAW ? ((plen + 3) >> 2) + 1 : ((plen + 15) >> 4) + 1;
+    const int twords = RAW ? ((tlen + 3) >> 2) + 1 : ((tlen + 15) >> 4) + 1;
 
     uint32_t status = WFA_ST_DONE;
     int s = 0;
@@ -162,8 +169,8 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
       status = WFA_ST_BAND;
     } else {
       // ---- stage packed sequences, reset row metadata -----------------------
-      const uint32_t* __restrict__ gp = p.packed + (mp.pattern_offset_packed >> 2);
-      const uint32_t* __restrict__ gt = p.packed + (mp.text_offset_packed >> 2);
+      const uint32_t* __restrict__ gp = p.packed + ((RAW ? mp.pattern_offset : mp.pattern_offset_packed) >> 2);
+      const uint32_t* __restrict__ gt = p.packed + ((RAW ? mp.text_offset : mp.text_offset_packed) >> 2);
       for (int i = tid; i < pwords; i += NT) Pw[i] = gp[i];
       for (int i = tid; i < twords; i += NT) Tw[i] = gt[i];
       for (int i = tid; i < dm; i += NT) { mlo[i] = 1; mhi[i] = -1; btrow[i] = WFA_ROW_NONE; }
@@ -199,7 +206,7 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
       }
       uint32_t d0 = 0;
       if (tid == 0) {
-        const int h0 = extend_lcp(Pw, Tw, plen, tlen, 0, 0);
+        const int h0 = extend_lcp<RAW>(Pw, Tw, plen, tlen, 0, 0);
         Mr[kidx0] = off_store<OffT>(h0);
         mlo[0] = 0; mhi[0] = 0; btrow[0] = row_s;
         d0 = (kend == 0 && h0 >= tlen) ? 1u : 0u;
@@ -308,7 +315,7 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
           const bool i_ok = have_i && ((unsigned)ins <= (unsigned)tlen) && ((unsigned)(ins - k) <= (unsigned)plen);
           const bool d_ok = have_d && ((unsigned)del <= (unsigned)tlen) && ((unsigned)(del - k) <= (unsigned)plen);
           if (ok) {
-            mv = extend_lcp(Pw, Tw, plen, tlen, k, mv);
+            mv = extend_lcp<RAW>(Pw, Tw, plen, tlen, k, mv);
           } else {
             mv = OFF_NULL;
             if constexpr (BT) code &= ~3u;
@@ -369,20 +376,40 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
   }
 }
 
-template <int NW, bool BT, typename OffT, bool GR>
+template <int NW, bool BT, typename OffT, bool GR, bool RAW>
 void launch_inst(const WfaAlignParams& p, size_t lds, int grid, hipStream_t stream) {
-  auto k = wfa_align_kernel<NW, BT, OffT, GR>;
-  hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  auto k = wfa_align_kernel<NW, BT, OffT, GR, RAW>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k, dim3(grid), dim3(NW * 64), lds, stream, p);
 }
 
-template <int NW, bool BT, typename OffT, bool GR>
+template <int NW, bool BT, typename OffT, bool GR, bool RAW>
 int occ_inst(size_t lds) {
-  auto k = wfa_align_kernel<NW, BT, OffT, GR>;
-  hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  auto k = wfa_align_kernel<NW, BT, OffT, GR, RAW>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   int nb = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k), NW * 64, lds) != hipSuccess) nb = 0;
   return nb;
+}
+
+// tier -> instantiation
+template <bool BT, bool RAW>
+void launch_tier(const WfaAlignParams& p, int tier, size_t lds, int grid, hipStream_t stream) {
+  switch (tier) {
+    case 0: launch_inst<1, BT, int16_t, false, RAW>(p, lds, grid, stream); break;
+    case 1: launch_inst<4, BT, int16_t, false, RAW>(p, lds, grid, stream); break;
+    case 2: launch_inst<16, BT, int16_t, false, RAW>(p, lds, grid, stream); break;
+    default: launch_inst<16, BT, int32_t, true, RAW>(p, lds, grid, stream); break;
+  }
+}
+template <bool BT, bool RAW>
+int occ_tier(int tier, size_t lds) {
+  switch (tier) {
+    case 0: return occ_inst<1, BT, int16_t, false, RAW>(lds);
+    case 1: return occ_inst<4, BT, int16_t, false, RAW>(lds);
+    case 2: return occ_inst<16, BT, int16_t, false, RAW>(lds);
+    default: return occ_inst<16, BT, int32_t, true, RAW>(lds);
+  }
 }
 
 }  // namespace
@@ -395,33 +422,13 @@ size_t wfa_align_lds_bytes(const WfaAlignParams& p, int tier) {
   return ((ring + seq + meta) + 15) & ~(size_t)15;
 }
 
-void wfa_launch_align(const WfaAlignParams& p, int tier, bool with_bt, int grid, hipStream_t stream) {
+void wfa_launch_align(const WfaAlignParams& p, int tier, bool with_bt, bool raw, int grid, hipStream_t stream) {
   const size_t lds = wfa_align_lds_bytes(p, tier);
-  switch (tier) {
-    case 0:
-      if (with_bt) launch_inst<1, true, int16_t, false>(p, lds, grid, stream);
-      else launch_inst<1, false, int16_t, false>(p, lds, grid, stream);
-      break;
-    case 1:
-      if (with_bt) launch_inst<4, true, int16_t, false>(p, lds, grid, stream);
-      else launch_inst<4, false, int16_t, false>(p, lds, grid, stream);
-      break;
-    case 2:
-      if (with_bt) launch_inst<16, true, int16_t, false>(p, lds, grid, stream);
-      else launch_inst<16, false, int16_t, false>(p, lds, grid, stream);
-      break;
-    default:
-      if (with_bt) launch_inst<16, true, int32_t, true>(p, lds, grid, stream);
-      else launch_inst<16, false, int32_t, true>(p, lds, grid, stream);
-      break;
-  }
+  if (with_bt) { if (raw) launch_tier<true, true>(p, tier, lds, grid, stream); else launch_tier<true, false>(p, tier, lds, grid, stream); }
+  else { if (raw) launch_tier<false, true>(p, tier, lds, grid, stream); else launch_tier<false, false>(p, tier, lds, grid, stream); }
 }
 
-int wfa_align_max_blocks_per_cu(int tier, bool with_bt, size_t lds) {
-  switch (tier) {
-    case 0: return with_bt ? occ_inst<1, true, int16_t, false>(lds) : occ_inst<1, false, int16_t, false>(lds);
-    case 1: return with_bt ? occ_inst<4, true, int16_t, false>(lds) : occ_inst<4, false, int16_t, false>(lds);
-    case 2: return with_bt ? occ_inst<16, true, int16_t, false>(lds) : occ_inst<16, false, int16_t, false>(lds);
-    default: return with_bt ? occ_inst<16, true, int32_t, true>(lds) : occ_inst<16, false, int32_t, true>(lds);
-  }
+int wfa_align_max_blocks_per_cu(int tier, bool with_bt, bool raw, size_t lds) {
+  if (with_bt) return raw ? occ_tier<true, true>(tier, lds) : occ_tier<true, false>(tier, lds);
+  return raw ? occ_tier<false, true>(tier, lds) : occ_tier<false, false>(tier, lds);
 }

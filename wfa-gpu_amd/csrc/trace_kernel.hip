@@ -23,20 +23,24 @@ namespace {
 
 enum : uint8_t { OP_X = 1, OP_I = 2, OP_D = 3, OP_EXT_AFTER = 0x10 };
 
-__device__ __forceinline__ int lcp_packed(const uint32_t* __restrict__ Pw,
-                                          const uint32_t* __restrict__ Tw, int plen, int tlen,
-                                          int v, int h) {
+template <bool RAW>
+__device__ __forceinline__ int lcp_seq(const uint32_t* __restrict__ Pw,
+                                       const uint32_t* __restrict__ Tw, int plen, int tlen,
+                                       int v, int h) {
+  constexpr int SH = RAW ? 2 : 4;
+  constexpr int PER = 1 << SH;
+  constexpr int BITS = RAW ? 3 : 1;
   int n_total = 0;
   int rem = min(plen - v, tlen - h);
   while (rem > 0) {
-    const int pi = v >> 4, ti = h >> 4;
-    const uint32_t a = __builtin_amdgcn_alignbit(Pw[pi + 1], Pw[pi], (v & 15) << 1);
-    const uint32_t b = __builtin_amdgcn_alignbit(Tw[ti + 1], Tw[ti], (h & 15) << 1);
+    const int pi = v >> SH, ti = h >> SH;
+    const uint32_t a = __builtin_amdgcn_alignbit(Pw[pi + 1], Pw[pi], (v & (PER - 1)) << BITS);
+    const uint32_t b = __builtin_amdgcn_alignbit(Tw[ti + 1], Tw[ti], (h & (PER - 1)) << BITS);
     const uint32_t d = a ^ b;
-    int n = d ? (__builtin_ctz(d) >> 1) : 16;
+    int n = d ? (__builtin_ctz(d) >> BITS) : PER;
     n = min(n, rem);
     n_total += n; h += n; v += n; rem -= n;
-    if (n < 16) break;
+    if (n < PER) break;
   }
   return n_total;
 }
@@ -88,12 +92,13 @@ struct RleSink {
   }
 };
 
+template <bool RAW>
 __device__ __forceinline__ uint32_t replay(const uint8_t* ops, uint32_t nops,
                                            const uint32_t* Pw, const uint32_t* Tw,
                                            int plen, int tlen, char* out) {
   RleSink sink{out, 0, 0, 0};
   int v = 0, h = 0;
-  int n = lcp_packed(Pw, Tw, plen, tlen, v, h);
+  int n = lcp_seq<RAW>(Pw, Tw, plen, tlen, v, h);
   sink.push('M', (uint32_t)n); v += n; h += n;
   for (uint32_t i = 0; i < nops; ++i) {
     const uint8_t op = ops[i];
@@ -103,7 +108,7 @@ __device__ __forceinline__ uint32_t replay(const uint8_t* ops, uint32_t nops,
       default:   sink.push('D', 1); ++v; break;
     }
     if (op & OP_EXT_AFTER) {
-      n = lcp_packed(Pw, Tw, plen, tlen, v, h);
+      n = lcp_seq<RAW>(Pw, Tw, plen, tlen, v, h);
       sink.push('M', (uint32_t)n); v += n; h += n;
     }
   }
@@ -129,8 +134,8 @@ __global__ void __launch_bounds__(TRACE_THREADS) wfa_trace_kernel(const WfaTrace
     score = p.score[pair];
     const WfaSeqPair mp = p.meta[pair];
     plen = (int)mp.pattern_len; tlen = (int)mp.text_len;
-    Pw = p.packed + (mp.pattern_offset_packed >> 2);
-    Tw = p.packed + (mp.text_offset_packed >> 2);
+    Pw = p.packed + ((p.raw ? mp.pattern_offset : mp.pattern_offset_packed) >> 2);
+    Tw = p.packed + ((p.raw ? mp.text_offset : mp.text_offset_packed) >> 2);
   }
   // ---- phase 1: backward walk ---------------------------------------------
   // every operation costs at least min(x, e) >= 1, so `score` bytes suffice
@@ -172,7 +177,7 @@ __global__ void __launch_bounds__(TRACE_THREADS) wfa_trace_kernel(const WfaTrace
   // ---- phase 2: forward replay, size then write ------------------------------
   uint32_t len = 0;
   if (active && !fail) {
-    len = replay(q, nops, Pw, Tw, plen, tlen, nullptr);
+    len = p.raw ? replay<true>(q, nops, Pw, Tw, plen, tlen, nullptr) : replay<false>(q, nops, Pw, Tw, plen, tlen, nullptr);
     if (len == 0xFFFFFFFFu) fail = true;
   }
   const uint32_t need_txt = (active && !fail) ? len + 1u : 0u;
@@ -180,7 +185,8 @@ __global__ void __launch_bounds__(TRACE_THREADS) wfa_trace_kernel(const WfaTrace
   if (active && !fail && txt_off + need_txt > p.text_cap) fail = true;
   if (active) {
     if (!fail) {
-      replay(q, nops, Pw, Tw, plen, tlen, p.text + txt_off);
+      if (p.raw) replay<true>(q, nops, Pw, Tw, plen, tlen, p.text + txt_off);
+      else replay<false>(q, nops, Pw, Tw, plen, tlen, p.text + txt_off);
       p.cigar_off[pair] = txt_off;
       p.cigar_len[pair] = len;
     } else {

@@ -54,7 +54,7 @@ struct WfaBtRowHdr {
 };
 
 struct WfaAlignParams {
-  const uint32_t* packed;        // packed sequences (word base)
+  const uint32_t* packed;        // packed sequences (word base); RAW kernels: the ASCII buffer
   const WfaSeqPair* meta;
   const uint32_t* work;          // pair indices to process (NULL: identity)
   uint32_t n_work;
@@ -80,6 +80,7 @@ struct WfaAlignParams {
 };
 
 struct WfaTraceParams {
+  int raw;                       // 1: sequences are the ASCII buffer (byte compare), 0: 2-bit packed
   const uint32_t* packed;
   const WfaSeqPair* meta;
   const uint32_t* work;          // pair indices (NULL: identity)
@@ -107,6 +108,6 @@ void wfa_launch_pack(const char* d_ascii, const WfaSeqPair* d_meta, uint32_t n_p
 // tier: 0 -> 1 wave/alignment (LDS ring), 1 -> 4 waves (LDS), 2 -> 16 waves (LDS),
 //       3 -> 16 waves, int32 ring in HBM.  Returns the dynamic LDS bytes used.
 size_t wfa_align_lds_bytes(const WfaAlignParams& p, int tier);
-void wfa_launch_align(const WfaAlignParams& p, int tier, bool with_bt, int grid, hipStream_t stream);
-int wfa_align_max_blocks_per_cu(int tier, bool with_bt, size_t lds_bytes);
+void wfa_launch_align(const WfaAlignParams& p, int tier, bool with_bt, bool raw, int grid, hipStream_t stream);
+int wfa_align_max_blocks_per_cu(int tier, bool with_bt, bool raw, size_t lds_bytes);
 void wfa_launch_trace(const WfaTraceParams& p, hipStream_t stream);

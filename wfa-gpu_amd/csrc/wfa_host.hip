@@ -224,7 +224,7 @@ namespace {
 struct TierPlan { int tier; int hcap; int max_score; size_t lds; int blocks_per_cu; };
 
 // Smallest tier whose LDS footprint fits for `hcap` diagonals each side.
-bool plan_tier(const wfagpu_amd_ctx* c, WfaAlignParams& p, int hcap, int max_score, unsigned max_seq_len, bool bt, TierPlan* out) {
+bool plan_tier(const wfagpu_amd_ctx* c, WfaAlignParams& p, int hcap, int max_score, unsigned max_seq_len, bool bt, bool raw, TierPlan* out) {
   p.hcap = hcap;
   p.rs = (2 * hcap + 3 + 1) & ~1;
   p.max_score = max_score;
@@ -237,14 +237,14 @@ bool plan_tier(const wfagpu_amd_ctx* c, WfaAlignParams& p, int hcap, int max_sco
     if (lds > budget[t]) continue;
     if (t == 0 && width > 1024) continue;
     if (t == 1 && width > 8192) continue;
-    const int nb = wfa_align_max_blocks_per_cu(t, bt, lds);
+    const int nb = wfa_align_max_blocks_per_cu(t, bt, raw, lds);
     if (nb < 1) continue;
     *out = {t, hcap, max_score, lds, nb};
     return true;
   }
   const size_t lds = wfa_align_lds_bytes(p, 3);
   if (lds > c->lds_per_block_max) return false;   // sequences themselves do not fit LDS
-  const int nb = wfa_align_max_blocks_per_cu(3, bt, lds);
+  const int nb = wfa_align_max_blocks_per_cu(3, bt, raw, lds);
   *out = {3, hcap, max_score, lds, std::max(1, std::min(nb, 2))};
   return true;
 }
@@ -341,20 +341,28 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
                      static_cast<uint32_t*>(c->status.p));
   HIP_TRY(hipEventRecord(c->ev_pack, st));
 
-  // pending list of this call: everything not flagged
-  uint32_t* pending = static_cast<uint32_t*>(c->list_c.p);
-  hipLaunchKernelGGL(k_compact, dim3(cdiv(n, 256)), dim3(256), 0, st, (const uint32_t*)nullptr, n,
-                     static_cast<const uint32_t*>(c->status.p), MASK(WFA_ST_PENDING), pending, ct + CT_LIST);
-  if (read_counters(c)) return -1;
-  uint32_t n_pending = (uint32_t)c->h_counters[CT_LIST];
-  const uint32_t n_alpha = n - n_pending;
-
   float align_ms = 0.f, trace_ms = 0.f;
   uint32_t grid_cap = UINT32_MAX;   // lowered when a pass makes no progress for lack of arena
   unsigned long long text_used = 0;
   const int hmax = (int)std::min<unsigned>(max_len, INT_MAX / 4);
   int rc = 0;
 
+  // two classes of pairs: ACGT-only (2-bit packed kernels) and the rest (byte-compare kernels)
+  for (int cls = 0; cls < 2; ++cls) {
+  const bool raw = cls == 1;
+  if (zero_counter(c, CT_LIST)) return -1;
+  uint32_t* pending = static_cast<uint32_t*>(c->list_c.p);
+  hipLaunchKernelGGL(k_compact, dim3(cdiv(n, 256)), dim3(256), 0, st, (const uint32_t*)nullptr, n,
+                     static_cast<const uint32_t*>(c->status.p), raw ? MASK(WFA_ST_ALPHABET) : MASK(WFA_ST_PENDING), pending,
+                     ct + CT_LIST);
+  if (read_counters(c)) return -1;
+  uint32_t n_pending = (uint32_t)c->h_counters[CT_LIST];
+  if (raw) {
+    c->stats.pairs_raw = n_pending;
+    ap.packed = reinterpret_cast<const uint32_t*>(b->d_sequences);
+    ap.seq_words_cap = (int)((max_len + 3) / 4 + 1);
+  }
+  grid_cap = UINT32_MAX;
   while (n_pending > 0) {
     c->stats.sub_batches++;
     // ---- forward pass with tier escalation ----------------------------------
@@ -367,7 +375,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
     int max_score = max_error;
     for (int round = 0; n_cur > 0; ++round) {
       TierPlan tp;
-      if (!plan_tier(c, ap, hcap, max_score, max_len, compute_cigar, &tp)) {
+      if (!plan_tier(c, ap, hcap, max_score, max_len, compute_cigar, raw, &tp)) {
         fprintf(stderr, "[!] ERROR: sequences of %u bases do not fit the LDS staging area\n", max_len);
         return -1;
       }
@@ -382,7 +390,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       const int grid = (int)std::min<uint32_t>(std::min<uint32_t>(n_cur, grid_cap), (uint32_t)(c->num_cus * tp.blocks_per_cu));
       if (zero_counter(c, CT_WORK, 2)) return -1;   // work counter + list counter
       HIP_TRY(hipEventRecord(c->ev_a0, st));
-      wfa_launch_align(ap, tp.tier, compute_cigar, grid, st);
+      wfa_launch_align(ap, tp.tier, compute_cigar, raw, grid, st);
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipEventRecord(c->ev_a1, st));
       uint32_t* nxt = spare[flip]; flip ^= 1;
@@ -419,6 +427,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       if (c->ops.ensure(ops_need, st)) return -1;
       if (c->text.ensure(std::max<size_t>(text_need, c->text_cfg), st, text_used)) return -1;
       WfaTraceParams tp{};
+      tp.raw = raw ? 1 : 0;
       tp.packed = ap.packed; tp.meta = ap.meta; tp.work = pending; tp.n_work = n_pending;
       tp.x = pen.x; tp.oe = oe; tp.e = pen.e;
       tp.score = d_scores; tp.status = static_cast<const uint32_t*>(c->status.p);
@@ -476,6 +485,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
     c->stats.cells = c->h_counters[CT_CELLS];
     pending = nxt_pending; n_pending = n_nomem;
   }
+  }  // class loop
   HIP_TRY(hipEventRecord(c->ev_end, st));
   HIP_TRY(hipStreamSynchronize(st));
   float ms = 0.f;
@@ -488,10 +498,6 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
     if (d_text) *d_text = static_cast<const char*>(c->text.p);
     if (d_off) *d_off = static_cast<const unsigned long long*>(c->cig_off.p);
     if (d_len) *d_len = static_cast<const unsigned int*>(c->cig_len.p);
-  }
-  if (n_alpha) {
-    fprintf(stderr, "[!] ERROR: %u pairs contain bytes outside ACGT; the byte-compare tier is not built yet\n", n_alpha);
-    rc = -2;
   }
   return rc;
 }

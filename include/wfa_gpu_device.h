@@ -52,6 +52,7 @@ typedef struct {
     unsigned int pairs_tier[4];        /* pairs finished per kernel tier                  */
     unsigned int pairs_retried;        /* pairs that needed a wider tier                  */
     unsigned int pairs_raw;            /* pairs with bytes outside ACGT (byte-compare kernels) */
+    unsigned int pairs_banded;         /* pairs finished by the adaptive-band kernels          */
     unsigned int sub_batches;          /* arena-bounded passes                            */
     size_t lds_bytes_tier0;
     int blocks_per_cu_tier0;
@@ -74,13 +75,15 @@ int wfagpu_amd_pack_device(wfagpu_amd_ctx_t* ctx, const wfagpu_amd_batch_t* batc
 
 /* The whole hot path on a resident batch: pack -> wavefront kernels (tier
  * escalation on the device, never on the CPU) -> backtrace + CIGAR text.
+ *   band          BAND_NONE (-1) for the exact search, else the re-centring period of the adaptive
+ *                 band heuristic and band_width its number of diagonals (the reference's -B and -t)
  *   d_scores      device int32[num_pairs], positive scores
  *   compute_cigar when true the CIGAR text stays in the context's arena:
  *                 *d_text, *d_off (uint64 byte offsets), *d_len (uint32 strlen)
  *                 are device pointers valid until the next call on ctx.
  * Blocking (returns after the stream has drained).  0 on success. */
 int wfagpu_amd_align_device(wfagpu_amd_ctx_t* ctx, const wfagpu_amd_batch_t* batch,
-                            affine_penalties_t penalties, int max_error, int band,
+                            affine_penalties_t penalties, int max_error, int band, int band_width,
                             bool compute_cigar, int32_t* d_scores,
                             const char** d_text, const unsigned long long** d_off,
                             const unsigned int** d_len);

@@ -176,3 +176,33 @@ def test_full_size_properties(aligner):
     for i in range(0, n, 7):
         ok, cost = oracle_lib.check_cigar(pairs[i][0], pairs[i][1], c[i], (2, 3, 1))
         assert ok and cost == s[i]
+
+
+@pytest.mark.parametrize("n,length,err,beta,lam,max_error,min_recall", [
+    (512, 10000, 0.03, 512, 25, 3000, 0.95),     # BASELINE configs[3] shape: -e 3000 -t 512 -B auto
+    (2000, 1000, 0.05, 128, 25, 300, 0.90),
+    (2000, 1000, 0.05, 64, 10, 300, 0.60),
+    (300, 3000, 0.15, 256, 50, 2000, 0.50),
+])
+def test_adaptive_band_is_valid_and_mostly_optimal(aligner, n, length, err, beta, lam, max_error, min_recall):
+    """the reference's banded mode has no bit-defined output, so parity = every CIGAR replays onto its
+    pair, its gap-affine cost equals the reported score, the score is never below the optimum, and recall (share of
+    optimal scores) is in the reference's range (img/approximate-recall.png: 96.8-99.9 % on its data).  Also: the result
+    is deterministic, and pairs the band cannot finish are finished exactly on the GPU."""
+    buf, meta = wfagpu.generate_pairs(n, length, err, seed=31)
+    batch = aligner.upload(buf, meta)
+    s, c = aligner.align(batch, (2, 3, 1), max_error=max_error, compute_cigar=True, band=lam, band_width=beta)
+    st = aligner.stats()
+    assert st.pairs_banded > 0
+    s2, c2 = aligner.align(batch, (2, 3, 1), max_error=max_error, compute_cigar=True, band=lam, band_width=beta)
+    assert np.array_equal(s, s2) and c == c2
+    so, _, _ = oracle_lib.oracle_batch(buf, meta, (2, 3, 1), cigar=False, nthreads=8)
+    assert (s >= so).all()
+    recall = float((s == so).mean())
+    print(f"banded beta={beta} lambda={lam} L={length} err={err}: recall {recall:.4f}, banded pairs {st.pairs_banded}/{n}")
+    assert recall >= min_recall
+    for (p, t), cg, sc in zip(wfagpu.pairs_from_layout(buf, meta), c, s):
+        ok, cost = oracle_lib.check_cigar(p, t, cg, (2, 3, 1))
+        assert ok and cost == sc
+    s3, _ = aligner.align(batch, (2, 3, 1), max_error=max_error, compute_cigar=False, band=lam, band_width=beta)
+    assert np.array_equal(s3, s)

@@ -57,7 +57,7 @@ class Batch(C.Structure):  # wfagpu_amd_batch_t
 class Stats(C.Structure):  # wfagpu_amd_stats_t
     _fields_ = [("pack_ms", C.c_float), ("align_ms", C.c_float), ("trace_ms", C.c_float), ("total_ms", C.c_float),
                 ("align_launches", C.c_int), ("cells", C.c_ulonglong), ("arena_units", C.c_ulonglong),
-                ("text_bytes", C.c_ulonglong), ("pairs_tier", C.c_uint * 4), ("pairs_retried", C.c_uint), ("pairs_raw", C.c_uint),
+                ("text_bytes", C.c_ulonglong), ("pairs_tier", C.c_uint * 4), ("pairs_retried", C.c_uint), ("pairs_raw", C.c_uint), ("pairs_banded", C.c_uint),
                 ("sub_batches", C.c_uint), ("lds_bytes_tier0", C.c_size_t), ("blocks_per_cu_tier0", C.c_int)]
 
 
@@ -98,7 +98,7 @@ def load():
     lib.wfagpu_amd_fill_packed_offsets.restype = C.c_size_t
     lib.wfagpu_amd_pack_device.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p]
     lib.wfagpu_amd_pack_device.restype = C.c_int
-    lib.wfagpu_amd_align_device.argtypes = [C.c_void_p, C.POINTER(Batch), Penalties, C.c_int, C.c_int, C.c_bool,
+    lib.wfagpu_amd_align_device.argtypes = [C.c_void_p, C.POINTER(Batch), Penalties, C.c_int, C.c_int, C.c_int, C.c_bool,
                                             C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                             C.POINTER(C.c_void_p)]
     lib.wfagpu_amd_align_device.restype = C.c_int
@@ -274,7 +274,7 @@ class DeviceAligner:
             raise RuntimeError(f"wfagpu_amd_pack_device failed ({rc})")
         return d_packed.cpu().numpy().view(np.uint32), d_flags.cpu().numpy()
 
-    def align(self, batch, penalties, max_error, compute_cigar, band=-1, fetch=True):
+    def align(self, batch, penalties, max_error, compute_cigar, band=-1, band_width=0, fetch=True):
         """Returns (scores ndarray, cigars list or None).  With fetch=False results stay on the device
         and (d_scores tensor, (text_ptr, off_ptr, len_ptr)) is returned."""
         torch = self.torch
@@ -283,7 +283,7 @@ class DeviceAligner:
         d_scores = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
         t, o, l = C.c_void_p(), C.c_void_p(), C.c_void_p()
         pen = Penalties(*penalties)
-        rc = self.lib.wfagpu_amd_align_device(self.ctx, C.byref(batch), pen, int(max_error), int(band),
+        rc = self.lib.wfagpu_amd_align_device(self.ctx, C.byref(batch), pen, int(max_error), int(band), int(band_width),
                                               bool(compute_cigar), d_scores.data_ptr(), C.byref(t), C.byref(o),
                                               C.byref(l))
         if rc != 0:

@@ -111,7 +111,16 @@ __device__ __forceinline__ int rd_cell(const OffT* row, int kidx0, int k, RowRan
   return ((unsigned)(k - r.lo) <= (unsigned)r.w) ? val : OFF_NULL;
 }
 
-template <int NW, bool BT, typename OffT, bool GLOBAL_RING, bool RAW>
+// Banded rows are stored relative to their own window base (the window moves), so the index
+// is only formed for in-range diagonals.
+template <typename OffT>
+__device__ __forceinline__ int rd_cell_rel(const OffT* row, int base, int k, RowRange r) {
+  const bool in = (unsigned)(k - r.lo) <= (unsigned)r.w;
+  const int val = (int)row[in ? k - base : 0];
+  return in ? val : OFF_NULL;
+}
+
+template <int NW, bool BT, typename OffT, bool GLOBAL_RING, bool RAW, bool BANDED>
 __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NT = NW * 64;
@@ -144,6 +153,8 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
   uint32_t* btrow = reinterpret_cast<uint32_t*>(dhi + de);
   int* red = reinterpret_cast<int*>(btrow + dm);        // [3][8]
   uint32_t* bslot = reinterpret_cast<uint32_t*>(red + 24);  // [2]
+  int* mbase = reinterpret_cast<int*>(bslot + 2);       // [dm] window base of each M row (BANDED)
+  int* ebase = mbase + dm;                              // [de] window base of each I/D row
 
   uint32_t chunk_cur = 0, chunk_left = 0;   // arena units owned by this block
 
@@ -207,7 +218,8 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
       uint32_t d0 = 0;
       if (tid == 0) {
         const int h0 = extend_lcp<RAW>(Pw, Tw, plen, tlen, 0, 0);
-        Mr[kidx0] = off_store<OffT>(h0);
+        if constexpr (BANDED) { Mr[0] = off_store<OffT>(h0); mbase[0] = 0; }
+        else Mr[kidx0] = off_store<OffT>(h0);
         mlo[0] = 0; mhi[0] = 0; btrow[0] = row_s;
         d0 = (kend == 0 && h0 >= tlen) ? 1u : 0u;
       }
@@ -248,7 +260,50 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
         lo = min(lo, molo - 1); hi = max(hi, mohi + 1);
         lo = min(lo, ielo + 1); hi = max(hi, iehi + 1);
         lo = min(lo, delo - 1); hi = max(hi, dehi - 1);
-        if (lo < -hcap || hi > hcap) { status = WFA_ST_BAND; break; }
+        if constexpr (!BANDED) {
+          if (lo < -hcap || hi > hcap) { status = WFA_ST_BAND; break; }
+        } else {
+          // Adaptive band (reference: sequence_distance_kernel_aband.cu:104-130): keep at most
+          // band_width diagonals; every band_period scores re-centre the window on the diagonal of
+          // the mismatch-source wavefront whose furthest point is closest to the end, otherwise
+          // shave the excess off both sides.
+          const int beta = p.band_width;
+          const int excess = (hi - lo + 1) - beta;
+          if (excess > 0) {
+            bool recentred = false;
+            if (!mx_null && (s % p.band_period) == 0) {
+              const OffT* rowc = Mr + (size_t)sl_x * rs;
+              const int cbase = mbase[sl_x];
+              uint32_t best = 0xFFFFFFFFu;
+              for (int kk = mxlo + tid; kk <= mxhi; kk += NT) {
+                const int off = (int)rowc[kk - cbase];
+                if (off >= 0) {
+                  const int dist = max(plen - (off - kk), tlen - off);
+                  best = min(best, ((uint32_t)dist << 16) | (uint32_t)(kk - mxlo));
+                }
+              }
+#pragma unroll
+              for (int d = 32; d > 0; d >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, d));
+              if constexpr (NW > 1) {
+                uint32_t* slot = bslot + 1;
+                if (tid == 0) *slot = 0xFFFFFFFFu;
+                __syncthreads();
+                if (lane == 0) atomicMin(slot, best);
+                __syncthreads();
+                best = *slot;
+                __syncthreads();
+              }
+              if (best != 0xFFFFFFFFu) {
+                const int centre = mxlo + (int)(best & 0xFFFFu);
+                int nlo = centre - beta / 2;
+                nlo = max(lo, min(nlo, hi - beta + 1));
+                lo = nlo; hi = nlo + beta - 1;
+                recentred = true;
+              }
+            }
+            if (!recentred) { hi -= (excess + 1) / 2; lo += excess / 2; }
+          }
+        }
         const bool have_i = !(mo_null && ie_null);
         const bool have_d = !(mo_null && de_null);
         const int width = hi - lo + 1;
@@ -285,6 +340,8 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
         OffT* out_m = Mr + (size_t)slot_m * rs;
         OffT* out_i = Ir + (size_t)slot_e * rs;
         OffT* out_d = Dr + (size_t)slot_e * rs;
+        const int base_mx = BANDED ? mbase[sl_x] : 0, base_mo = BANDED ? mbase[sl_oe] : 0, base_e = BANDED ? ebase[sl_e] : 0;
+        const int wbase = BANDED ? -lo : kidx0;   // index of diagonal 0 in the rows written now
 
         int wmlo = INT_MAX, wmhi = INT_MIN, wilo = INT_MAX, wihi = INT_MIN, wdlo = INT_MAX, wdhi = INT_MIN;
         bool my_done = false;
@@ -293,11 +350,20 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
           const bool active = kraw <= hi;
           const int k = active ? kraw : hi;
           // recurrences (wavefront_compute_affine.c:66-84)
-          const int m_x = rd_cell(row_mx, kidx0, k, rg_mx);
-          const int m_ol = rd_cell(row_mo, kidx0, k - 1, rg_mo);
-          const int m_or = rd_cell(row_mo, kidx0, k + 1, rg_mo);
-          const int i_e = rd_cell(row_ie, kidx0, k - 1, rg_ie);
-          const int d_e = rd_cell(row_de, kidx0, k + 1, rg_de);
+          int m_x, m_ol, m_or, i_e, d_e;
+          if constexpr (BANDED) {
+            m_x = rd_cell_rel(row_mx, base_mx, k, rg_mx);
+            m_ol = rd_cell_rel(row_mo, base_mo, k - 1, rg_mo);
+            m_or = rd_cell_rel(row_mo, base_mo, k + 1, rg_mo);
+            i_e = rd_cell_rel(row_ie, base_e, k - 1, rg_ie);
+            d_e = rd_cell_rel(row_de, base_e, k + 1, rg_de);
+          } else {
+            m_x = rd_cell(row_mx, kidx0, k, rg_mx);
+            m_ol = rd_cell(row_mo, kidx0, k - 1, rg_mo);
+            m_or = rd_cell(row_mo, kidx0, k + 1, rg_mo);
+            i_e = rd_cell(row_ie, kidx0, k - 1, rg_ie);
+            d_e = rd_cell(row_de, kidx0, k + 1, rg_de);
+          }
           const int ins = max(m_ol, i_e) + 1;
           const int del = max(m_or, d_e);
           const int mis = m_x + 1;
@@ -321,9 +387,9 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
             if constexpr (BT) code &= ~3u;
           }
           if (active) {
-            out_m[kidx0 + k] = off_store<OffT>(mv);
-            if (have_i) out_i[kidx0 + k] = off_store<OffT>(ins);
-            if (have_d) out_d[kidx0 + k] = off_store<OffT>(del);
+            out_m[wbase + k] = off_store<OffT>(mv);
+            if (have_i) out_i[wbase + k] = off_store<OffT>(ins);
+            if (have_d) out_d[wbase + k] = off_store<OffT>(del);
             if constexpr (BT) codes[k - lo] = (uint8_t)code;
             if (k == kend && mv >= tlen) my_done = true;
           }
@@ -359,6 +425,7 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
         if (wilo > wihi) { wilo = 1; wihi = -1; }
         if (wdlo > wdhi) { wdlo = 1; wdhi = -1; }
         mlo[slot_m] = wmlo; mhi[slot_m] = wmhi; btrow[slot_m] = row_s;
+        if constexpr (BANDED) { mbase[slot_m] = lo; ebase[slot_e] = lo; }
         ilo[slot_e] = wilo; ihi[slot_e] = wihi;
         dlo[slot_e] = wdlo; dhi[slot_e] = wdhi;
         if constexpr (NW == 1) block_sync<NW>();
@@ -376,39 +443,55 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
   }
 }
 
-template <int NW, bool BT, typename OffT, bool GR, bool RAW>
+template <int NW, bool BT, typename OffT, bool GR, bool RAW, bool BANDED>
 void launch_inst(const WfaAlignParams& p, size_t lds, int grid, hipStream_t stream) {
-  auto k = wfa_align_kernel<NW, BT, OffT, GR, RAW>;
+  auto k = wfa_align_kernel<NW, BT, OffT, GR, RAW, BANDED>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k, dim3(grid), dim3(NW * 64), lds, stream, p);
 }
 
-template <int NW, bool BT, typename OffT, bool GR, bool RAW>
+template <int NW, bool BT, typename OffT, bool GR, bool RAW, bool BANDED>
 int occ_inst(size_t lds) {
-  auto k = wfa_align_kernel<NW, BT, OffT, GR, RAW>;
+  auto k = wfa_align_kernel<NW, BT, OffT, GR, RAW, BANDED>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   int nb = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k), NW * 64, lds) != hipSuccess) nb = 0;
   return nb;
 }
 
-// tier -> instantiation
+// tier -> instantiation (banded kernels exist for the packed LDS tiers only)
 template <bool BT, bool RAW>
 void launch_tier(const WfaAlignParams& p, int tier, size_t lds, int grid, hipStream_t stream) {
   switch (tier) {
-    case 0: launch_inst<1, BT, int16_t, false, RAW>(p, lds, grid, stream); break;
-    case 1: launch_inst<4, BT, int16_t, false, RAW>(p, lds, grid, stream); break;
-    case 2: launch_inst<16, BT, int16_t, false, RAW>(p, lds, grid, stream); break;
-    default: launch_inst<16, BT, int32_t, true, RAW>(p, lds, grid, stream); break;
+    case 0: launch_inst<1, BT, int16_t, false, RAW, false>(p, lds, grid, stream); break;
+    case 1: launch_inst<4, BT, int16_t, false, RAW, false>(p, lds, grid, stream); break;
+    case 2: launch_inst<16, BT, int16_t, false, RAW, false>(p, lds, grid, stream); break;
+    default: launch_inst<16, BT, int32_t, true, RAW, false>(p, lds, grid, stream); break;
+  }
+}
+template <bool BT>
+void launch_tier_banded(const WfaAlignParams& p, int tier, size_t lds, int grid, hipStream_t stream) {
+  switch (tier) {
+    case 0: launch_inst<1, BT, int16_t, false, false, true>(p, lds, grid, stream); break;
+    case 1: launch_inst<4, BT, int16_t, false, false, true>(p, lds, grid, stream); break;
+    default: launch_inst<16, BT, int16_t, false, false, true>(p, lds, grid, stream); break;
   }
 }
 template <bool BT, bool RAW>
 int occ_tier(int tier, size_t lds) {
   switch (tier) {
-    case 0: return occ_inst<1, BT, int16_t, false, RAW>(lds);
-    case 1: return occ_inst<4, BT, int16_t, false, RAW>(lds);
-    case 2: return occ_inst<16, BT, int16_t, false, RAW>(lds);
-    default: return occ_inst<16, BT, int32_t, true, RAW>(lds);
+    case 0: return occ_inst<1, BT, int16_t, false, RAW, false>(lds);
+    case 1: return occ_inst<4, BT, int16_t, false, RAW, false>(lds);
+    case 2: return occ_inst<16, BT, int16_t, false, RAW, false>(lds);
+    default: return occ_inst<16, BT, int32_t, true, RAW, false>(lds);
+  }
+}
+template <bool BT>
+int occ_tier_banded(int tier, size_t lds) {
+  switch (tier) {
+    case 0: return occ_inst<1, BT, int16_t, false, false, true>(lds);
+    case 1: return occ_inst<4, BT, int16_t, false, false, true>(lds);
+    default: return occ_inst<16, BT, int16_t, false, false, true>(lds);
   }
 }
 
@@ -418,17 +501,22 @@ size_t wfa_align_lds_bytes(const WfaAlignParams& p, int tier) {
   size_t ring = 0;
   if (tier != 3) ring = (((size_t)(p.dm + 2 * p.de) * p.rs * sizeof(int16_t)) + 15) & ~(size_t)15;
   const size_t seq = (size_t)2 * p.seq_words_cap * 4;
-  const size_t meta = (size_t)(2 * p.dm + 4 * p.de + p.dm + 24 + 2) * 4;
+  const size_t meta = (size_t)(2 * p.dm + 4 * p.de + p.dm + 24 + 2 + p.dm + p.de) * 4;
   return ((ring + seq + meta) + 15) & ~(size_t)15;
 }
 
 void wfa_launch_align(const WfaAlignParams& p, int tier, bool with_bt, bool raw, int grid, hipStream_t stream) {
   const size_t lds = wfa_align_lds_bytes(p, tier);
+  if (p.band_width > 0) {
+    if (with_bt) launch_tier_banded<true>(p, tier, lds, grid, stream); else launch_tier_banded<false>(p, tier, lds, grid, stream);
+    return;
+  }
   if (with_bt) { if (raw) launch_tier<true, true>(p, tier, lds, grid, stream); else launch_tier<true, false>(p, tier, lds, grid, stream); }
   else { if (raw) launch_tier<false, true>(p, tier, lds, grid, stream); else launch_tier<false, false>(p, tier, lds, grid, stream); }
 }
 
-int wfa_align_max_blocks_per_cu(int tier, bool with_bt, bool raw, size_t lds) {
+int wfa_align_max_blocks_per_cu(int tier, bool with_bt, bool raw, bool banded, size_t lds) {
+  if (banded) return with_bt ? occ_tier_banded<true>(tier, lds) : occ_tier_banded<false>(tier, lds);
   if (with_bt) return raw ? occ_tier<true, true>(tier, lds) : occ_tier<true, false>(tier, lds);
   return raw ? occ_tier<false, true>(tier, lds) : occ_tier<false, false>(tier, lds);
 }

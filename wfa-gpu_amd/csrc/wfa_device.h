@@ -64,6 +64,8 @@ struct WfaAlignParams {
   int hcap;                      // diagonals supported: k in [-hcap, +hcap]
   int rs;                        // row stride (elements), even, >= 2*hcap+3
   int max_score;                 // give up (WFA_ST_SCORE) beyond this score
+  int band_width;                // > 0: adaptive band, diagonals kept per wavefront (banded kernels)
+  int band_period;               //      re-centre the band every this many scores
   int seq_words_cap;             // LDS words reserved per packed sequence
   int32_t* score;                // [pair] out
   uint32_t* status;              // [pair] out
@@ -109,5 +111,5 @@ void wfa_launch_pack(const char* d_ascii, const WfaSeqPair* d_meta, uint32_t n_p
 //       3 -> 16 waves, int32 ring in HBM.  Returns the dynamic LDS bytes used.
 size_t wfa_align_lds_bytes(const WfaAlignParams& p, int tier);
 void wfa_launch_align(const WfaAlignParams& p, int tier, bool with_bt, bool raw, int grid, hipStream_t stream);
-int wfa_align_max_blocks_per_cu(int tier, bool with_bt, bool raw, size_t lds_bytes);
+int wfa_align_max_blocks_per_cu(int tier, bool with_bt, bool raw, bool banded, size_t lds_bytes);
 void wfa_launch_trace(const WfaTraceParams& p, hipStream_t stream);

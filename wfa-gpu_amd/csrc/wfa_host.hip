@@ -225,9 +225,21 @@ struct TierPlan { int tier; int hcap; int max_score; size_t lds; int blocks_per_
 
 // Smallest tier whose LDS footprint fits for `hcap` diagonals each side.
 bool plan_tier(const wfagpu_amd_ctx* c, WfaAlignParams& p, int hcap, int max_score, unsigned max_seq_len, bool bt, bool raw, TierPlan* out) {
+  p.max_score = max_score;
+  if (p.band_width > 0) {
+    // adaptive band: the ring rows hold band_width diagonals whatever the score
+    p.hcap = INT_MAX / 4;
+    p.rs = (p.band_width + 2 + 1) & ~1;
+    const int t = p.band_width <= 256 ? 0 : (p.band_width <= 1024 ? 1 : 2);
+    const size_t lds = wfa_align_lds_bytes(p, t);
+    if (lds > c->lds_per_block_max || max_seq_len > 32766u || max_score > 30000) return false;
+    const int nb = wfa_align_max_blocks_per_cu(t, bt, false, true, lds);
+    if (nb < 1) return false;
+    *out = {t, p.hcap, max_score, lds, nb};
+    return true;
+  }
   p.hcap = hcap;
   p.rs = (2 * hcap + 3 + 1) & ~1;
-  p.max_score = max_score;
   const bool i16_ok = max_seq_len <= 32766u && max_score <= 30000;
   const size_t budget[3] = {40u << 10, 80u << 10, c->lds_per_block_max};
   // a single wavefront sweeps up to ~8 chunks per score before more waves pay off
@@ -237,14 +249,14 @@ bool plan_tier(const wfagpu_amd_ctx* c, WfaAlignParams& p, int hcap, int max_sco
     if (lds > budget[t]) continue;
     if (t == 0 && width > 1024) continue;
     if (t == 1 && width > 8192) continue;
-    const int nb = wfa_align_max_blocks_per_cu(t, bt, raw, lds);
+    const int nb = wfa_align_max_blocks_per_cu(t, bt, raw, false, lds);
     if (nb < 1) continue;
     *out = {t, hcap, max_score, lds, nb};
     return true;
   }
   const size_t lds = wfa_align_lds_bytes(p, 3);
   if (lds > c->lds_per_block_max) return false;   // sequences themselves do not fit LDS
-  const int nb = wfa_align_max_blocks_per_cu(3, bt, raw, lds);
+  const int nb = wfa_align_max_blocks_per_cu(3, bt, raw, false, lds);
   *out = {3, hcap, max_score, lds, std::max(1, std::min(nb, 2))};
   return true;
 }
@@ -263,7 +275,7 @@ int zero_counter(wfagpu_amd_ctx* c, int idx, int count = 1) {
 }  // namespace
 
 extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_batch_t* b,
-                                       affine_penalties_t pen, int max_error, int band,
+                                       affine_penalties_t pen, int max_error, int band, int band_width,
                                        bool compute_cigar, int32_t* d_scores,
                                        const char** d_text, const unsigned long long** d_off,
                                        const unsigned int** d_len) {
@@ -272,7 +284,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
     fprintf(stderr, "[!] ERROR: penalties must be x>0, o>=0, e>0 (got %d,%d,%d)\n", pen.x, pen.o, pen.e);
     return -1;
   }
-  (void)band;  // adaptive band: not implemented in this round (exact search is always valid)
+  const bool want_band = band > 0 && band_width > 0;
   HIP_TRY(hipSetDevice(c->device));
   const uint32_t n = (uint32_t)b->num_pairs;
   c->stats = wfagpu_amd_stats_t{};
@@ -375,7 +387,12 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
     int max_score = max_error;
     for (int round = 0; n_cur > 0; ++round) {
       TierPlan tp;
-      if (!plan_tier(c, ap, hcap, max_score, max_len, compute_cigar, raw, &tp)) {
+      // banded first attempt (packed class only); whatever it cannot finish goes to the exact tiers
+      ap.band_width = (want_band && !raw && round == 0) ? band_width : 0;
+      ap.band_period = band;
+      if (ap.band_width > 0 && !plan_tier(c, ap, hcap, std::min(max_score, 30000), max_len, compute_cigar, raw, &tp)) ap.band_width = 0;
+      if (ap.band_width > 0) c->stats.pairs_banded += n_cur;
+      if (ap.band_width == 0 && !plan_tier(c, ap, hcap, max_score, max_len, compute_cigar, raw, &tp)) {
         fprintf(stderr, "[!] ERROR: sequences of %u bases do not fit the LDS staging area\n", max_len);
         return -1;
       }
@@ -410,6 +427,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         return -1;
       }
       cur = nxt; n_cur = n_next;
+      if (ap.band_width > 0) { c->stats.pairs_banded -= n_next; continue; }   // banded misses: exact tiers from the start
       // widen: 4x the diagonals, no score limit beyond what 16-bit offsets allow
       hcap = (hcap >= hmax / 4) ? hmax : hcap * 4;
       max_score = (max_score == 30000 || max_len > 32766u) ? INT_MAX : 30000;

@@ -142,7 +142,7 @@ int run_shard(const CallArgs& a, Shard& sh) {
     b.d_sequences = d_seq; b.sequences_bytes = span; b.d_metadata = d_meta; b.num_pairs = n;
     b.packed_bytes = packed_bytes; b.max_seq_len = max_len;
     const char* d_text = nullptr; const unsigned long long* d_off = nullptr; const unsigned int* d_len = nullptr;
-    const int arc = wfagpu_amd_align_device(ctx, &b, a.opt.penalties, a.opt.max_error, a.opt.band, a.cigar, d_scores,
+    const int arc = wfagpu_amd_align_device(ctx, &b, a.opt.penalties, a.opt.max_error, a.opt.band, a.opt.threads_per_block, a.cigar, d_scores,
                                             &d_text, &d_off, &d_len);
     if (arc) { rc = arc; break; }
     hs.resize(n);

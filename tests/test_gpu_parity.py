@@ -206,3 +206,34 @@ def test_adaptive_band_is_valid_and_mostly_optimal(aligner, n, length, err, beta
         assert ok and cost == sc
     s3, _ = aligner.align(batch, (2, 3, 1), max_error=max_error, compute_cigar=False, band=lam, band_width=beta)
     assert np.array_equal(s3, s)
+
+
+@pytest.mark.parametrize("pen", [(2, 3, 1), (1, 0, 1), (5, 3, 2), (3, 1, 4)])
+def test_score_budget_window_is_exact(aligner, pen):
+    """The exact kernels only keep the diagonals an alignment of score <= max_error can visit.  Run every pair with
+    max_error EQUAL to its optimal score (the tightest window that must still succeed, no escalation) and with
+    max_error one below (must escalate): score and CIGAR stay byte-identical to WFA2's."""
+    rng = random.Random(2024 + sum(pen))
+    pairs = _rand_pairs(rng, 500, 120, err=0.2) + _rand_pairs(rng, 100, 600, err=0.1)
+    # long gaps: the window is asymmetric around kend/2
+    pairs += [(bytes(rng.choice(b"ACGT") for _ in range(60)), bytes(rng.choice(b"ACGT") for _ in range(60 + d))) for d in range(0, 40, 3)]
+    pairs += [(bytes(rng.choice(b"ACGT") for _ in range(60 + d)), bytes(rng.choice(b"ACGT") for _ in range(60))) for d in range(0, 40, 3)]
+    buf, meta = wfagpu.layout_pairs(pairs)
+    so, co, _ = oracle_lib.oracle_batch(buf, meta, pen, cigar=True, nthreads=8)
+    groups = {}
+    for i in np.argsort(so, kind="stable"):
+        groups.setdefault(int(so[i]), []).append(int(i))
+    checked = 0
+    for score, idx in sorted(groups.items()):
+        if score == 0 or checked > 60:
+            continue
+        sub = [pairs[i] for i in idx]
+        sb, sm = wfagpu.layout_pairs(sub)
+        for me in (score, max(1, score - 1)):
+            s, c = _run(aligner, sb, sm, pen, max_error=me)
+            assert np.array_equal(s, so[idx]) and c == [co[i] for i in idx], (score, me)
+            if me == score:
+                assert aligner.stats().pairs_retried == 0, (score, me)
+            else:
+                assert aligner.stats().pairs_retried == len(idx), (score, me)
+        checked += 1

@@ -127,9 +127,8 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int dm = p.dm, de = p.de, rs = p.rs, hcap = p.hcap;
+  const int dm = p.dm, de = p.de, rs = p.rs;
   const int x = p.x, oe = p.oe, e = p.e;
-  const int kidx0 = hcap + 1;               // row index of diagonal 0
 
   // ---- carve LDS -------------------------------------------------------
   unsigned char* sp = smem;
@@ -176,7 +175,30 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
     uint32_t ncells = 1;
     bool done = false;
 
-    if (kend < -hcap || kend > hcap || pwords > p.seq_words_cap || twords > p.seq_words_cap) {
+    // Diagonal window that can hold an alignment of score <= max_score (exact, not a heuristic):
+    // a path that visits diagonal k beyond both 0 and kend needs one gap out and one gap back,
+    // i.e. costs at least 2o + (|k| + |k - kend|) e, so cells outside the window cannot lie on any
+    // path the backtrace can choose while the score stays within the limit.  It halves the LDS
+    // ring compared to the reference's |k| <= max_error sizing.
+    int wlo = -plen, whi = tlen;
+    bool feasible = true;
+    if constexpr (!BANDED) {
+      if (p.max_score < INT_MAX / 2) {
+        const long long S = p.max_score, o = oe - e;
+        const int ak = kend < 0 ? -kend : kend;
+        feasible = (ak ? o + (long long)ak * e : 0) <= S;
+        const long long a_hi = S - 2 * o + (long long)kend * e, a_lo = S - 2 * o - (long long)kend * e;
+        const int kmax0 = max(0, kend), kmin0 = min(0, kend);
+        whi = a_hi >= 0 ? max(kmax0, (int)min((long long)tlen, a_hi / (2 * e))) : kmax0;
+        wlo = a_lo >= 0 ? min(kmin0, -(int)min((long long)plen, a_lo / (2 * e))) : kmin0;
+        whi = min(whi, tlen); wlo = max(wlo, -plen);
+      }
+    }
+    const int kidx0 = 1 - wlo;              // row index of diagonal 0 (one guard cell each side)
+
+    if (!feasible) {
+      status = WFA_ST_SCORE;
+    } else if ((!BANDED && whi - wlo + 3 > rs) || pwords > p.seq_words_cap || twords > p.seq_words_cap) {
       status = WFA_ST_BAND;
     } else {
       // ---- stage packed sequences, reset row metadata -----------------------
@@ -231,6 +253,10 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
       while (!done && status == WFA_ST_DONE) {
         ++s;
         if (s > p.max_score) { status = WFA_ST_SCORE; break; }
+        if constexpr (NW > 1) {
+          // reduction slot of the NEXT score (nobody reads it any more: its readers passed barrier s-1)
+          if (tid < 8) red[8 * ((s + 1) % 3) + tid] = (tid == 6) ? 0 : ((tid & 1) ? INT_MIN : INT_MAX);
+        }
         slot_m = (slot_m + 1 == dm) ? 0 : slot_m + 1;
         slot_e = (slot_e + 1 == de) ? 0 : slot_e + 1;
         // predecessor rows
@@ -248,21 +274,20 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
           r_e = btrow[sl_me];
         }
         const bool mx_null = mxlo > mxhi, mo_null = molo > mohi, ie_null = ielo > iehi, de_null = delo > dehi;
-        if (mx_null && mo_null && ie_null && de_null) {
+        // limits (wavefront_compute.c:41-71; null rows carry lo=1, hi=-1)
+        int lo = mxlo, hi = mxhi;
+        lo = min(lo, molo - 1); hi = max(hi, mohi + 1);
+        lo = min(lo, ielo + 1); hi = max(hi, iehi + 1);
+        lo = min(lo, delo - 1); hi = max(hi, dehi - 1);
+        if constexpr (!BANDED) { lo = max(lo, wlo); hi = min(hi, whi); }
+        if ((mx_null && mo_null && ie_null && de_null) || lo > hi) {
           // no wavefront at this score (wavefront_compute_affine.c:236-243)
           mlo[slot_m] = 1; mhi[slot_m] = -1; btrow[slot_m] = WFA_ROW_NONE;
           ilo[slot_e] = 1; ihi[slot_e] = -1; dlo[slot_e] = 1; dhi[slot_e] = -1;
           block_sync<NW>();
           continue;
         }
-        // limits (wavefront_compute.c:41-71; null rows carry lo=1, hi=-1)
-        int lo = mxlo, hi = mxhi;
-        lo = min(lo, molo - 1); hi = max(hi, mohi + 1);
-        lo = min(lo, ielo + 1); hi = max(hi, iehi + 1);
-        lo = min(lo, delo - 1); hi = max(hi, dehi - 1);
-        if constexpr (!BANDED) {
-          if (lo < -hcap || hi > hcap) { status = WFA_ST_BAND; break; }
-        } else {
+        if constexpr (BANDED) {
           // Adaptive band (reference: sequence_distance_kernel_aband.cu:104-130): keep at most
           // band_width diagonals; every band_period scores re-centre the window on the diagonal of
           // the mismatch-source wavefront whose furthest point is closest to the end, otherwise
@@ -408,8 +433,6 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
           done = wave_done;
         } else {
           int* acc = red + 8 * (s % 3);
-          int* nxt = red + 8 * ((s + 1) % 3);
-          if (tid < 8) nxt[tid] = (tid == 6) ? 0 : ((tid & 1) ? INT_MIN : INT_MAX);
           if (lane == 0) {
             if (wmlo <= wmhi) { atomicMin(&acc[0], wmlo); atomicMax(&acc[1], wmhi); }
             if (wilo <= wihi) { atomicMin(&acc[2], wilo); atomicMax(&acc[3], wihi); }

@@ -61,8 +61,7 @@ struct WfaAlignParams {
   unsigned int* work_counter;    // dynamic work distribution (zeroed before launch)
   int x, oe, e;                  // penalties: mismatch, open+extend, extend
   int dm, de;                    // ring depths: max(x,oe)+1 rows of M, e+1 rows of I and D
-  int hcap;                      // diagonals supported: k in [-hcap, +hcap]
-  int rs;                        // row stride (elements), even, >= 2*hcap+3
+  int rs;                        // row stride (elements), even: widest diagonal window + 3
   int max_score;                 // give up (WFA_ST_SCORE) beyond this score
   int band_width;                // > 0: adaptive band, diagonals kept per wavefront (banded kernels)
   int band_period;               //      re-centre the band every this many scores

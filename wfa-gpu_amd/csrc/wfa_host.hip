@@ -221,43 +221,49 @@ void wfagpu_amd_last_stats(const wfagpu_amd_ctx_t* c, wfagpu_amd_stats_t* out) {
 
 namespace {
 
-struct TierPlan { int tier; int hcap; int max_score; size_t lds; int blocks_per_cu; };
+struct TierPlan { int tier; int width; int max_score; size_t lds; int blocks_per_cu; };
 
-// Smallest tier whose LDS footprint fits for `hcap` diagonals each side.
-bool plan_tier(const wfagpu_amd_ctx* c, WfaAlignParams& p, int hcap, int max_score, unsigned max_seq_len, bool bt, bool raw, TierPlan* out) {
+// Widest diagonal window an alignment of score <= S can need (see the kernel): (S - o)/e + 1,
+// never more than every diagonal of the longest pair.
+int window_width(long long S, int o, int e, unsigned max_seq_len) {
+  const long long all = 2ll * max_seq_len + 1;
+  if (S >= INT_MAX / 2) return (int)all;
+  return (int)std::max<long long>(1, std::min<long long>(all, (S - o) / e + 1));
+}
+
+// Smallest tier whose LDS footprint fits a score budget S.
+bool plan_tier(const wfagpu_amd_ctx* c, WfaAlignParams& p, int max_score, unsigned max_seq_len, bool bt, bool raw, TierPlan* out) {
   p.max_score = max_score;
   if (p.band_width > 0) {
     // adaptive band: the ring rows hold band_width diagonals whatever the score
-    p.hcap = INT_MAX / 4;
     p.rs = (p.band_width + 2 + 1) & ~1;
     const int t = p.band_width <= 256 ? 0 : (p.band_width <= 1024 ? 1 : 2);
     const size_t lds = wfa_align_lds_bytes(p, t);
     if (lds > c->lds_per_block_max || max_seq_len > 32766u || max_score > 30000) return false;
     const int nb = wfa_align_max_blocks_per_cu(t, bt, false, true, lds);
     if (nb < 1) return false;
-    *out = {t, p.hcap, max_score, lds, nb};
+    *out = {t, p.band_width, max_score, lds, nb};
     return true;
   }
-  p.hcap = hcap;
-  p.rs = (2 * hcap + 3 + 1) & ~1;
+  const int width = window_width(max_score, p.oe - p.e, p.e, max_seq_len);
+  p.rs = (width + 3 + 1) & ~1;
   const bool i16_ok = max_seq_len <= 32766u && max_score <= 30000;
   const size_t budget[3] = {40u << 10, 80u << 10, c->lds_per_block_max};
-  // a single wavefront sweeps up to ~8 chunks per score before more waves pay off
-  const int width = 2 * hcap + 1;
   for (int t = 0; t < 3 && i16_ok; ++t) {
     const size_t lds = wfa_align_lds_bytes(p, t);
     if (lds > budget[t]) continue;
+    // a single wavefront sweeps up to ~16 chunks per score before more waves pay off
     if (t == 0 && width > 1024) continue;
     if (t == 1 && width > 8192) continue;
     const int nb = wfa_align_max_blocks_per_cu(t, bt, raw, false, lds);
     if (nb < 1) continue;
-    *out = {t, hcap, max_score, lds, nb};
+    *out = {t, width, max_score, lds, nb};
     return true;
   }
   const size_t lds = wfa_align_lds_bytes(p, 3);
   if (lds > c->lds_per_block_max) return false;   // sequences themselves do not fit LDS
   const int nb = wfa_align_max_blocks_per_cu(3, bt, raw, false, lds);
-  *out = {3, hcap, max_score, lds, std::max(1, std::min(nb, 2))};
+  *out = {3, width, max_score, lds, std::max(1, std::min(nb, 2))};
   return true;
 }
 
@@ -356,7 +362,6 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   float align_ms = 0.f, trace_ms = 0.f;
   uint32_t grid_cap = UINT32_MAX;   // lowered when a pass makes no progress for lack of arena
   unsigned long long text_used = 0;
-  const int hmax = (int)std::min<unsigned>(max_len, INT_MAX / 4);
   int rc = 0;
 
   // two classes of pairs: ACGT-only (2-bit packed kernels) and the rest (byte-compare kernels)
@@ -383,16 +388,15 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
     uint32_t n_cur = n_pending;
     uint32_t* spare[2] = {static_cast<uint32_t*>(c->list_a.p), static_cast<uint32_t*>(c->list_b.p)};
     int flip = 0;
-    int hcap = std::min<int>(std::min<int>(max_error, hmax), INT_MAX / 4);
     int max_score = max_error;
     for (int round = 0; n_cur > 0; ++round) {
       TierPlan tp;
       // banded first attempt (packed class only); whatever it cannot finish goes to the exact tiers
       ap.band_width = (want_band && !raw && round == 0) ? band_width : 0;
       ap.band_period = band;
-      if (ap.band_width > 0 && !plan_tier(c, ap, hcap, std::min(max_score, 30000), max_len, compute_cigar, raw, &tp)) ap.band_width = 0;
+      if (ap.band_width > 0 && !plan_tier(c, ap, std::min(max_score, 30000), max_len, compute_cigar, raw, &tp)) ap.band_width = 0;
       if (ap.band_width > 0) c->stats.pairs_banded += n_cur;
-      if (ap.band_width == 0 && !plan_tier(c, ap, hcap, max_score, max_len, compute_cigar, raw, &tp)) {
+      if (ap.band_width == 0 && !plan_tier(c, ap, max_score, max_len, compute_cigar, raw, &tp)) {
         fprintf(stderr, "[!] ERROR: sequences of %u bases do not fit the LDS staging area\n", max_len);
         return -1;
       }
@@ -422,15 +426,16 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       c->stats.pairs_tier[tp.tier] += n_cur - n_next;
       if (round == 0) c->stats.pairs_retried += n_next;
       if (n_next == 0) break;
-      if (tp.tier == 3 && hcap >= hmax && max_score == INT_MAX) {
+      if (tp.tier == 3 && max_score == INT_MAX) {
         fprintf(stderr, "[!] ERROR: %u alignments did not finish in the unbounded tier\n", n_next);
         return -1;
       }
       cur = nxt; n_cur = n_next;
       if (ap.band_width > 0) { c->stats.pairs_banded -= n_next; continue; }   // banded misses: exact tiers from the start
-      // widen: 4x the diagonals, no score limit beyond what 16-bit offsets allow
-      hcap = (hcap >= hmax / 4) ? hmax : hcap * 4;
-      max_score = (max_score == 30000 || max_len > 32766u) ? INT_MAX : 30000;
+      // widen: 4x the score budget (and with it the diagonal window); beyond what 16-bit offsets
+      // allow the last resort is the unbounded 32-bit tier
+      if (max_score >= 30000 || max_len > 32766u) max_score = INT_MAX;
+      else max_score = (int)std::min<long long>(30000, 4ll * max_score);
     }
     // ---- backtrace + CIGAR for everything that finished in this pass ---------
     if (zero_counter(c, CT_SUM_OPS, 2)) return -1;

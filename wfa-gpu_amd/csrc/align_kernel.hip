@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
   constexpr int NT = NW * 64;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = (NW == 1) ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6);
   const int dm = p.dm, de = p.de, rs = p.rs;
   const int x = p.x, oe = p.oe, e = p.e;
 
@@ -206,6 +206,16 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
       const uint32_t* __restrict__ gt = p.packed + ((RAW ? mp.text_offset : mp.text_offset_packed) >> 2);
       for (int i = tid; i < pwords; i += NT) Pw[i] = gp[i];
       for (int i = tid; i < twords; i += NT) Tw[i] = gt[i];
+      if constexpr (!BANDED) {
+        // Exact mode keeps the ring rows physically NULL wherever a later score may read them
+        // (so reads need no range predicate): before any row is written, that is |k| <= dm + 1.
+        const int f0 = max(wlo - 1, -(dm + 1)), f1 = min(whi + 1, dm + 1);
+        const int nf = f1 - f0 + 1;
+        for (int i = tid; i < (dm + 2 * de) * nf; i += NT) {
+          const int r = i / nf, q = f0 + (i - r * nf);
+          Mr[(size_t)r * rs + kidx0 + q] = off_store<OffT>(OFF_NULL);   // rows of M, I, D are contiguous
+        }
+      }
       for (int i = tid; i < dm; i += NT) { mlo[i] = 1; mhi[i] = -1; btrow[i] = WFA_ROW_NONE; }
       for (int i = tid; i < de; i += NT) { ilo[i] = 1; ihi[i] = -1; dlo[i] = 1; dhi[i] = -1; }
       if constexpr (NW > 1) {
@@ -249,6 +259,7 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
       block_sync<NW>();
 
       int slot_m = 0, slot_e = 0;   // ring slots of score s
+      int hist_lo = 0, hist_hi = 0;  // widest limits so far (exact mode: bounds of the NULL fill)
       // ---- score loop ---------------------------------------------------------
       while (!done && status == WFA_ST_DONE) {
         ++s;
@@ -284,6 +295,13 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
           // no wavefront at this score (wavefront_compute_affine.c:236-243)
           mlo[slot_m] = 1; mhi[slot_m] = -1; btrow[slot_m] = WFA_ROW_NONE;
           ilo[slot_e] = 1; ihi[slot_e] = -1; dlo[slot_e] = 1; dhi[slot_e] = -1;
+          if constexpr (!BANDED) {
+            const int f0 = max(wlo - 1, hist_lo - dm), f1 = min(whi + 1, hist_hi + dm);
+            OffT* nm = Mr + (size_t)slot_m * rs; OffT* ni = Ir + (size_t)slot_e * rs; OffT* nd = Dr + (size_t)slot_e * rs;
+            for (int q = f0 + tid; q <= f1; q += NT) {
+              nm[kidx0 + q] = off_store<OffT>(OFF_NULL); ni[kidx0 + q] = off_store<OffT>(OFF_NULL); nd[kidx0 + q] = off_store<OffT>(OFF_NULL);
+            }
+          }
           block_sync<NW>();
           continue;
         }
@@ -368,12 +386,25 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
         const int base_mx = BANDED ? mbase[sl_x] : 0, base_mo = BANDED ? mbase[sl_oe] : 0, base_e = BANDED ? ebase[sl_e] : 0;
         const int wbase = BANDED ? -lo : kidx0;   // index of diagonal 0 in the rows written now
 
-        int wmlo = INT_MAX, wmhi = INT_MIN, wilo = INT_MAX, wihi = INT_MIN, wdlo = INT_MAX, wdhi = INT_MIN;
-        bool my_done = false;
+        if constexpr (!BANDED) {
+          // NULL guard cells on both sides of the computed range: every diagonal a later score can
+          // read from this row (limits move by at most one diagonal per score, a row lives dm scores)
+          hist_lo = min(hist_lo, lo); hist_hi = max(hist_hi, hi);
+          const int f0 = max(wlo - 1, hist_lo - dm), f1 = min(whi + 1, hist_hi + dm);
+          for (int q = f0 + tid; q < lo; q += NT) {
+            out_m[kidx0 + q] = off_store<OffT>(OFF_NULL); out_i[kidx0 + q] = off_store<OffT>(OFF_NULL); out_d[kidx0 + q] = off_store<OffT>(OFF_NULL);
+          }
+          for (int q = hi + 1 + tid; q <= f1; q += NT) {
+            out_m[kidx0 + q] = off_store<OffT>(OFF_NULL); out_i[kidx0 + q] = off_store<OffT>(OFF_NULL); out_d[kidx0 + q] = off_store<OffT>(OFF_NULL);
+          }
+        }
+        // ---- the cells of this score.  Straight-line per lane: no divergent branch inside, the
+        // only loop (extend) is wave-uniform.  Lanes past the end recompute cell `hi` (same values,
+        // same addresses), so no store needs an exec mask.  Scalar-unit work per chunk is a loop
+        // counter and the wait counters; validity ballots happen once per score.
+        bool my_done = false, my_over = false;
         for (int k0 = lo; k0 <= hi; k0 += NT) {
-          const int kraw = k0 + tid;
-          const bool active = kraw <= hi;
-          const int k = active ? kraw : hi;
+          const int k = min(k0 + tid, hi);
           // recurrences (wavefront_compute_affine.c:66-84)
           int m_x, m_ol, m_or, i_e, d_e;
           if constexpr (BANDED) {
@@ -383,70 +414,119 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
             i_e = rd_cell_rel(row_ie, base_e, k - 1, rg_ie);
             d_e = rd_cell_rel(row_de, base_e, k + 1, rg_de);
           } else {
-            m_x = rd_cell(row_mx, kidx0, k, rg_mx);
-            m_ol = rd_cell(row_mo, kidx0, k - 1, rg_mo);
-            m_or = rd_cell(row_mo, kidx0, k + 1, rg_mo);
-            i_e = rd_cell(row_ie, kidx0, k - 1, rg_ie);
-            d_e = rd_cell(row_de, kidx0, k + 1, rg_de);
+            m_x = (int)row_mx[kidx0 + k];
+            m_ol = (int)row_mo[kidx0 + k - 1];
+            m_or = (int)row_mo[kidx0 + k + 1];
+            i_e = (int)row_ie[kidx0 + k - 1];
+            d_e = (int)row_de[kidx0 + k + 1];
           }
           const int ins = max(m_ol, i_e) + 1;
           const int del = max(m_or, d_e);
           const int mis = m_x + 1;
-          int mv = max(del, max(mis, ins));
+          const int mv0 = max(del, max(mis, ins));
+          // !(h > tlen || v > plen), unsigned so that negatives fail too
+          const bool ok = ((unsigned)mv0 <= (unsigned)tlen) && ((unsigned)(mv0 - k) <= (unsigned)plen);
           uint32_t code = 0;
           if constexpr (BT) {
             // tie-breaks: gap extension wins over gap open on equal offsets
             // (wavefront_compute_affine.c:135-143,153-161); for M: mismatch,
             // then deletion, then insertion (wavefront_backtrace.c:48-59)
             code = (i_e >= m_ol ? BT_I_EXT : 0u) | (d_e >= m_or ? BT_D_EXT : 0u);
-            code |= (mis == mv) ? BT_M_X : ((del == mv) ? BT_M_D : BT_M_I);
+            const uint32_t org = (mis == mv0) ? BT_M_X : ((del == mv0) ? BT_M_D : BT_M_I);
+            code |= ok ? org : 0u;
           }
-          // !(h > tlen || v > plen), unsigned so that negatives fail too
-          const bool ok = ((unsigned)mv <= (unsigned)tlen) && ((unsigned)(mv - k) <= (unsigned)plen);
-          const bool i_ok = have_i && ((unsigned)ins <= (unsigned)tlen) && ((unsigned)(ins - k) <= (unsigned)plen);
-          const bool d_ok = have_d && ((unsigned)del <= (unsigned)tlen) && ((unsigned)(del - k) <= (unsigned)plen);
-          if (ok) {
-            mv = extend_lcp<RAW>(Pw, Tw, plen, tlen, k, mv);
-          } else {
-            mv = OFF_NULL;
-            if constexpr (BT) code &= ~3u;
+          // An I (D) value can only be out of range by running past the text (pattern) end; such
+          // values are rare (last scores only) and send the row through the exact trimming pass
+          // below.  Everywhere else "invalid" means negative, which already reads as NULL, so the
+          // computed limits can stand in for the trimmed ones.
+          my_over |= (ins > tlen) || (del - k > plen);
+          // extend = longest common prefix from (v,h) (wavefront_extend.c:174-199), PER symbols per
+          // iteration; lanes that are done carry rem == 0 and idle along
+          int h = ok ? mv0 : 0;
+          int v = ok ? mv0 - k : 0;
+          int rem = ok ? min(plen - v, tlen - h) : 0;
+          {
+            constexpr int SH = RAW ? 2 : 4, PER = 1 << SH, BITS = RAW ? 3 : 1;
+            bool more;
+            do {
+              const int pi = v >> SH, ti = h >> SH;
+              const uint32_t p0 = Pw[pi], p1 = Pw[pi + 1];
+              const uint32_t t0 = Tw[ti], t1 = Tw[ti + 1];
+              const uint32_t a = __builtin_amdgcn_alignbit(p1, p0, (uint32_t)v << BITS);
+              const uint32_t b = __builtin_amdgcn_alignbit(t1, t0, (uint32_t)h << BITS);
+              const uint32_t d = a ^ b;
+              const uint32_t eq = (d ? (uint32_t)__builtin_ctz(d) : 32u) >> BITS;   // equal symbols, PER if all
+              const int n = (int)min(eq, (uint32_t)rem);
+              h += n; v += n;
+              rem = (n == PER) ? rem - PER : 0;
+              more = rem > 0;
+            } while (__builtin_amdgcn_ballot_w64(more) != 0ull);
           }
-          if (active) {
-            out_m[wbase + k] = off_store<OffT>(mv);
-            if (have_i) out_i[wbase + k] = off_store<OffT>(ins);
-            if (have_d) out_d[wbase + k] = off_store<OffT>(del);
-            if constexpr (BT) codes[k - lo] = (uint8_t)code;
-            if (k == kend && mv >= tlen) my_done = true;
-          }
-          // trimmed limits = first/last valid cell (wavefront_compute.c:570-603)
-          const int b = k0 + wave * 64;
-          const unsigned long long bm = __ballot(active && ok);
-          const unsigned long long bi = __ballot(active && i_ok);
-          const unsigned long long bd = __ballot(active && d_ok);
-          if (bm) { wmlo = min(wmlo, b + (int)__builtin_ctzll(bm)); wmhi = max(wmhi, b + 63 - (int)__builtin_clzll(bm)); }
-          if (bi) { wilo = min(wilo, b + (int)__builtin_ctzll(bi)); wihi = max(wihi, b + 63 - (int)__builtin_clzll(bi)); }
-          if (bd) { wdlo = min(wdlo, b + (int)__builtin_ctzll(bd)); wdhi = max(wdhi, b + 63 - (int)__builtin_clzll(bd)); }
+          const int mv = ok ? h : OFF_NULL;
+          out_m[wbase + k] = off_store<OffT>(mv);
+          if (!BANDED || have_i) out_i[wbase + k] = off_store<OffT>(ins);
+          if (!BANDED || have_d) out_d[wbase + k] = off_store<OffT>(del);
+          if constexpr (BT) codes[k - lo] = (uint8_t)code;
+          my_done |= (k == kend) && (mv >= tlen);
         }
-        const bool wave_done = __ballot(my_done) != 0ull;
-
-        if constexpr (NW == 1) {
-          done = wave_done;
-        } else {
-          int* acc = red + 8 * (s % 3);
-          if (lane == 0) {
-            if (wmlo <= wmhi) { atomicMin(&acc[0], wmlo); atomicMax(&acc[1], wmhi); }
-            if (wilo <= wihi) { atomicMin(&acc[2], wilo); atomicMax(&acc[3], wihi); }
-            if (wdlo <= wdhi) { atomicMin(&acc[4], wdlo); atomicMax(&acc[5], wdhi); }
-            if (wave_done) atomicOr(&acc[6], 1);
+        bool any_over = false;
+        {
+          const bool wave_done = __ballot(my_done) != 0ull;
+          const bool wave_over = __ballot(my_over) != 0ull;
+          if constexpr (NW == 1) {
+            done = wave_done; any_over = wave_over;
+          } else {
+            int* acc = red + 8 * (s % 3);
+            if (lane == 0 && (wave_done || wave_over)) atomicOr(&acc[6], (wave_done ? 1 : 0) | (wave_over ? 2 : 0));
+            __syncthreads();
+            done = (acc[6] & 1) != 0;
+            any_over = (acc[6] & 2) != 0;
           }
-          __syncthreads();
-          wmlo = acc[0]; wmhi = acc[1]; wilo = acc[2]; wihi = acc[3]; wdlo = acc[4]; wdhi = acc[5];
-          done = acc[6] != 0;
+        }
+        // M limits: the computed ones (cells that are not valid hold NULL, which is all a reader needs)
+        int wmlo = lo, wmhi = hi;
+        // I and D limits: the computed ones, unless some value ran past a sequence end
+        int wilo = have_i ? lo : 1, wihi = have_i ? hi : -1, wdlo = have_d ? lo : 1, wdhi = have_d ? hi : -1;
+        if (any_over) {
+          // exact per-component trimming (wavefront_compute.c:570-603): first/last in-range cell
+          int r[4] = {INT_MAX, INT_MIN, INT_MAX, INT_MIN};
+          for (int k0 = lo; k0 <= hi; k0 += NT) {
+            const int kraw = k0 + tid;
+            const bool active = kraw <= hi;
+            const int k = active ? kraw : hi;
+            const int iv = have_i ? (int)out_i[wbase + k] : OFF_NULL;
+            const int dv = have_d ? (int)out_d[wbase + k] : OFF_NULL;
+            const bool i_ok = ((unsigned)iv <= (unsigned)tlen) && ((unsigned)(iv - k) <= (unsigned)plen);
+            const bool d_ok = ((unsigned)dv <= (unsigned)tlen) && ((unsigned)(dv - k) <= (unsigned)plen);
+            const int b = k0 + wave * 64;
+            const unsigned long long bi = __ballot(active && i_ok), bd = __ballot(active && d_ok);
+            if (bi) { r[0] = min(r[0], b + (int)__builtin_ctzll(bi)); r[1] = max(r[1], b + 63 - (int)__builtin_clzll(bi)); }
+            if (bd) { r[2] = min(r[2], b + (int)__builtin_ctzll(bd)); r[3] = max(r[3], b + 63 - (int)__builtin_clzll(bd)); }
+          }
+          if constexpr (NW > 1) {
+            // rare path: one more triple of barriers is fine
+            int* acc = red + 8 * (s % 3) + 2;            // words 2..5 of this score's slot are unused so far
+            if (lane == 0) {
+              if (r[0] <= r[1]) { atomicMin(&acc[0], r[0]); atomicMax(&acc[1], r[1]); }
+              if (r[2] <= r[3]) { atomicMin(&acc[2], r[2]); atomicMax(&acc[3], r[3]); }
+            }
+            __syncthreads();
+            r[0] = acc[0]; r[1] = acc[1]; r[2] = acc[2]; r[3] = acc[3];
+          }
+          wilo = r[0]; wihi = r[1]; wdlo = r[2]; wdhi = r[3];
+          if (wilo > wihi) { wilo = 1; wihi = -1; }
+          if (wdlo > wdhi) { wdlo = 1; wdhi = -1; }
+          if constexpr (!BANDED) {
+            // trimmed-away cells read as NULL from now on (wavefront_compute.c:480-520)
+            for (int q = lo + tid; q <= hi; q += NT) {
+              if (q < wilo || q > wihi) out_i[kidx0 + q] = off_store<OffT>(OFF_NULL);
+              if (q < wdlo || q > wdhi) out_d[kidx0 + q] = off_store<OffT>(OFF_NULL);
+            }
+            if constexpr (NW > 1) __syncthreads();
+          }
         }
         // every thread records the same row metadata (it reads its own copy back)
         if (wmlo > wmhi) { wmlo = 1; wmhi = -1; }
-        if (wilo > wihi) { wilo = 1; wihi = -1; }
-        if (wdlo > wdhi) { wdlo = 1; wdhi = -1; }
         mlo[slot_m] = wmlo; mhi[slot_m] = wmhi; btrow[slot_m] = row_s;
         if constexpr (BANDED) { mbase[slot_m] = lo; ebase[slot_e] = lo; }
         ilo[slot_e] = wilo; ihi[slot_e] = wihi;

@@ -154,7 +154,6 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
   uint32_t* bslot = reinterpret_cast<uint32_t*>(red + 24);  // [2]
   int* mbase = reinterpret_cast<int*>(bslot + 2);       // [dm] window base of each M row (BANDED)
   int* ebase = mbase + dm;                              // [de] window base of each I/D row
-
   uint32_t chunk_cur = 0, chunk_left = 0;   // arena units owned by this block
 
   for (;;) {
@@ -443,30 +442,37 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
           // extend = longest common prefix from (v,h) (wavefront_extend.c:174-199), PER symbols per
           // iteration; lanes that are done carry rem == 0 and idle along
           int h = ok ? mv0 : 0;
-          int v = ok ? mv0 - k : 0;
-          int rem = ok ? min(plen - v, tlen - h) : 0;
           {
             constexpr int SH = RAW ? 2 : 4, PER = 1 << SH, BITS = RAW ? 3 : 1;
+            const int v = ok ? mv0 - k : 0;
+            int rem = ok ? min(plen - v, tlen - h) : 0;
+            // word pointers and bit offsets are fixed for the whole run: a lane that goes on has
+            // consumed exactly PER symbols = one word
+            const uint32_t* pp = Pw + (v >> SH);
+            const uint32_t* tp = Tw + (h >> SH);
+            const uint32_t sa = (uint32_t)v << BITS, sb = (uint32_t)h << BITS;
             bool more;
             do {
-              const int pi = v >> SH, ti = h >> SH;
-              const uint32_t p0 = Pw[pi], p1 = Pw[pi + 1];
-              const uint32_t t0 = Tw[ti], t1 = Tw[ti + 1];
-              const uint32_t a = __builtin_amdgcn_alignbit(p1, p0, (uint32_t)v << BITS);
-              const uint32_t b = __builtin_amdgcn_alignbit(t1, t0, (uint32_t)h << BITS);
+              const uint32_t a = __builtin_amdgcn_alignbit(pp[1], pp[0], sa);
+              const uint32_t b = __builtin_amdgcn_alignbit(tp[1], tp[0], sb);
               const uint32_t d = a ^ b;
               const uint32_t eq = (d ? (uint32_t)__builtin_ctz(d) : 32u) >> BITS;   // equal symbols, PER if all
               const int n = (int)min(eq, (uint32_t)rem);
-              h += n; v += n;
-              rem = (n == PER) ? rem - PER : 0;
+              h += n;
+              const bool full = n == PER;
+              rem = full ? rem - PER : 0;
+              const int adv = full ? 1 : 0;
+              pp += adv; tp += adv;
               more = rem > 0;
             } while (__builtin_amdgcn_ballot_w64(more) != 0ull);
           }
           const int mv = ok ? h : OFF_NULL;
-          out_m[wbase + k] = off_store<OffT>(mv);
+          // M and D offsets never exceed the text length, so they fit 16 bits as they are; only an I
+          // chain running past the text end keeps growing and is saturated by off_store
+          out_m[wbase + k] = (OffT)mv;
           if (!BANDED || have_i) out_i[wbase + k] = off_store<OffT>(ins);
-          if (!BANDED || have_d) out_d[wbase + k] = off_store<OffT>(del);
-          if constexpr (BT) codes[k - lo] = (uint8_t)code;
+          if (!BANDED || have_d) out_d[wbase + k] = (OffT)del;
+          if constexpr (BT) codes[(uint32_t)(k - lo)] = (uint8_t)code;
           my_done |= (k == kend) && (mv >= tlen);
         }
         bool any_over = false;
@@ -604,7 +610,7 @@ size_t wfa_align_lds_bytes(const WfaAlignParams& p, int tier) {
   size_t ring = 0;
   if (tier != 3) ring = (((size_t)(p.dm + 2 * p.de) * p.rs * sizeof(int16_t)) + 15) & ~(size_t)15;
   const size_t seq = (size_t)2 * p.seq_words_cap * 4;
-  const size_t meta = (size_t)(2 * p.dm + 4 * p.de + p.dm + 24 + 2 + p.dm + p.de) * 4;
+  const size_t meta = (size_t)(2 * p.dm + 4 * p.de + p.dm + 24 + 2 + p.dm + p.de) * 4 + 16;
   return ((ring + seq + meta) + 15) & ~(size_t)15;
 }
 

@@ -332,6 +332,8 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   ap.work_counter = reinterpret_cast<unsigned int*>(ct + CT_WORK);
   ap.arena_top = ct + CT_ARENA;
   ap.chunk_units = 256;   // 4 KiB refills
+  // tuning knob for experiments (not part of the interface)
+  const char* env_chunk = getenv("WFAGPU_CHUNK_UNITS");
   ap.bt_final_row = static_cast<uint32_t*>(c->bt_final.p);
 
   if (compute_cigar) {
@@ -409,6 +411,10 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       if (round == 0 && c->stats.sub_batches == 1) { c->stats.lds_bytes_tier0 = tp.lds; c->stats.blocks_per_cu_tier0 = tp.blocks_per_cu; }
       ap.work = cur; ap.n_work = n_cur;
       const int grid = (int)std::min<uint32_t>(std::min<uint32_t>(n_cur, grid_cap), (uint32_t)(c->num_cus * tp.blocks_per_cu));
+      // arena refill size: as large as lets every workgroup hold a few chunks -- each refill is a
+      // returning atomic on ONE word (~88 per microsecond on this chip), which at 4 KiB refills
+      // was the whole kernel time
+      if (compute_cigar) ap.chunk_units = (uint32_t)std::min<unsigned long long>(env_chunk ? (unsigned)atoi(env_chunk) : 4096u, std::max<unsigned long long>(256, ap.arena_units / (4ull * (unsigned)grid)));
       if (zero_counter(c, CT_WORK, 2)) return -1;   // work counter + list counter
       HIP_TRY(hipEventRecord(c->ev_a0, st));
       wfa_launch_align(ap, tp.tier, compute_cigar, raw, grid, st);

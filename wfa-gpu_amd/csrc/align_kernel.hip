@@ -156,12 +156,23 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
   int* ebase = mbase + dm;                              // [de] window base of each I/D row
   uint32_t chunk_cur = 0, chunk_left = 0;   // arena units owned by this block
 
+  // Work distribution: the list is cut into 8 contiguous shards, each with its own counter on its
+  // own cache line; a block starts on shard blockIdx % 8 (the XCD it most likely runs on) and moves
+  // on when a shard is empty.  One counter word serves only ~88 claims per microsecond, which
+  // capped short-read batches (BASELINE configs[1]) at 1.2 ms per 100k pairs.
+  uint32_t shard = blockIdx.x & 7u, shards_left = 8;
   for (;;) {
-    // ---- next alignment ---------------------------------------------------
-    uint32_t w = 0;
-    if (tid == 0) w = atomicAdd(p.work_counter, 1u);
-    w = block_bcast<NW>(w, bslot);
-    if (w >= p.n_work) break;
+    uint32_t w = 0xFFFFFFFFu;
+    while (shards_left) {
+      const uint32_t lo_w = (uint32_t)(((unsigned long long)p.n_work * shard) >> 3);
+      const uint32_t hi_w = (uint32_t)(((unsigned long long)p.n_work * (shard + 1)) >> 3);
+      uint32_t c = 0;
+      if (tid == 0) c = atomicAdd(p.work_counter + shard * 16, 1u);
+      c = block_bcast<NW>(c, bslot);
+      if (c < hi_w - lo_w) { w = lo_w + c; break; }
+      shard = (shard + 1) & 7u; --shards_left;
+    }
+    if (w == 0xFFFFFFFFu) break;
     const uint32_t pair = p.work ? p.work[w] : w;
     const WfaSeqPair mp = p.meta[pair];
     const int plen = (int)mp.pattern_len, tlen = (int)mp.text_len;
@@ -555,7 +566,14 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
 template <int NW, bool BT, typename OffT, bool GR, bool RAW, bool BANDED>
 void launch_inst(const WfaAlignParams& p, size_t lds, int grid, hipStream_t stream) {
   auto k = wfa_align_kernel<NW, BT, OffT, GR, RAW, BANDED>;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  // the opt-in for large dynamic LDS is sticky per device and per kernel: pay the driver call once
+  static thread_local size_t allowed[16] = {0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (lds > allowed[dev & 15]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    allowed[dev & 15] = lds;
+  }
   hipLaunchKernelGGL(k, dim3(grid), dim3(NW * 64), lds, stream, p);
 }
 

@@ -120,24 +120,21 @@ __device__ __forceinline__ uint32_t replay(const uint8_t* ops, uint32_t nops,
 
 constexpr int TRACE_THREADS = 64;
 
-__global__ void __launch_bounds__(TRACE_THREADS) wfa_trace_kernel(const WfaTraceParams p) {
+// Phase 1 kernel: backward walk over the origin bytes, one lane per alignment, no LDS: it is a
+// chain of dependent HBM reads, so it wants every wave slot of the CU.  Leaves the op list of
+// each pair in the scratch arena (ops_off/nops per pair).
+__global__ void __launch_bounds__(TRACE_THREADS) wfa_walk_kernel(const WfaTraceParams p) {
   const uint32_t gid = blockIdx.x * TRACE_THREADS + threadIdx.x;
   const int lane = threadIdx.x & 63;
   bool active = gid < p.n_work;
   uint32_t pair = 0;
   if (active) pair = p.work ? p.work[gid] : gid;
   if (active && p.status[pair] != WFA_ST_DONE) active = false;
-
   int score = 0, plen = 0, tlen = 0;
-  const uint32_t* Pw = nullptr; const uint32_t* Tw = nullptr;
   if (active) {
     score = p.score[pair];
-    const WfaSeqPair mp = p.meta[pair];
-    plen = (int)mp.pattern_len; tlen = (int)mp.text_len;
-    Pw = p.packed + ((p.raw ? mp.pattern_offset : mp.pattern_offset_packed) >> 2);
-    Tw = p.packed + ((p.raw ? mp.text_offset : mp.text_offset_packed) >> 2);
+    plen = (int)p.meta[pair].pattern_len; tlen = (int)p.meta[pair].text_len;
   }
-  // ---- phase 1: backward walk ---------------------------------------------
   // every operation costs at least min(x, e) >= 1, so `score` bytes suffice
   const uint32_t need_ops = active ? (((uint32_t)score + 3u) & ~3u) : 0u;
   const unsigned long long ops_off = wave_alloc(p.ops_top, need_ops, lane);
@@ -173,8 +170,57 @@ __global__ void __launch_bounds__(TRACE_THREADS) wfa_trace_kernel(const WfaTrace
     }
     if (s != 0 || state != 0 || k != 0) fail = true;
   }
-  const uint32_t nops = (uint32_t)(q_end - q);
-  // ---- phase 2: forward replay, size then write ------------------------------
+  if (active) {
+    // the op list now sits at [q, q_end); cigar_off/cigar_len carry it to the emit kernel
+    p.cigar_off[pair] = (unsigned long long)(q - p.ops);
+    p.cigar_len[pair] = fail ? 0xFFFFFFFFu : (uint32_t)(q_end - q);
+  }
+}
+
+// Phase 2 kernel: forward replay, once to size the text and once to write it.
+// SEQ_LDS: the 64 pairs of a block are first copied into LDS (coalesced, one pair at a time by
+// the whole wavefront), so the many small reads of the replay never leave the CU.  Without it
+// every 4-byte read of a packed sequence misses L1 and L2 (the working set of all resident lanes
+// is far larger than both) and the kernel is HBM-transaction bound (57 GB fetched per 1M pairs).
+template <bool SEQ_LDS>
+__global__ void __launch_bounds__(TRACE_THREADS) wfa_emit_kernel(const WfaTraceParams p) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t seq_lds[];
+  const uint32_t gid = blockIdx.x * TRACE_THREADS + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  bool active = gid < p.n_work;
+  uint32_t pair = 0;
+  if (active) pair = p.work ? p.work[gid] : gid;
+  if (active && p.status[pair] != WFA_ST_DONE) active = false;
+
+  int plen = 0, tlen = 0;
+  const uint32_t* Pw = nullptr; const uint32_t* Tw = nullptr;
+  const uint8_t* q = nullptr; uint32_t nops = 0;
+  bool fail = false;
+  if (active) {
+    const WfaSeqPair mp = p.meta[pair];
+    plen = (int)mp.pattern_len; tlen = (int)mp.text_len;
+    Pw = p.packed + ((p.raw ? mp.pattern_offset : mp.pattern_offset_packed) >> 2);
+    Tw = p.packed + ((p.raw ? mp.text_offset : mp.text_offset_packed) >> 2);
+    q = p.ops + p.cigar_off[pair];
+    nops = p.cigar_len[pair];
+    fail = nops == 0xFFFFFFFFu;
+  }
+  if constexpr (SEQ_LDS) {
+    const int sh = p.raw ? 2 : 4;
+    const int pw = active ? ((plen + (1 << sh) - 1) >> sh) + 1 : 0, tw = active ? ((tlen + (1 << sh) - 1) >> sh) + 1 : 0;
+    const int stride = p.seq_lds_stride;   // odd number of words per lane
+    for (int j = 0; j < 64; ++j) {
+      const uint32_t* gp = reinterpret_cast<const uint32_t*>(shfl64(reinterpret_cast<unsigned long long>(Pw), j));
+      const uint32_t* gt = reinterpret_cast<const uint32_t*>(shfl64(reinterpret_cast<unsigned long long>(Tw), j));
+      const int pwj = __shfl(pw, j), twj = __shfl(tw, j);
+      uint32_t* dst = seq_lds + (size_t)j * stride;
+      for (int i = lane; i < pwj; i += 64) dst[i] = gp[i];
+      for (int i = lane; i < twj; i += 64) dst[pwj + i] = gt[i];
+    }
+    __syncthreads();
+    Pw = seq_lds + (size_t)lane * stride;
+    Tw = Pw + pw;
+  }
   uint32_t len = 0;
   if (active && !fail) {
     len = p.raw ? replay<true>(q, nops, Pw, Tw, plen, tlen, nullptr) : replay<false>(q, nops, Pw, Tw, plen, tlen, nullptr);
@@ -201,5 +247,12 @@ __global__ void __launch_bounds__(TRACE_THREADS) wfa_trace_kernel(const WfaTrace
 void wfa_launch_trace(const WfaTraceParams& p, hipStream_t stream) {
   if (p.n_work == 0) return;
   const uint32_t grid = (p.n_work + TRACE_THREADS - 1) / TRACE_THREADS;
-  hipLaunchKernelGGL(wfa_trace_kernel, dim3(grid), dim3(TRACE_THREADS), 0, stream, p);
+  hipLaunchKernelGGL(wfa_walk_kernel, dim3(grid), dim3(TRACE_THREADS), 0, stream, p);
+  if (p.seq_lds_stride > 0) {
+    const size_t lds = (size_t)64 * p.seq_lds_stride * 4;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wfa_emit_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(wfa_emit_kernel<true>, dim3(grid), dim3(TRACE_THREADS), lds, stream, p);
+  } else {
+    hipLaunchKernelGGL(wfa_emit_kernel<false>, dim3(grid), dim3(TRACE_THREADS), 0, stream, p);
+  }
 }

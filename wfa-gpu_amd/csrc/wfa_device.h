@@ -58,7 +58,7 @@ struct WfaAlignParams {
   const WfaSeqPair* meta;
   const uint32_t* work;          // pair indices to process (NULL: identity)
   uint32_t n_work;
-  unsigned int* work_counter;    // dynamic work distribution (zeroed before launch)
+  unsigned int* work_counter;    // dynamic work distribution: 8 counters, 64 bytes apart (zeroed before launch)
   int x, oe, e;                  // penalties: mismatch, open+extend, extend
   int dm, de;                    // ring depths: max(x,oe)+1 rows of M, e+1 rows of I and D
   int rs;                        // row stride (elements), even: widest diagonal window + 3
@@ -82,6 +82,7 @@ struct WfaAlignParams {
 
 struct WfaTraceParams {
   int raw;                       // 1: sequences are the ASCII buffer (byte compare), 0: 2-bit packed
+  int seq_lds_stride;            // > 0: stage each lane's pair in LDS, this many (odd) words per lane
   const uint32_t* packed;
   const WfaSeqPair* meta;
   const uint32_t* work;          // pair indices (NULL: identity)

@@ -92,28 +92,34 @@ __global__ void k_flag_alphabet(const uint8_t* __restrict__ flags, uint32_t n, u
 }
 
 // bounds for the trace scratch: sum over finished pairs of the op-list and
-// text sizes; also the total of computed cells
-__global__ void k_trace_bounds(const uint32_t* __restrict__ work, uint32_t n, const uint32_t* __restrict__ status,
+// text sizes; also the total of computed cells.  Grid-stride, one atomic triple per block.
+__global__ void __launch_bounds__(256) k_trace_bounds(const uint32_t* __restrict__ work, uint32_t n, const uint32_t* __restrict__ status,
                                const int32_t* __restrict__ score, const uint32_t* __restrict__ cells, int min_op_cost,
                                unsigned long long* __restrict__ ct) {
-  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ unsigned long long part[3][4];
   unsigned long long ops = 0, txt = 0, cl = 0;
-  if (gid < n) {
+  for (uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x; gid < n; gid += gridDim.x * blockDim.x) {
     const uint32_t pair = work ? work[gid] : gid;
     if (status[pair] == WFA_ST_DONE) {
       const uint32_t s = (uint32_t)score[pair];
-      ops = (s + 3u) & ~3u;
+      ops += (s + 3u) & ~3u;
       const uint32_t m = s / (uint32_t)min_op_cost;
-      txt = 6ull * (2ull * m + 1ull) + 1ull;
+      txt += 6ull * (2ull * m + 1ull) + 1ull;
     }
-    if (cells && status[pair] != WFA_ST_PENDING) cl = cells[pair];
+    if (cells && status[pair] != WFA_ST_PENDING) cl += cells[pair];
   }
   for (int d = 32; d > 0; d >>= 1) {
     ops += __shfl_down((unsigned long long)ops, d);
     txt += __shfl_down((unsigned long long)txt, d);
     cl += __shfl_down((unsigned long long)cl, d);
   }
-  if ((threadIdx.x & 63) == 0) {
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { part[0][wv] = ops; part[1][wv] = txt; part[2][wv] = cl; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    ops = part[0][0] + part[0][1] + part[0][2] + part[0][3];
+    txt = part[1][0] + part[1][1] + part[1][2] + part[1][3];
+    cl = part[2][0] + part[2][1] + part[2][2] + part[2][3];
     if (ops) atomicAdd(&ct[CT_SUM_OPS], ops);
     if (txt) atomicAdd(&ct[CT_SUM_TEXT], txt);
     if (cl) atomicAdd(&ct[CT_CELLS], cl);
@@ -136,7 +142,7 @@ struct wfagpu_amd_ctx {
   int num_cus = 0;
   size_t lds_per_block_max = 0;
   size_t arena_cfg = 0, text_cfg = 0;
-  DevBuf packed, flags, status, cells, bt_final, list_a, list_b, list_c, list_d, counters, arena, ops, text, cig_off, cig_len, gring;
+  DevBuf packed, flags, status, cells, bt_final, list_a, list_b, list_c, list_d, work_ctr, counters, arena, ops, text, cig_off, cig_len, gring;
   unsigned long long* h_counters = nullptr;  // pinned
   hipEvent_t ev_start = nullptr, ev_pack = nullptr, ev_a0 = nullptr, ev_a1 = nullptr, ev_t0 = nullptr, ev_t1 = nullptr, ev_end = nullptr;
   wfagpu_amd_stats_t stats{};
@@ -174,6 +180,7 @@ int wfagpu_amd_create(wfagpu_amd_ctx_t** out, const wfagpu_amd_config_t* cfg) {
   HIP_TRY(hipEventCreate(&c->ev_t0)); HIP_TRY(hipEventCreate(&c->ev_t1));
   HIP_TRY(hipEventCreate(&c->ev_end));
   if (c->counters.ensure(CT_N * sizeof(unsigned long long), c->stream)) return -1;
+  if (c->work_ctr.ensure(8 * 64, c->stream)) return -1;
   *out = c;
   return 0;
 }
@@ -182,7 +189,7 @@ void wfagpu_amd_destroy(wfagpu_amd_ctx_t* c) {
   if (!c) return;
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
-  for (DevBuf* b : {&c->packed, &c->flags, &c->status, &c->cells, &c->bt_final, &c->list_a, &c->list_b, &c->list_c, &c->list_d,
+  for (DevBuf* b : {&c->packed, &c->flags, &c->status, &c->cells, &c->bt_final, &c->list_a, &c->list_b, &c->list_c, &c->list_d, &c->work_ctr,
                     &c->counters, &c->arena, &c->ops, &c->text, &c->cig_off, &c->cig_len, &c->gring})
     b->release();
   if (c->h_counters) hipHostFree(c->h_counters);
@@ -329,7 +336,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   ap.score = d_scores;
   ap.status = static_cast<uint32_t*>(c->status.p);
   ap.cells = static_cast<uint32_t*>(c->cells.p);
-  ap.work_counter = reinterpret_cast<unsigned int*>(ct + CT_WORK);
+  ap.work_counter = static_cast<unsigned int*>(c->work_ctr.p);
   ap.arena_top = ct + CT_ARENA;
   ap.chunk_units = 256;   // 4 KiB refills
   // tuning knob for experiments (not part of the interface)
@@ -415,7 +422,8 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       // returning atomic on ONE word (~88 per microsecond on this chip), which at 4 KiB refills
       // was the whole kernel time
       if (compute_cigar) ap.chunk_units = (uint32_t)std::min<unsigned long long>(env_chunk ? (unsigned)atoi(env_chunk) : 4096u, std::max<unsigned long long>(256, ap.arena_units / (4ull * (unsigned)grid)));
-      if (zero_counter(c, CT_WORK, 2)) return -1;   // work counter + list counter
+      if (zero_counter(c, CT_LIST)) return -1;
+      HIP_TRY(hipMemsetAsync(c->work_ctr.p, 0, 8 * 64, st));
       HIP_TRY(hipEventRecord(c->ev_a0, st));
       wfa_launch_align(ap, tp.tier, compute_cigar, raw, grid, st);
       HIP_TRY(hipGetLastError());
@@ -446,7 +454,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
     // ---- backtrace + CIGAR for everything that finished in this pass ---------
     if (zero_counter(c, CT_SUM_OPS, 2)) return -1;
     if (zero_counter(c, CT_OPS)) return -1;
-    hipLaunchKernelGGL(k_trace_bounds, dim3(cdiv(n_pending, 256)), dim3(256), 0, st, (const uint32_t*)pending, n_pending,
+    hipLaunchKernelGGL(k_trace_bounds, dim3(std::min<uint32_t>(cdiv(n_pending, 256), 1024u)), dim3(256), 0, st, (const uint32_t*)pending, n_pending,
                        static_cast<const uint32_t*>(c->status.p), (const int32_t*)d_scores,
                        static_cast<const uint32_t*>(c->cells.p), std::min(pen.x, pen.e), ct);
     if (read_counters(c)) return -1;
@@ -457,6 +465,12 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       if (c->text.ensure(std::max<size_t>(text_need, c->text_cfg), st, text_used)) return -1;
       WfaTraceParams tp{};
       tp.raw = raw ? 1 : 0;
+      {
+        // both sequences of a pair, as words, per lane; staged in LDS when 64 lanes fit 48 KiB
+        const unsigned per_seq = raw ? (max_len + 3) / 4 + 1 : (max_len + 15) / 16 + 1;
+        const unsigned stride = (2 * per_seq) | 1u;
+        tp.seq_lds_stride = ((size_t)64 * stride * 4 <= (48u << 10)) ? (int)stride : 0;
+      }
       tp.packed = ap.packed; tp.meta = ap.meta; tp.work = pending; tp.n_work = n_pending;
       tp.x = pen.x; tp.oe = oe; tp.e = pen.e;
       tp.score = d_scores; tp.status = static_cast<const uint32_t*>(c->status.p);

@@ -26,6 +26,8 @@ typedef struct {
     void* stream;          /* hipStream_t to run on; NULL: the context creates its own   */
     size_t arena_bytes;    /* backtrace arena (origin bytes + row headers); 0: automatic */
     size_t text_bytes;     /* CIGAR text arena; 0: automatic                             */
+    size_t arena_limit_bytes; /* cap for the automatic arena size (0: none); a batch that needs
+                              more runs in several passes                                   */
 } wfagpu_amd_config_t;
 
 typedef struct {

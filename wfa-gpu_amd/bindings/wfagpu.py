@@ -46,7 +46,8 @@ class Aligner(C.Structure):  # wfagpu_aligner_t
 
 
 class Config(C.Structure):  # wfagpu_amd_config_t
-    _fields_ = [("device", C.c_int), ("stream", C.c_void_p), ("arena_bytes", C.c_size_t), ("text_bytes", C.c_size_t)]
+    _fields_ = [("device", C.c_int), ("stream", C.c_void_p), ("arena_bytes", C.c_size_t), ("text_bytes", C.c_size_t),
+                ("arena_limit_bytes", C.c_size_t)]
 
 
 class Batch(C.Structure):  # wfagpu_amd_batch_t
@@ -225,13 +226,14 @@ def read_seq_file(path, limit=None):
 class DeviceAligner:
     """Owns a wfagpu_amd context on one GPU and runs resident batches through the C-ABI."""
 
-    def __init__(self, device=0, arena_bytes=0, text_bytes=0, use_torch_stream=True):
+    def __init__(self, device=0, arena_bytes=0, text_bytes=0, use_torch_stream=True, arena_limit_bytes=0):
         import torch
         self.torch = torch
         self.lib = load()
         self.device = device
         torch.cuda.set_device(device)
-        cfg = Config(device=device, stream=None, arena_bytes=arena_bytes, text_bytes=text_bytes)
+        cfg = Config(device=device, stream=None, arena_bytes=arena_bytes, text_bytes=text_bytes,
+                     arena_limit_bytes=arena_limit_bytes)
         if use_torch_stream:
             cfg.stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
         self.ctx = C.c_void_p()

@@ -1,11 +1,11 @@
 // Gap-affine wavefront alignment (forward pass) for gfx950.
 //
-// Replaces the reference's distance_kernel / alignment_kernel
-// (lib/kernels/sequence_distance_kernel.cu:175-425,
-//  lib/kernels/sequence_alignment_kernel.cu:355-688), its extend device
-// function (lib/kernels/common_alignment_kernels.cuh:29-111) and their
-// launch layer (lib/sequence_alignment.cu:211-470).  The arithmetic follows
-// WFA2-lib (the ground truth the reference checks itself against):
+// Replaces the reference's distance_kernel / alignment_kernel and their adaptive-band variants
+// (lib/kernels/sequence_distance_kernel.cu:175-425, sequence_alignment_kernel.cu:355-688,
+//  sequence_*_kernel_aband.cu), its extend device function
+// (lib/kernels/common_alignment_kernels.cuh:29-111) and their launch layer
+// (lib/sequence_alignment.cu:211-470).  The arithmetic follows WFA2-lib, the ground truth the
+// reference checks itself against (paths under external/WFA/wavefront):
 //   recurrences + out-of-range nulling  wavefront_compute_affine.c:45-87
 //   per-component end trimming          wavefront_compute.c:570-603
 //   limits of the next wavefront        wavefront_compute.c:41-71
@@ -14,42 +14,44 @@
 // so that score AND CIGAR are identical to WFA2's.
 //
 // Design (MI355X):
-//   * A persistent workgroup of NW wavefronts (NW = 1, 4 or 16) owns one
-//     alignment at a time and pulls the next one from an atomic counter.
-//     The diagonals of the current score are striped over the NW*64 lanes.
-//   * The wavefront ring -- max(x,o+e)+1 rows of M, e+1 rows of I and of D,
-//     16-bit offsets -- and both 2-bit packed sequences live in LDS.  With
-//     NW == 1 the whole score loop runs without a single barrier (LDS
-//     operations of one wavefront execute in order); with NW > 1 there is
-//     exactly one barrier per score.
-//   * extend(): two 32-bit LDS words per sequence, v_alignbit_b32 to the
-//     base position, XOR, count-trailing-zeros: 16 bases per iteration.
-//   * Trimming and termination are wave ballots + scalar bit scans.
-//   * For CIGARs each cell emits ONE origin byte (coalesced 64-byte stores
-//     per wavefront instruction) into a bump-allocated arena; rows are
-//     linked backwards through a 16-byte header.  No O(max_error^2)
-//     per-alignment reservation and nothing to memset between alignments.
-//   * A last-resort instantiation keeps a 32-bit ring in HBM/L2 for
-//     wavefronts too wide for LDS.
+//   * A persistent workgroup of NW wavefronts (NW = 1, 4 or 16) owns one alignment at a time and
+//     claims the next one from 8 sharded counters.  The diagonals of the current score are striped
+//     over the NW*64 lanes.
+//   * The wavefront ring -- max(x,o+e)+1 rows of M, e+1 rows of I and of D, 16-bit offsets -- and
+//     both 2-bit packed sequences live in LDS.  Only the diagonals an alignment within the score
+//     budget can visit are kept (see "window" below), which halves the ring against the
+//     reference's |k| <= max_error sizing.
+//   * Rows are kept physically NULL wherever a later score may read them (guard cells), so the five
+//     reads per cell need no range predicate, and lanes past the end of a row recompute its last
+//     cell, so no store needs an exec mask: the per-cell code is straight-line, the only inner
+//     loop (extend) is wave-uniform.  Validity ballots happen once per score, not per chunk.
+//   * NW == 1: no barrier anywhere in the score loop (LDS operations of one wavefront execute in
+//     order) and the per-row bookkeeping lives in three VGPRs indexed by lane (v_readlane /
+//     v_writelane), not in memory.  NW > 1: one barrier per score.
+//   * extend(): two 32-bit LDS words per sequence, v_alignbit_b32 to the base position, XOR,
+//     count-trailing-zeros: 16 bases per iteration (4 bytes in the byte-compare instantiation).
+//   * For CIGARs each cell emits ONE origin byte (64 consecutive bytes per wavefront store) into a
+//     bump-allocated arena; rows are linked backwards through a 16-byte header.  No
+//     O(max_error^2) per-alignment reservation and nothing to memset between alignments.
+//   * A last-resort instantiation keeps a 32-bit ring in HBM/L2 for wavefronts too wide for LDS.
 #include "wfa_device.h"
 
 namespace {
 
 constexpr int OFF_NULL = -32768;       // any negative offset is "no cell"
-constexpr int EMPTY_LO = 0x3FFFFFFF;   // makes the range predicate false
 
 template <typename OffT> __device__ __forceinline__ OffT off_store(int v);
 template <> __device__ __forceinline__ int16_t off_store<int16_t>(int v) {
-  // offsets past the end of the text only ever grow; saturate them so they
-  // stay "past the end" in 16 bits (host guarantees lengths <= 32766)
+  // an I chain running past the end of the text only ever grows; saturate it so that it stays
+  // "past the end" in 16 bits (host guarantees lengths <= 32766)
   return (int16_t)min(v, 32767);
 }
 template <> __device__ __forceinline__ int32_t off_store<int32_t>(int v) { return v; }
 
 template <int NW> __device__ __forceinline__ void block_sync() {
   if constexpr (NW == 1) {
-    // single wavefront: DS/VMEM operations issue in program order, only the
-    // compiler has to be stopped from reordering or caching across this point
+    // single wavefront: DS/VMEM operations issue in program order, only the compiler has to be
+    // stopped from reordering or caching across this point
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
   } else {
@@ -70,55 +72,33 @@ template <int NW> __device__ __forceinline__ uint32_t block_bcast(uint32_t v, ui
   }
 }
 
-// Longest common prefix of pattern[v..] and text[h..].
-//   RAW == false: 2-bit packed words (little-endian base order), 16 bases per iteration;
-//   RAW == true : the ASCII bytes themselves, 4 per iteration -- for pairs with bytes outside
-//                 ACGT, which must compare as raw bytes like WFA2 does (wavefront_extend.c:174-199).
-template <bool RAW>
-__device__ __forceinline__ int extend_lcp(const uint32_t* __restrict__ Pw,
-                                          const uint32_t* __restrict__ Tw, int plen, int tlen,
-                                          int k, int h) {
-  constexpr int SH = RAW ? 2 : 4;            // log2(symbols per word)
-  constexpr int PER = 1 << SH;
-  constexpr int BITS = RAW ? 3 : 1;          // log2(bits per symbol)
-  int v = h - k;
-  int rem = min(plen - v, tlen - h);
-  while (rem > 0) {
-    const int pi = v >> SH, ti = h >> SH;
-    const uint32_t p0 = Pw[pi], p1 = Pw[pi + 1];
-    const uint32_t t0 = Tw[ti], t1 = Tw[ti + 1];
-    const uint32_t a = __builtin_amdgcn_alignbit(p1, p0, (v & (PER - 1)) << BITS);
-    const uint32_t b = __builtin_amdgcn_alignbit(t1, t0, (h & (PER - 1)) << BITS);
-    const uint32_t d = a ^ b;
-    int n = d ? (__builtin_ctz(d) >> BITS) : PER;
-    n = min(n, rem);
-    h += n; v += n; rem -= n;
-    if (n < PER) break;
+// Per-row bookkeeping of the ring, indexed by M-ring slot:
+//   A = limits of the row, lo in the low and hi in the high 16 bits (lo > hi: no wavefront)
+//   B = arena unit of the row's backtrace record
+//   C = bit 0: I row exists, bit 1: D row exists, bit 2: their limits were trimmed (then they are
+//       in the LDS side table)
+// NW == 1 keeps A, B, C in one VGPR each (lane = slot): reading is one v_readlane, no LDS round trip.
+constexpr int ROW_NONE_A = (int)0xFFFF0001u;   // lo = 1, hi = -1
+__device__ __forceinline__ int pack_range(int lo, int hi) { return (lo & 0xFFFF) | (int)((unsigned)hi << 16); }
+__device__ __forceinline__ int range_lo(int a) { return (int)(int16_t)(a & 0xFFFF); }
+__device__ __forceinline__ int range_hi(int a) { return a >> 16; }
+
+template <int NW> struct RowBook {
+  int a, b, c;          // NW == 1
+  int *A, *B, *C;       // NW > 1 (LDS)
+  __device__ __forceinline__ int get_a(int slot) const { if constexpr (NW == 1) return __builtin_amdgcn_readlane(a, slot); else return A[slot]; }
+  __device__ __forceinline__ int get_b(int slot) const { if constexpr (NW == 1) return __builtin_amdgcn_readlane(b, slot); else return B[slot]; }
+  __device__ __forceinline__ int get_c(int slot) const { if constexpr (NW == 1) return __builtin_amdgcn_readlane(c, slot); else return C[slot]; }
+  // every thread calls set with the same values (NW > 1: same-value stores, each thread reads back its own)
+  __device__ __forceinline__ void set(int slot, int va, int vb, int vc) {
+    if constexpr (NW == 1) {
+      const bool mine = (int)(threadIdx.x & 63) == slot;
+      a = mine ? va : a; b = mine ? vb : b; c = mine ? vc : c;
+    } else {
+      A[slot] = va; B[slot] = vb; C[slot] = vc;
+    }
   }
-  return h;
-}
-
-struct RowRange { int lo, w; };  // predicate: (unsigned)(k - lo) <= (unsigned)w
-__device__ __forceinline__ RowRange make_range(int lo, int hi) {
-  RowRange r;
-  if (hi >= lo) { r.lo = lo; r.w = hi - lo; } else { r.lo = EMPTY_LO; r.w = 0; }
-  return r;
-}
-
-template <typename OffT>
-__device__ __forceinline__ int rd_cell(const OffT* row, int kidx0, int k, RowRange r) {
-  const int val = (int)row[kidx0 + k];
-  return ((unsigned)(k - r.lo) <= (unsigned)r.w) ? val : OFF_NULL;
-}
-
-// Banded rows are stored relative to their own window base (the window moves), so the index
-// is only formed for in-range diagonals.
-template <typename OffT>
-__device__ __forceinline__ int rd_cell_rel(const OffT* row, int base, int k, RowRange r) {
-  const bool in = (unsigned)(k - r.lo) <= (unsigned)r.w;
-  const int val = (int)row[in ? k - base : 0];
-  return in ? val : OFF_NULL;
-}
+};
 
 template <int NW, bool BT, typename OffT, bool GLOBAL_RING, bool RAW, bool BANDED>
 __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams p) {
@@ -126,11 +106,10 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
   constexpr int NT = NW * 64;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = (NW == 1) ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6);
   const int dm = p.dm, de = p.de, rs = p.rs;
   const int x = p.x, oe = p.oe, e = p.e;
 
-  // ---- carve LDS -------------------------------------------------------
+  // ---- carve LDS -----------------------------------------------------------------------------
   unsigned char* sp = smem;
   OffT* Mr;
   if constexpr (GLOBAL_RING) {
@@ -139,38 +118,34 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
     Mr = reinterpret_cast<OffT*>(sp);
     sp += (((size_t)(dm + 2 * de) * rs * sizeof(OffT)) + 15) & ~(size_t)15;
   }
-  OffT* Ir = Mr + (size_t)dm * rs;
-  OffT* Dr = Ir + (size_t)de * rs;
+  const int i_off = dm * rs, d_off = (dm + de) * rs;     // element offsets of the I and D rings
   uint32_t* Pw = reinterpret_cast<uint32_t*>(sp);
   uint32_t* Tw = Pw + p.seq_words_cap;
-  int* mlo = reinterpret_cast<int*>(Tw + p.seq_words_cap);
-  int* mhi = mlo + dm;
-  int* ilo = mhi + dm;
-  int* ihi = ilo + de;
-  int* dlo = ihi + de;
-  int* dhi = dlo + de;
-  uint32_t* btrow = reinterpret_cast<uint32_t*>(dhi + de);
-  int* red = reinterpret_cast<int*>(btrow + dm);        // [3][8]
-  uint32_t* bslot = reinterpret_cast<uint32_t*>(red + 24);  // [2]
-  int* mbase = reinterpret_cast<int*>(bslot + 2);       // [dm] window base of each M row (BANDED)
-  int* ebase = mbase + dm;                              // [de] window base of each I/D row
+  int* side = reinterpret_cast<int*>(Tw + p.seq_words_cap);   // [4][dm] trimmed I/D limits (rare)
+  int* red = side + 4 * dm;                                   // [3][8] per-score reduction slots (NW > 1)
+  uint32_t* bslot = reinterpret_cast<uint32_t*>(red + 24);    // [2] broadcast slots
+  RowBook<NW> book;
+  if constexpr (NW == 1) { book.a = ROW_NONE_A; book.b = (int)WFA_ROW_NONE; book.c = 0; book.A = book.B = book.C = nullptr; }
+  else { book.a = book.b = book.c = 0; book.A = reinterpret_cast<int*>(bslot + 2); book.B = book.A + dm; book.C = book.B + dm; }
+
   uint32_t chunk_cur = 0, chunk_left = 0;   // arena units owned by this block
 
-  // Work distribution: the list is cut into 8 contiguous shards, each with its own counter on its
-  // own cache line; a block starts on shard blockIdx % 8 (the XCD it most likely runs on) and moves
-  // on when a shard is empty.  One counter word serves only ~88 claims per microsecond, which
-  // capped short-read batches (BASELINE configs[1]) at 1.2 ms per 100k pairs.
-  uint32_t shard = blockIdx.x & 7u, shards_left = 8;
+  // Work distribution: the list is cut into contiguous shards, each with its own counter on its
+  // own cache line; a block starts on shard blockIdx % 8 and moves on when a shard is empty.  One
+  // counter word serves only ~88 claims per microsecond, which capped short-read batches
+  // (BASELINE configs[1]) at 1.2 ms per 100k pairs.
+  const uint32_t nsh = p.work_shards;              // 1 or 8
+  uint32_t shard = blockIdx.x & (nsh - 1u), shards_left = nsh;
   for (;;) {
     uint32_t w = 0xFFFFFFFFu;
     while (shards_left) {
-      const uint32_t lo_w = (uint32_t)(((unsigned long long)p.n_work * shard) >> 3);
-      const uint32_t hi_w = (uint32_t)(((unsigned long long)p.n_work * (shard + 1)) >> 3);
+      const uint32_t lo_w = (uint32_t)(((unsigned long long)p.n_work * shard) / nsh);
+      const uint32_t hi_w = (uint32_t)(((unsigned long long)p.n_work * (shard + 1)) / nsh);
       uint32_t c = 0;
       if (tid == 0) c = atomicAdd(p.work_counter + shard * 16, 1u);
       c = block_bcast<NW>(c, bslot);
       if (c < hi_w - lo_w) { w = lo_w + c; break; }
-      shard = (shard + 1) & 7u; --shards_left;
+      shard = (shard + 1) & (nsh - 1u); --shards_left;
     }
     if (w == 0xFFFFFFFFu) break;
     const uint32_t pair = p.work ? p.work[w] : w;
@@ -184,12 +159,12 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
     int s = 0;
     uint32_t ncells = 1;
     bool done = false;
+    uint32_t row_s = WFA_ROW_NONE;
 
     // Diagonal window that can hold an alignment of score <= max_score (exact, not a heuristic):
     // a path that visits diagonal k beyond both 0 and kend needs one gap out and one gap back,
     // i.e. costs at least 2o + (|k| + |k - kend|) e, so cells outside the window cannot lie on any
-    // path the backtrace can choose while the score stays within the limit.  It halves the LDS
-    // ring compared to the reference's |k| <= max_error sizing.
+    // path the backtrace can choose while the score stays within the limit.
     int wlo = -plen, whi = tlen;
     bool feasible = true;
     if constexpr (!BANDED) {
@@ -204,39 +179,36 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
         whi = min(whi, tlen); wlo = max(wlo, -plen);
       }
     }
-    const int kidx0 = 1 - wlo;              // row index of diagonal 0 (one guard cell each side)
+    const int kidx0 = 1 - wlo;              // exact mode: row index of diagonal 0 (one guard cell each side)
 
     if (!feasible) {
       status = WFA_ST_SCORE;
     } else if ((!BANDED && whi - wlo + 3 > rs) || pwords > p.seq_words_cap || twords > p.seq_words_cap) {
       status = WFA_ST_BAND;
     } else {
-      // ---- stage packed sequences, reset row metadata -----------------------
+      // ---- stage the sequences, reset the ring ---------------------------------------------
       const uint32_t* __restrict__ gp = p.packed + ((RAW ? mp.pattern_offset : mp.pattern_offset_packed) >> 2);
       const uint32_t* __restrict__ gt = p.packed + ((RAW ? mp.text_offset : mp.text_offset_packed) >> 2);
       for (int i = tid; i < pwords; i += NT) Pw[i] = gp[i];
       for (int i = tid; i < twords; i += NT) Tw[i] = gt[i];
       if constexpr (!BANDED) {
-        // Exact mode keeps the ring rows physically NULL wherever a later score may read them
-        // (so reads need no range predicate): before any row is written, that is |k| <= dm + 1.
+        // rows that no score has written yet must read as NULL: that is |k| <= dm + 1
         const int f0 = max(wlo - 1, -(dm + 1)), f1 = min(whi + 1, dm + 1);
         const int nf = f1 - f0 + 1;
         for (int i = tid; i < (dm + 2 * de) * nf; i += NT) {
           const int r = i / nf, q = f0 + (i - r * nf);
-          Mr[(size_t)r * rs + kidx0 + q] = off_store<OffT>(OFF_NULL);   // rows of M, I, D are contiguous
+          Mr[(size_t)r * rs + kidx0 + q] = (OffT)OFF_NULL;   // rows of M, I, D are contiguous
         }
       }
-      for (int i = tid; i < dm; i += NT) { mlo[i] = 1; mhi[i] = -1; btrow[i] = WFA_ROW_NONE; }
-      for (int i = tid; i < de; i += NT) { ilo[i] = 1; ihi[i] = -1; dlo[i] = 1; dhi[i] = -1; }
-      if constexpr (NW > 1) {
+      if constexpr (NW == 1) { book.a = ROW_NONE_A; book.b = (int)WFA_ROW_NONE; book.c = 0; }
+      else {
+        for (int i = tid; i < dm; i += NT) { book.A[i] = ROW_NONE_A; book.B[i] = (int)WFA_ROW_NONE; book.C[i] = 0; }
         if (tid < 24) red[tid] = (tid & 7) == 6 ? 0 : (((tid & 7) & 1) ? INT_MIN : INT_MAX);
       }
       block_sync<NW>();
 
-      // ---- score 0: M[0][0] = extend(0) -------------------------------------
-      uint32_t row_s = WFA_ROW_NONE;
+      // ---- score 0: M[0][0] = extend(0) ------------------------------------------------------
       if constexpr (BT) {
-        // row 0: header + one code byte
         if (chunk_left < 2) {
           const uint32_t grab = max(2u, p.chunk_units);
           uint32_t base = WFA_ROW_NONE;
@@ -259,18 +231,25 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
       }
       uint32_t d0 = 0;
       if (tid == 0) {
-        const int h0 = extend_lcp<RAW>(Pw, Tw, plen, tlen, 0, 0);
-        if constexpr (BANDED) { Mr[0] = off_store<OffT>(h0); mbase[0] = 0; }
-        else Mr[kidx0] = off_store<OffT>(h0);
-        mlo[0] = 0; mhi[0] = 0; btrow[0] = row_s;
+        // longest common prefix from (0,0): both sequences start word-aligned
+        constexpr int SH = RAW ? 2 : 4, PER = 1 << SH, BITS = RAW ? 3 : 1;
+        int h0 = 0, rem = min(plen, tlen);
+        while (rem > 0) {
+          const uint32_t d = Pw[h0 >> SH] ^ Tw[h0 >> SH];
+          const int n = min((int)((d ? (uint32_t)__builtin_ctz(d) : 32u) >> BITS), rem);
+          h0 += n; rem -= n;
+          if (n < PER) break;
+        }
+        Mr[BANDED ? 0 : kidx0] = (OffT)h0;
         d0 = (kend == 0 && h0 >= tlen) ? 1u : 0u;
       }
+      book.set(0, pack_range(0, 0), (int)row_s, 0);
       done = block_bcast<NW>(d0, bslot) != 0;
       block_sync<NW>();
 
-      int slot_m = 0, slot_e = 0;   // ring slots of score s
-      int hist_lo = 0, hist_hi = 0;  // widest limits so far (exact mode: bounds of the NULL fill)
-      // ---- score loop ---------------------------------------------------------
+      int slot_m = 0, slot_e = 0;    // ring slots of score s
+      int hist_lo = 0, hist_hi = 0;  // widest limits so far (exact mode: bounds of the NULL guard cells)
+      // ---- score loop ----------------------------------------------------------------------------
       while (!done && status == WFA_ST_DONE) {
         ++s;
         if (s > p.max_score) { status = WFA_ST_SCORE; break; }
@@ -280,19 +259,21 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
         }
         slot_m = (slot_m + 1 == dm) ? 0 : slot_m + 1;
         slot_e = (slot_e + 1 == de) ? 0 : slot_e + 1;
-        // predecessor rows
+        // predecessor rows: s-x and s-(o+e) of M, s-e of I and D
         int sl_x = slot_m - x;   if (sl_x < 0) sl_x += dm;
         int sl_oe = slot_m - oe; if (sl_oe < 0) sl_oe += dm;
-        int sl_e = slot_e - e;   if (sl_e < 0) sl_e += de;
-        int mxlo = 1, mxhi = -1, molo = 1, mohi = -1, ielo = 1, iehi = -1, delo = 1, dehi = -1;
-        uint32_t r_x = WFA_ROW_NONE, r_oe = WFA_ROW_NONE, r_e = WFA_ROW_NONE;
-        if (s >= x) { mxlo = mlo[sl_x]; mxhi = mhi[sl_x]; r_x = btrow[sl_x]; }
-        if (s >= oe) { molo = mlo[sl_oe]; mohi = mhi[sl_oe]; r_oe = btrow[sl_oe]; }
-        if (s >= e) {
-          ielo = ilo[sl_e]; iehi = ihi[sl_e]; delo = dlo[sl_e]; dehi = dhi[sl_e];
-          // the M ring is deeper than the I/D ring: row s-e of M holds the bt row
-          int sl_me = slot_m - e; if (sl_me < 0) sl_me += dm;
-          r_e = btrow[sl_me];
+        int sl_me = slot_m - e;  if (sl_me < 0) sl_me += dm;   // M-ring slot of score s-e (bookkeeping)
+        int sl_e = slot_e - e;   if (sl_e < 0) sl_e += de;     // I/D-ring slot of score s-e (data)
+        const int a_x = (s >= x) ? book.get_a(sl_x) : ROW_NONE_A;
+        const int a_oe = (s >= oe) ? book.get_a(sl_oe) : ROW_NONE_A;
+        const int a_e = (s >= e) ? book.get_a(sl_me) : ROW_NONE_A;
+        const int c_e = (s >= e) ? book.get_c(sl_me) : 0;
+        const int mxlo = range_lo(a_x), mxhi = range_hi(a_x), molo = range_lo(a_oe), mohi = range_hi(a_oe);
+        int ielo = 1, iehi = -1, delo = 1, dehi = -1;
+        if (c_e & 1) { ielo = range_lo(a_e); iehi = range_hi(a_e); }
+        if (c_e & 2) { delo = range_lo(a_e); dehi = range_hi(a_e); }
+        if (c_e & 4) {   // trimmed limits (some value ran past a sequence end at that score)
+          ielo = side[sl_me]; iehi = side[dm + sl_me]; delo = side[2 * dm + sl_me]; dehi = side[3 * dm + sl_me];
         }
         const bool mx_null = mxlo > mxhi, mo_null = molo > mohi, ie_null = ielo > iehi, de_null = delo > dehi;
         // limits (wavefront_compute.c:41-71; null rows carry lo=1, hi=-1)
@@ -301,35 +282,36 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
         lo = min(lo, ielo + 1); hi = max(hi, iehi + 1);
         lo = min(lo, delo - 1); hi = max(hi, dehi - 1);
         if constexpr (!BANDED) { lo = max(lo, wlo); hi = min(hi, whi); }
+        OffT* out_m = Mr + (size_t)slot_m * rs;
+        OffT* out_i = Mr + (size_t)(i_off + slot_e * rs);
+        OffT* out_d = Mr + (size_t)(d_off + slot_e * rs);
         if ((mx_null && mo_null && ie_null && de_null) || lo > hi) {
           // no wavefront at this score (wavefront_compute_affine.c:236-243)
-          mlo[slot_m] = 1; mhi[slot_m] = -1; btrow[slot_m] = WFA_ROW_NONE;
-          ilo[slot_e] = 1; ihi[slot_e] = -1; dlo[slot_e] = 1; dhi[slot_e] = -1;
+          book.set(slot_m, ROW_NONE_A, (int)WFA_ROW_NONE, 0);
           if constexpr (!BANDED) {
             const int f0 = max(wlo - 1, hist_lo - dm), f1 = min(whi + 1, hist_hi + dm);
-            OffT* nm = Mr + (size_t)slot_m * rs; OffT* ni = Ir + (size_t)slot_e * rs; OffT* nd = Dr + (size_t)slot_e * rs;
             for (int q = f0 + tid; q <= f1; q += NT) {
-              nm[kidx0 + q] = off_store<OffT>(OFF_NULL); ni[kidx0 + q] = off_store<OffT>(OFF_NULL); nd[kidx0 + q] = off_store<OffT>(OFF_NULL);
+              out_m[kidx0 + q] = (OffT)OFF_NULL; out_i[kidx0 + q] = (OffT)OFF_NULL; out_d[kidx0 + q] = (OffT)OFF_NULL;
             }
           }
           block_sync<NW>();
           continue;
         }
+        const int base_mx = BANDED ? mxlo : 0, base_mo = BANDED ? molo : 0, base_e = BANDED ? range_lo(a_e) : 0;
         if constexpr (BANDED) {
           // Adaptive band (reference: sequence_distance_kernel_aband.cu:104-130): keep at most
           // band_width diagonals; every band_period scores re-centre the window on the diagonal of
           // the mismatch-source wavefront whose furthest point is closest to the end, otherwise
-          // shave the excess off both sides.
+          // shave the excess off both sides.  Rows are stored relative to their own lo.
           const int beta = p.band_width;
           const int excess = (hi - lo + 1) - beta;
           if (excess > 0) {
             bool recentred = false;
             if (!mx_null && (s % p.band_period) == 0) {
               const OffT* rowc = Mr + (size_t)sl_x * rs;
-              const int cbase = mbase[sl_x];
               uint32_t best = 0xFFFFFFFFu;
               for (int kk = mxlo + tid; kk <= mxhi; kk += NT) {
-                const int off = (int)rowc[kk - cbase];
+                const int off = (int)rowc[kk - mxlo];
                 if (off >= 0) {
                   const int dist = max(plen - (off - kk), tlen - off);
                   best = min(best, ((uint32_t)dist << 16) | (uint32_t)(kk - mxlo));
@@ -377,23 +359,17 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
             chunk_cur = base; chunk_left = grab;
           }
           row_s = chunk_cur; chunk_cur += need; chunk_left -= need;
-          if (tid == 0) {
-            WfaBtRowHdr* hdr = reinterpret_cast<WfaBtRowHdr*>(p.arena + (size_t)row_s * 16);
-            hdr->lo = lo; hdr->prev_x = r_x; hdr->prev_oe = r_oe; hdr->prev_e = r_e;
-          }
+          const uint32_t r_x = (s >= x) ? (uint32_t)book.get_b(sl_x) : WFA_ROW_NONE;
+          const uint32_t r_oe = (s >= oe) ? (uint32_t)book.get_b(sl_oe) : WFA_ROW_NONE;
+          const uint32_t r_e = (s >= e) ? (uint32_t)book.get_b(sl_me) : WFA_ROW_NONE;
+          if (tid == 0) *reinterpret_cast<uint4*>(p.arena + (size_t)row_s * 16) = make_uint4((uint32_t)lo, r_x, r_oe, r_e);
           codes = p.arena + (size_t)row_s * 16 + 16;
         }
 
-        const RowRange rg_mx = make_range(mxlo, mxhi), rg_mo = make_range(molo, mohi);
-        const RowRange rg_ie = make_range(ielo, iehi), rg_de = make_range(delo, dehi);
         const OffT* row_mx = Mr + (size_t)sl_x * rs;
         const OffT* row_mo = Mr + (size_t)sl_oe * rs;
-        const OffT* row_ie = Ir + (size_t)sl_e * rs;
-        const OffT* row_de = Dr + (size_t)sl_e * rs;
-        OffT* out_m = Mr + (size_t)slot_m * rs;
-        OffT* out_i = Ir + (size_t)slot_e * rs;
-        OffT* out_d = Dr + (size_t)slot_e * rs;
-        const int base_mx = BANDED ? mbase[sl_x] : 0, base_mo = BANDED ? mbase[sl_oe] : 0, base_e = BANDED ? ebase[sl_e] : 0;
+        const OffT* row_ie = Mr + (size_t)(i_off + sl_e * rs);
+        const OffT* row_de = Mr + (size_t)(d_off + sl_e * rs);
         const int wbase = BANDED ? -lo : kidx0;   // index of diagonal 0 in the rows written now
 
         if constexpr (!BANDED) {
@@ -401,28 +377,33 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
           // read from this row (limits move by at most one diagonal per score, a row lives dm scores)
           hist_lo = min(hist_lo, lo); hist_hi = max(hist_hi, hi);
           const int f0 = max(wlo - 1, hist_lo - dm), f1 = min(whi + 1, hist_hi + dm);
-          for (int q = f0 + tid; q < lo; q += NT) {
-            out_m[kidx0 + q] = off_store<OffT>(OFF_NULL); out_i[kidx0 + q] = off_store<OffT>(OFF_NULL); out_d[kidx0 + q] = off_store<OffT>(OFF_NULL);
-          }
-          for (int q = hi + 1 + tid; q <= f1; q += NT) {
-            out_m[kidx0 + q] = off_store<OffT>(OFF_NULL); out_i[kidx0 + q] = off_store<OffT>(OFF_NULL); out_d[kidx0 + q] = off_store<OffT>(OFF_NULL);
+          const int nlo = lo - f0, ntot = nlo + (f1 - hi);
+          for (int j = tid; j < ntot; j += NT) {
+            const int q = (j < nlo) ? f0 + j : hi + 1 + (j - nlo);
+            out_m[kidx0 + q] = (OffT)OFF_NULL; out_i[kidx0 + q] = (OffT)OFF_NULL; out_d[kidx0 + q] = (OffT)OFF_NULL;
           }
         }
+
         // ---- the cells of this score.  Straight-line per lane: no divergent branch inside, the
         // only loop (extend) is wave-uniform.  Lanes past the end recompute cell `hi` (same values,
-        // same addresses), so no store needs an exec mask.  Scalar-unit work per chunk is a loop
-        // counter and the wait counters; validity ballots happen once per score.
+        // same addresses), so no store needs an exec mask.
         bool my_done = false, my_over = false;
         for (int k0 = lo; k0 <= hi; k0 += NT) {
           const int k = min(k0 + tid, hi);
           // recurrences (wavefront_compute_affine.c:66-84)
           int m_x, m_ol, m_or, i_e, d_e;
           if constexpr (BANDED) {
-            m_x = rd_cell_rel(row_mx, base_mx, k, rg_mx);
-            m_ol = rd_cell_rel(row_mo, base_mo, k - 1, rg_mo);
-            m_or = rd_cell_rel(row_mo, base_mo, k + 1, rg_mo);
-            i_e = rd_cell_rel(row_ie, base_e, k - 1, rg_ie);
-            d_e = rd_cell_rel(row_de, base_e, k + 1, rg_de);
+            // rows live at their own window base: form the index only for diagonals inside the row
+            const bool in_x = !mx_null && (unsigned)(k - mxlo) <= (unsigned)(mxhi - mxlo);
+            const bool in_ol = !mo_null && (unsigned)(k - 1 - molo) <= (unsigned)(mohi - molo);
+            const bool in_or = !mo_null && (unsigned)(k + 1 - molo) <= (unsigned)(mohi - molo);
+            const bool in_ie = !ie_null && (unsigned)(k - 1 - ielo) <= (unsigned)(iehi - ielo);
+            const bool in_de = !de_null && (unsigned)(k + 1 - delo) <= (unsigned)(dehi - delo);
+            m_x = in_x ? (int)row_mx[k - base_mx] : OFF_NULL;
+            m_ol = in_ol ? (int)row_mo[k - 1 - base_mo] : OFF_NULL;
+            m_or = in_or ? (int)row_mo[k + 1 - base_mo] : OFF_NULL;
+            i_e = in_ie ? (int)row_ie[k - 1 - base_e] : OFF_NULL;
+            d_e = in_de ? (int)row_de[k + 1 - base_e] : OFF_NULL;
           } else {
             m_x = (int)row_mx[kidx0 + k];
             m_ol = (int)row_mo[kidx0 + k - 1];
@@ -439,8 +420,8 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
           uint32_t code = 0;
           if constexpr (BT) {
             // tie-breaks: gap extension wins over gap open on equal offsets
-            // (wavefront_compute_affine.c:135-143,153-161); for M: mismatch,
-            // then deletion, then insertion (wavefront_backtrace.c:48-59)
+            // (wavefront_compute_affine.c:135-143,153-161); for M: mismatch, then deletion, then
+            // insertion (wavefront_backtrace.c:48-59)
             code = (i_e >= m_ol ? BT_I_EXT : 0u) | (d_e >= m_or ? BT_D_EXT : 0u);
             const uint32_t org = (mis == mv0) ? BT_M_X : ((del == mv0) ? BT_M_D : BT_M_I);
             code |= ok ? org : 0u;
@@ -481,8 +462,8 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
           // M and D offsets never exceed the text length, so they fit 16 bits as they are; only an I
           // chain running past the text end keeps growing and is saturated by off_store
           out_m[wbase + k] = (OffT)mv;
-          if (!BANDED || have_i) out_i[wbase + k] = off_store<OffT>(ins);
-          if (!BANDED || have_d) out_d[wbase + k] = (OffT)del;
+          out_i[wbase + k] = off_store<OffT>(ins);
+          out_d[wbase + k] = (OffT)del;
           if constexpr (BT) codes[(uint32_t)(k - lo)] = (uint8_t)code;
           my_done |= (k == kend) && (mv >= tlen);
         }
@@ -500,12 +481,12 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
             any_over = (acc[6] & 2) != 0;
           }
         }
-        // M limits: the computed ones (cells that are not valid hold NULL, which is all a reader needs)
-        int wmlo = lo, wmhi = hi;
-        // I and D limits: the computed ones, unless some value ran past a sequence end
-        int wilo = have_i ? lo : 1, wihi = have_i ? hi : -1, wdlo = have_d ? lo : 1, wdhi = have_d ? hi : -1;
+        // Limits recorded for the row: the computed ones.  Cells that are not valid hold NULL or a
+        // negative value, which is all a reader needs; only values past a sequence end need the
+        // exact per-component trimming (wavefront_compute.c:570-603): first/last in-range cell.
+        int cflags = (have_i ? 1 : 0) | (have_d ? 2 : 0);
         if (any_over) {
-          // exact per-component trimming (wavefront_compute.c:570-603): first/last in-range cell
+          const int wave = (NW == 1) ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6);
           int r[4] = {INT_MAX, INT_MIN, INT_MAX, INT_MIN};
           for (int k0 = lo; k0 <= hi; k0 += NT) {
             const int kraw = k0 + tid;
@@ -521,7 +502,6 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
             if (bd) { r[2] = min(r[2], b + (int)__builtin_ctzll(bd)); r[3] = max(r[3], b + 63 - (int)__builtin_clzll(bd)); }
           }
           if constexpr (NW > 1) {
-            // rare path: one more triple of barriers is fine
             int* acc = red + 8 * (s % 3) + 2;            // words 2..5 of this score's slot are unused so far
             if (lane == 0) {
               if (r[0] <= r[1]) { atomicMin(&acc[0], r[0]); atomicMax(&acc[1], r[1]); }
@@ -530,24 +510,21 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
             __syncthreads();
             r[0] = acc[0]; r[1] = acc[1]; r[2] = acc[2]; r[3] = acc[3];
           }
-          wilo = r[0]; wihi = r[1]; wdlo = r[2]; wdhi = r[3];
-          if (wilo > wihi) { wilo = 1; wihi = -1; }
-          if (wdlo > wdhi) { wdlo = 1; wdhi = -1; }
+          if (r[0] > r[1]) { r[0] = 1; r[1] = -1; }
+          if (r[2] > r[3]) { r[2] = 1; r[3] = -1; }
+          // every thread stores the same values and later reads its own copy back
+          side[slot_m] = r[0]; side[dm + slot_m] = r[1]; side[2 * dm + slot_m] = r[2]; side[3 * dm + slot_m] = r[3];
+          cflags = 7;
           if constexpr (!BANDED) {
             // trimmed-away cells read as NULL from now on (wavefront_compute.c:480-520)
             for (int q = lo + tid; q <= hi; q += NT) {
-              if (q < wilo || q > wihi) out_i[kidx0 + q] = off_store<OffT>(OFF_NULL);
-              if (q < wdlo || q > wdhi) out_d[kidx0 + q] = off_store<OffT>(OFF_NULL);
+              if (q < r[0] || q > r[1]) out_i[kidx0 + q] = (OffT)OFF_NULL;
+              if (q < r[2] || q > r[3]) out_d[kidx0 + q] = (OffT)OFF_NULL;
             }
             if constexpr (NW > 1) __syncthreads();
           }
         }
-        // every thread records the same row metadata (it reads its own copy back)
-        if (wmlo > wmhi) { wmlo = 1; wmhi = -1; }
-        mlo[slot_m] = wmlo; mhi[slot_m] = wmhi; btrow[slot_m] = row_s;
-        if constexpr (BANDED) { mbase[slot_m] = lo; ebase[slot_e] = lo; }
-        ilo[slot_e] = wilo; ihi[slot_e] = wihi;
-        dlo[slot_e] = wdlo; dhi[slot_e] = wdhi;
+        book.set(slot_m, pack_range(lo, hi), (int)row_s, cflags);
         if constexpr (NW == 1) block_sync<NW>();
       }
       if (tid == 0 && status == WFA_ST_DONE) {
@@ -628,7 +605,8 @@ size_t wfa_align_lds_bytes(const WfaAlignParams& p, int tier) {
   size_t ring = 0;
   if (tier != 3) ring = (((size_t)(p.dm + 2 * p.de) * p.rs * sizeof(int16_t)) + 15) & ~(size_t)15;
   const size_t seq = (size_t)2 * p.seq_words_cap * 4;
-  const size_t meta = (size_t)(2 * p.dm + 4 * p.de + p.dm + 24 + 2 + p.dm + p.de) * 4 + 16;
+  // side table [4][dm] + reduction slots [24] + broadcast [2] + (NW > 1) row book [3][dm]
+  const size_t meta = (size_t)(4 * p.dm + 24 + 2 + (tier == 0 ? 0 : 3 * p.dm)) * 4;
   return ((ring + seq + meta) + 15) & ~(size_t)15;
 }
 

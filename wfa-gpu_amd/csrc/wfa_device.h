@@ -59,6 +59,7 @@ struct WfaAlignParams {
   const uint32_t* work;          // pair indices to process (NULL: identity)
   uint32_t n_work;
   unsigned int* work_counter;    // dynamic work distribution: 8 counters, 64 bytes apart (zeroed before launch)
+  uint32_t work_shards;          // 1 or 8 of them in use
   int x, oe, e;                  // penalties: mismatch, open+extend, extend
   int dm, de;                    // ring depths: max(x,oe)+1 rows of M, e+1 rows of I and D
   int rs;                        // row stride (elements), even: widest diagonal window + 3

@@ -141,7 +141,7 @@ struct wfagpu_amd_ctx {
   bool own_stream = false;
   int num_cus = 0;
   size_t lds_per_block_max = 0;
-  size_t arena_cfg = 0, text_cfg = 0;
+  size_t arena_cfg = 0, text_cfg = 0, arena_limit = 0;
   DevBuf packed, flags, status, cells, bt_final, list_a, list_b, list_c, list_d, work_ctr, counters, arena, ops, text, cig_off, cig_len, gring;
   unsigned long long* h_counters = nullptr;  // pinned
   hipEvent_t ev_start = nullptr, ev_pack = nullptr, ev_a0 = nullptr, ev_a1 = nullptr, ev_t0 = nullptr, ev_t1 = nullptr, ev_end = nullptr;
@@ -174,6 +174,7 @@ int wfagpu_amd_create(wfagpu_amd_ctx_t** out, const wfagpu_amd_config_t* cfg) {
   c->lds_per_block_max = prop.sharedMemPerBlock;   // 160 KiB on gfx950 (checked, not assumed)
   c->arena_cfg = cfg ? cfg->arena_bytes : 0;
   c->text_cfg = cfg ? cfg->text_bytes : 0;
+  c->arena_limit = cfg ? cfg->arena_limit_bytes : 0;
   HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_counters), CT_N * sizeof(unsigned long long), hipHostMallocDefault));
   HIP_TRY(hipEventCreate(&c->ev_start)); HIP_TRY(hipEventCreate(&c->ev_pack));
   HIP_TRY(hipEventCreate(&c->ev_a0)); HIP_TRY(hipEventCreate(&c->ev_a1));
@@ -244,7 +245,8 @@ bool plan_tier(const wfagpu_amd_ctx* c, WfaAlignParams& p, int max_score, unsign
   if (p.band_width > 0) {
     // adaptive band: the ring rows hold band_width diagonals whatever the score
     p.rs = (p.band_width + 2 + 1) & ~1;
-    const int t = p.band_width <= 256 ? 0 : (p.band_width <= 1024 ? 1 : 2);
+    // (the single-wavefront kernels keep the row book in VGPR lanes: at most 64 ring rows)
+    const int t = (p.band_width <= 256 && p.dm <= 64) ? 0 : (p.band_width <= 1024 ? 1 : 2);
     const size_t lds = wfa_align_lds_bytes(p, t);
     if (lds > c->lds_per_block_max || max_seq_len > 32766u || max_score > 30000) return false;
     const int nb = wfa_align_max_blocks_per_cu(t, bt, false, true, lds);
@@ -260,7 +262,7 @@ bool plan_tier(const wfagpu_amd_ctx* c, WfaAlignParams& p, int max_score, unsign
     const size_t lds = wfa_align_lds_bytes(p, t);
     if (lds > budget[t]) continue;
     // a single wavefront sweeps up to ~16 chunks per score before more waves pay off
-    if (t == 0 && width > 1024) continue;
+    if (t == 0 && (width > 1024 || p.dm > 64)) continue;
     if (t == 1 && width > 8192) continue;
     const int nb = wfa_align_max_blocks_per_cu(t, bt, raw, false, lds);
     if (nb < 1) continue;
@@ -343,16 +345,20 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   const char* env_chunk = getenv("WFAGPU_CHUNK_UNITS");
   ap.bt_final_row = static_cast<uint32_t*>(c->bt_final.p);
 
+  // Expected backtrace bytes per pair: a quarter of the score-budget square of origin bytes plus row
+  // headers; refined from what finished pairs really used after every pass.  Passes launch only as
+  // many pairs as the arena is expected to hold, so a small arena costs passes, not repeated work.
+  double est_pair_bytes = 0.25 * ((double)std::min<unsigned>(max_error, 2 * max_len) + 1) * ((double)std::min<unsigned>(max_error, 2 * max_len) + 1) +
+                          16.0 * std::min<unsigned>(max_error, 2 * max_len) + 4096.0;
   if (compute_cigar) {
     // arena: expected need, bounded by configuration / free memory / 32-bit unit addressing
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     size_t want = c->arena_cfg;
     if (!want) {
-      const double h = std::min<double>(max_error, max_len);
-      const double per_pair = (h + 1) * (h + 1) + 16.0 * max_error + 8192.0;
-      want = (size_t)std::min<double>(per_pair * n, 0.45 * (double)(free_b + c->arena.cap));
+      want = (size_t)std::min<double>(est_pair_bytes * 1.1 * n, 0.45 * (double)(free_b + c->arena.cap));
       want = std::max<size_t>(want, (size_t)64 << 20);
+      if (c->arena_limit) want = std::min(want, std::max<size_t>(c->arena_limit, (size_t)64 << 20));
     }
     want = std::min<size_t>(want, ((size_t)1 << 36) - 4096);
     if (c->arena.cap < want && c->arena.ensure(want, st)) return -1;
@@ -391,10 +397,16 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   grid_cap = UINT32_MAX;
   while (n_pending > 0) {
     c->stats.sub_batches++;
+    // pairs launched in this pass: what the arena is expected to hold (at least one wave of workgroups)
+    uint32_t n_pass = n_pending;
+    if (compute_cigar) {
+      const double fit = (double)c->arena.cap / std::max(1.0, est_pair_bytes);
+      n_pass = (uint32_t)std::min<double>(n_pending, std::max<double>(fit, 4.0 * c->num_cus));
+    }
     // ---- forward pass with tier escalation ----------------------------------
     if (zero_counter(c, CT_ARENA)) return -1;
     uint32_t* cur = pending;
-    uint32_t n_cur = n_pending;
+    uint32_t n_cur = n_pass;
     uint32_t* spare[2] = {static_cast<uint32_t*>(c->list_a.p), static_cast<uint32_t*>(c->list_b.p)};
     int flip = 0;
     int max_score = max_error;
@@ -422,6 +434,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       // returning atomic on ONE word (~88 per microsecond on this chip), which at 4 KiB refills
       // was the whole kernel time
       if (compute_cigar) ap.chunk_units = (uint32_t)std::min<unsigned long long>(env_chunk ? (unsigned)atoi(env_chunk) : 4096u, std::max<unsigned long long>(256, ap.arena_units / (4ull * (unsigned)grid)));
+      { const char* es = getenv("WFAGPU_SHARDS"); ap.work_shards = es ? (uint32_t)atoi(es) : 8u; }
       if (zero_counter(c, CT_LIST)) return -1;
       HIP_TRY(hipMemsetAsync(c->work_ctr.p, 0, 8 * 64, st));
       HIP_TRY(hipEventRecord(c->ev_a0, st));
@@ -454,7 +467,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
     // ---- backtrace + CIGAR for everything that finished in this pass ---------
     if (zero_counter(c, CT_SUM_OPS, 2)) return -1;
     if (zero_counter(c, CT_OPS)) return -1;
-    hipLaunchKernelGGL(k_trace_bounds, dim3(std::min<uint32_t>(cdiv(n_pending, 256), 1024u)), dim3(256), 0, st, (const uint32_t*)pending, n_pending,
+    hipLaunchKernelGGL(k_trace_bounds, dim3(std::min<uint32_t>(cdiv(n_pass, 256), 1024u)), dim3(256), 0, st, (const uint32_t*)pending, n_pass,
                        static_cast<const uint32_t*>(c->status.p), (const int32_t*)d_scores,
                        static_cast<const uint32_t*>(c->cells.p), std::min(pen.x, pen.e), ct);
     if (read_counters(c)) return -1;
@@ -471,7 +484,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         const unsigned stride = (2 * per_seq) | 1u;
         tp.seq_lds_stride = ((size_t)64 * stride * 4 <= (48u << 10)) ? (int)stride : 0;
       }
-      tp.packed = ap.packed; tp.meta = ap.meta; tp.work = pending; tp.n_work = n_pending;
+      tp.packed = ap.packed; tp.meta = ap.meta; tp.work = pending; tp.n_work = n_pass;
       tp.x = pen.x; tp.oe = oe; tp.e = pen.e;
       tp.score = d_scores; tp.status = static_cast<const uint32_t*>(c->status.p);
       tp.arena = ap.arena; tp.bt_final_row = ap.bt_final_row;
@@ -488,7 +501,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
     if (zero_counter(c, CT_LIST)) return -1;
     uint32_t* nxt_pending = (pending == static_cast<uint32_t*>(c->list_c.p)) ? static_cast<uint32_t*>(c->list_d.p)
                                                                              : static_cast<uint32_t*>(c->list_c.p);
-    hipLaunchKernelGGL(k_compact, dim3(cdiv(n_pending, 256)), dim3(256), 0, st, (const uint32_t*)pending, n_pending,
+    hipLaunchKernelGGL(k_compact, dim3(cdiv(n_pass, 256)), dim3(256), 0, st, (const uint32_t*)pending, n_pass,
                        static_cast<const uint32_t*>(c->status.p), MASK(WFA_ST_NOMEM), nxt_pending, ct + CT_LIST);
     if (read_counters(c)) return -1;
     if (compute_cigar) {
@@ -511,12 +524,12 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         ap.arena = static_cast<uint8_t*>(c->arena.p);
         ap.arena_units = c->arena.cap / 16;
       }
-      if (n_nomem == n_pending && !can_grow) {
+      if (n_nomem == n_pass && !can_grow) {
         if (grid_cap == 1) {
           fprintf(stderr, "[!] ERROR: backtrace arena (%zu bytes) too small for one alignment\n", c->arena.cap);
           return -1;
         }
-        const uint32_t cur_cap = std::min<uint32_t>(grid_cap, std::min<uint32_t>(n_pending, (uint32_t)c->num_cus * 32u));
+        const uint32_t cur_cap = std::min<uint32_t>(grid_cap, std::min<uint32_t>(n_pass, (uint32_t)c->num_cus * 32u));
         grid_cap = std::max<uint32_t>(1u, cur_cap / 2);
       }
     }
@@ -526,7 +539,12 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
     }
     c->stats.arena_units = std::max<unsigned long long>(c->stats.arena_units, c->h_counters[CT_ARENA]);
     c->stats.cells = c->h_counters[CT_CELLS];
-    pending = nxt_pending; n_pending = n_nomem;
+    // refine the per-pair estimate from this pass, then queue what was not launched behind the re-runs
+    if (compute_cigar && n_pass > n_nomem)
+      est_pair_bytes = std::max(256.0, 1.15 * 16.0 * (double)c->h_counters[CT_ARENA] / (double)(n_pass - n_nomem));
+    if (n_pending > n_pass)
+      HIP_TRY(hipMemcpyAsync(nxt_pending + n_nomem, pending + n_pass, (size_t)4 * (n_pending - n_pass), hipMemcpyDeviceToDevice, st));
+    pending = nxt_pending; n_pending = n_nomem + (n_pending - n_pass);
   }
   }  // class loop
   HIP_TRY(hipEventRecord(c->ev_end, st));

@@ -99,6 +99,9 @@ int run_shard(const CallArgs& a, Shard& sh) {
   wfagpu_amd_ctx_t* ctx = nullptr;
   wfagpu_amd_config_t cfg{};
   cfg.device = sh.device;
+  // one-shot call: allocating device memory costs ~33 ms per GiB, so keep the backtrace arena small and
+  // let big batches run in several passes
+  cfg.arena_limit_bytes = (size_t)4 << 30;
   if (wfagpu_amd_create(&ctx, &cfg)) return -1;
   HIP_OK(hipSetDevice(sh.device));
   size_t bs = a.opt.batch_size ? a.opt.batch_size : (sh.to - sh.from);

@@ -119,3 +119,37 @@ def test_examples_run():
         assert line.endswith(f"score {s} cigar {cg}")
     subprocess.run([os.path.join(PKG, "examples", "tuned")], check=True, capture_output=True)
     subprocess.run([os.path.join(PKG, "examples", "quickstart-cpp")], check=True, capture_output=True)
+
+
+def test_cli_banded_is_valid(golden_dir, tmp_path):
+    """tests/test-fasta.sh style: -B auto (re-centre every 25 scores, band = -t) on the HiFi-shaped pairs; every
+    output line must be a valid alignment whose cost equals the printed score, never better than the optimum."""
+    out = tmp_path / "band.out"
+    _run_cli(["-i", os.path.join(golden_dir, "hifi.seq"), "-x", "-B", "auto", "-t", "512", "-e", "3000", "-o", str(out)])
+    pairs = wfagpu.read_seq_file(os.path.join(golden_dir, "hifi.seq"))
+    gs, _ = oracle_lib.read_alg(os.path.join(golden_dir, "hifi.g231.alg"))
+    lines = open(out).read().splitlines()
+    assert len(lines) == len(pairs)
+    for (p, t), line, opt in zip(pairs, lines, gs):
+        sc, cg = line.split("\t")
+        ok, cost = oracle_lib.check_cigar(p, t, cg, (2, 3, 1))
+        assert ok and cost == -int(sc) and cost >= opt
+
+
+def test_api_longest_supported_sequences():
+    """lib/aligner.c:139 of the reference: sequences up to 2^15 - 1 bases; offsets then do not fit the 16-bit LDS
+    tiers and the 32-bit HBM-ring tier takes the pair."""
+    import random
+    rng = random.Random(8)
+    t = bytes(rng.choice(b"ACGT") for _ in range(32767))
+    p = bytearray(t)
+    for _ in range(40):
+        p[rng.randrange(len(p))] = rng.choice(b"ACGT")
+    del p[1000:1003]
+    p = bytes(p) + b"ACG"
+    assert len(p) == 32767
+    pairs = [(p, t), (t[:200], t[:200]), (p[:5000], t[:5003])]
+    buf, meta = wfagpu.layout_pairs(pairs)
+    so, co, _ = oracle_lib.oracle_batch(buf, meta, (2, 3, 1), cigar=True, nthreads=4)
+    s, c = _api_align(pairs, (2, 3, 1), cigar=True, max_error=200)
+    assert np.array_equal(s, so) and c == co

@@ -384,10 +384,20 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
           }
         }
 
-        // ---- the cells of this score.  Straight-line per lane: no divergent branch inside, the
-        // only loop (extend) is wave-uniform.  Lanes past the end recompute cell `hi` (same values,
-        // same addresses), so no store needs an exec mask.
-        bool my_done = false, my_over = false;
+        // ---- the cells of this score.  Lanes past the end recompute cell `hi` (same values, same
+        // addresses), so no store needs an exec mask; the only inner loop (extend) is wave-uniform.
+        // The vector ALU is the unit this kernel saturates (one integer wave64 instruction holds its
+        // SIMD for 4 cycles), so everything uniform is folded into scalar row bases: each LDS address
+        // is one v_lshl_add of the diagonal.
+        const OffT* rb_mx = row_mx + (BANDED ? -base_mx : kidx0);          // [k]
+        const OffT* rb_mo = row_mo + (BANDED ? -base_mo : kidx0) - 1;      // [k] = k-1, [k+2] = k+1
+        const OffT* rb_ie = row_ie + (BANDED ? -base_e : kidx0) - 1;       // [k] = k-1
+        const OffT* rb_de = row_de + (BANDED ? -base_e : kidx0) + 1;       // [k] = k+1
+        OffT* wb_m = out_m + wbase;
+        OffT* wb_i = out_i + wbase;
+        OffT* wb_d = out_d + wbase;
+        uint8_t* cb = BT ? codes - lo : nullptr;
+        bool my_over = false;
         for (int k0 = lo; k0 <= hi; k0 += NT) {
           const int k = min(k0 + tid, hi);
           // recurrences (wavefront_compute_affine.c:66-84)
@@ -399,17 +409,17 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
             const bool in_or = !mo_null && (unsigned)(k + 1 - molo) <= (unsigned)(mohi - molo);
             const bool in_ie = !ie_null && (unsigned)(k - 1 - ielo) <= (unsigned)(iehi - ielo);
             const bool in_de = !de_null && (unsigned)(k + 1 - delo) <= (unsigned)(dehi - delo);
-            m_x = in_x ? (int)row_mx[k - base_mx] : OFF_NULL;
-            m_ol = in_ol ? (int)row_mo[k - 1 - base_mo] : OFF_NULL;
-            m_or = in_or ? (int)row_mo[k + 1 - base_mo] : OFF_NULL;
-            i_e = in_ie ? (int)row_ie[k - 1 - base_e] : OFF_NULL;
-            d_e = in_de ? (int)row_de[k + 1 - base_e] : OFF_NULL;
+            m_x = in_x ? (int)rb_mx[k] : OFF_NULL;
+            m_ol = in_ol ? (int)rb_mo[k] : OFF_NULL;
+            m_or = in_or ? (int)rb_mo[k + 2] : OFF_NULL;
+            i_e = in_ie ? (int)rb_ie[k] : OFF_NULL;
+            d_e = in_de ? (int)rb_de[k] : OFF_NULL;
           } else {
-            m_x = (int)row_mx[kidx0 + k];
-            m_ol = (int)row_mo[kidx0 + k - 1];
-            m_or = (int)row_mo[kidx0 + k + 1];
-            i_e = (int)row_ie[kidx0 + k - 1];
-            d_e = (int)row_de[kidx0 + k + 1];
+            m_x = (int)rb_mx[k];
+            m_ol = (int)rb_mo[k];
+            m_or = (int)rb_mo[k + 2];
+            i_e = (int)rb_ie[k];
+            d_e = (int)rb_de[k];
           }
           const int ins = max(m_ol, i_e) + 1;
           const int del = max(m_or, d_e);
@@ -432,28 +442,33 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
           // computed limits can stand in for the trimmed ones.
           my_over |= (ins > tlen) || (del - k > plen);
           // extend = longest common prefix from (v,h) (wavefront_extend.c:174-199), PER symbols per
-          // iteration; lanes that are done carry rem == 0 and idle along
-          int h = ok ? mv0 : 0;
-          {
+          // iteration, under the exec mask of the valid cells (scalar-unit work is cheap here); lanes
+          // that are done carry rem == 0 and idle along
+          int h = mv0;
+          if (ok) {
             constexpr int SH = RAW ? 2 : 4, PER = 1 << SH, BITS = RAW ? 3 : 1;
-            const int v = ok ? mv0 - k : 0;
-            int rem = ok ? min(plen - v, tlen - h) : 0;
+            const int v = mv0 - k;
+            int rem = min(plen - v, tlen - h);
             // word pointers and bit offsets are fixed for the whole run: a lane that goes on has
             // consumed exactly PER symbols = one word
-            const uint32_t* pp = Pw + (v >> SH);
-            const uint32_t* tp = Tw + (h >> SH);
+            const char* pp = reinterpret_cast<const char*>(Pw + (v >> SH));
+            const char* tp = reinterpret_cast<const char*>(Tw + (h >> SH));
             const uint32_t sa = (uint32_t)v << BITS, sb = (uint32_t)h << BITS;
             bool more;
             do {
-              const uint32_t a = __builtin_amdgcn_alignbit(pp[1], pp[0], sa);
-              const uint32_t b = __builtin_amdgcn_alignbit(tp[1], tp[0], sb);
+              const uint32_t* pw = reinterpret_cast<const uint32_t*>(pp);
+              const uint32_t* tw = reinterpret_cast<const uint32_t*>(tp);
+              const uint32_t a = __builtin_amdgcn_alignbit(pw[1], pw[0], sa);
+              const uint32_t b = __builtin_amdgcn_alignbit(tw[1], tw[0], sb);
               const uint32_t d = a ^ b;
-              const uint32_t eq = (d ? (uint32_t)__builtin_ctz(d) : 32u) >> BITS;   // equal symbols, PER if all
-              const int n = (int)min(eq, (uint32_t)rem);
+              // v_ffbl_b32 returns 0xFFFFFFFF for 0, so "all equal" falls out of the cap at PER
+              uint32_t fb;
+              asm("v_ffbl_b32 %0, %1" : "=v"(fb) : "v"(d));
+              const int n = (int)min(min(fb >> BITS, (uint32_t)PER), (uint32_t)rem);
               h += n;
               const bool full = n == PER;
               rem = full ? rem - PER : 0;
-              const int adv = full ? 1 : 0;
+              const int adv = full ? 4 : 0;
               pp += adv; tp += adv;
               more = rem > 0;
             } while (__builtin_amdgcn_ballot_w64(more) != 0ull);
@@ -461,25 +476,25 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
           const int mv = ok ? h : OFF_NULL;
           // M and D offsets never exceed the text length, so they fit 16 bits as they are; only an I
           // chain running past the text end keeps growing and is saturated by off_store
-          out_m[wbase + k] = (OffT)mv;
-          out_i[wbase + k] = off_store<OffT>(ins);
-          out_d[wbase + k] = (OffT)del;
-          if constexpr (BT) codes[(uint32_t)(k - lo)] = (uint8_t)code;
-          my_done |= (k == kend) && (mv >= tlen);
+          wb_m[k] = (OffT)mv;
+          wb_i[k] = off_store<OffT>(ins);
+          wb_d[k] = (OffT)del;
+          if constexpr (BT) cb[k] = (uint8_t)code;
         }
         bool any_over = false;
         {
-          const bool wave_done = __ballot(my_done) != 0ull;
           const bool wave_over = __ballot(my_over) != 0ull;
           if constexpr (NW == 1) {
-            done = wave_done; any_over = wave_over;
+            block_sync<NW>();
+            any_over = wave_over;
           } else {
             int* acc = red + 8 * (s % 3);
-            if (lane == 0 && (wave_done || wave_over)) atomicOr(&acc[6], (wave_done ? 1 : 0) | (wave_over ? 2 : 0));
+            if (lane == 0 && wave_over) atomicOr(&acc[6], 2);
             __syncthreads();
-            done = (acc[6] & 1) != 0;
             any_over = (acc[6] & 2) != 0;
           }
+          // termination (wavefront_extend.c:47-67): every lane reads the same cell
+          done = (kend >= lo && kend <= hi) && (int)wb_m[kend] >= tlen;
         }
         // Limits recorded for the row: the computed ones.  Cells that are not valid hold NULL or a
         // negative value, which is all a reader needs; only values past a sequence end need the

@@ -73,6 +73,19 @@ def pmc_traffic_bytes(workload):
     return int((2.0 * fetch + write) * 1024), os.path.relpath(files[-1], ROOT)
 
 
+def pmc_valu_insts(workload):
+    """SQ_INSTS_VALU of the dominant kernel from the same committed PMC summary (wave-instructions per launch)."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"{workload}_pmc_counters.csv")))
+    if not files:
+        return None
+    for r in csv.DictReader(open(files[-1])):
+        if "wfa_align_kernel" in r["kernel"] and r["counter"] == "SQ_INSTS_VALU":
+            return float(r["value"])
+    return None
+
+
 def usable_cores():
     """Host cores this process may really use: affinity mask capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -191,6 +204,15 @@ def main():
                     "cells_per_step": int(st.cells), "cells_per_s": round(st.cells / (acc["align_ms"] / args.steps * 1e-3), 1)
                     if acc["align_ms"] > 0 else None,
                     "note": "LDS-resident integer kernel: HBM fraction is low by construction, see DESIGN.md"}
+        valu = pmc_valu_insts(args.workload) if not args.pairs and not args.max_error else None
+        if valu and k_ms > 0:
+            # the unit this kernel saturates: integer wave64 VALU issue, 1 instruction per 4 cycles per SIMD
+            # (scratch/valu_rate.hip measures 4.04-4.17 cycles), 1024 SIMDs, 2.4 GHz max clock
+            peak = 1024 * 0.25 * 2.4e9 / 1e9
+            ach = valu / (k_ms * 1e-3) / 1e9
+            roofline["valu_issue"] = {"achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instr/s",
+                                      "frac": round(ach / peak, 3), "insts_per_launch": int(valu),
+                                      "source": "SQ_INSTS_VALU from the committed PMC pass of this command"}
         out = {
             "metric": "alignments_per_sec", "value": round(value, 1), "unit": "alignments/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

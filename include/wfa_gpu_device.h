@@ -55,6 +55,8 @@ typedef struct {
     unsigned int pairs_retried;        /* pairs that needed a wider tier                  */
     unsigned int pairs_raw;            /* pairs with bytes outside ACGT (byte-compare kernels) */
     unsigned int pairs_banded;         /* pairs finished by the adaptive-band kernels          */
+    unsigned int pairs_budget_missed;  /* pairs whose score exceeded the auto-tuned budget      */
+    int auto_budget;                   /* largest auto-tuned score budget of the call (0: off)  */
     unsigned int sub_batches;          /* arena-bounded passes                            */
     size_t lds_bytes_tier0;
     int blocks_per_cu_tier0;

@@ -237,3 +237,32 @@ def test_score_budget_window_is_exact(aligner, pen):
             else:
                 assert aligner.stats().pairs_retried == len(idx), (score, me)
         checked += 1
+
+
+def test_randomised_penalties_and_shapes(aligner):
+    """Stress: 24 random (x,o,e) triples x ragged pair sets (similar, unrelated, one-sided gaps, very different
+    lengths, homopolymers) x three max_error settings -- byte-identical scores and CIGARs vs the oracle.  Exercises the
+    exact-trimming slow path (values past a sequence end), null scores (all-even penalties), the score-budget window
+    with large |kend| and every escalation tier."""
+    rng = random.Random(77)
+    for it in range(24):
+        pen = (rng.randint(1, 9), rng.randint(0, 12), rng.randint(1, 6))
+        pairs = _rand_pairs(rng, 120, 150, err=rng.choice([0.02, 0.1, 0.3]))
+        pairs += [(bytes(rng.choice(b"ACGT") for _ in range(rng.randint(0, 90))),
+                   bytes(rng.choice(b"ACGT") for _ in range(rng.randint(0, 90)))) for _ in range(40)]        # unrelated
+        for _ in range(20):                                                                                      # one long gap
+            base = bytes(rng.choice(b"ACGT") for _ in range(rng.randint(40, 200)))
+            cut = rng.randint(0, len(base) // 2)
+            gap = rng.randint(1, len(base) // 2)
+            other = base[:cut] + base[cut + gap:]
+            pairs.append((base, other) if rng.random() < 0.5 else (other, base))
+        pairs += [(b"A" * rng.randint(1, 120), b"A" * rng.randint(1, 120)) for _ in range(10)]                  # homopolymers
+        pairs += [(b"AC" * rng.randint(1, 60), b"CA" * rng.randint(1, 60)) for _ in range(6)]
+        buf, meta = wfagpu.layout_pairs(pairs)
+        so, co, _ = oracle_lib.oracle_batch(buf, meta, pen, cigar=True, nthreads=8)
+        for max_error in (1, 40, 5000):
+            s, c = _run(aligner, buf, meta, pen, max_error=max_error)
+            assert np.array_equal(s, so), (pen, max_error)
+            assert c == co, (pen, max_error)
+        s2, _ = _run(aligner, buf, meta, pen, max_error=40, cigar=False)
+        assert np.array_equal(s2, so), pen

@@ -121,12 +121,14 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
   const int i_off = dm * rs, d_off = (dm + de) * rs;     // element offsets of the I and D rings
   uint32_t* Pw = reinterpret_cast<uint32_t*>(sp);
   uint32_t* Tw = Pw + p.seq_words_cap;
-  int* side = reinterpret_cast<int*>(Tw + p.seq_words_cap);   // [4][dm] trimmed I/D limits (rare)
-  int* red = side + 4 * dm;                                   // [3][8] per-score reduction slots (NW > 1)
+  const int bkm = p.book_mask;                                // row book: 64 (or more) entries indexed by score & bkm
+  const int sdm = p.side_mask;                                // side table: power of two >= dm entries, score & sdm
+  int* side = reinterpret_cast<int*>(Tw + p.seq_words_cap);   // [4][sdm+1] trimmed I/D limits (rare)
+  int* red = side + 4 * (sdm + 1);                            // [3][8] per-score reduction slots (NW > 1)
   uint32_t* bslot = reinterpret_cast<uint32_t*>(red + 24);    // [2] broadcast slots
   RowBook<NW> book;
   if constexpr (NW == 1) { book.a = ROW_NONE_A; book.b = (int)WFA_ROW_NONE; book.c = 0; book.A = book.B = book.C = nullptr; }
-  else { book.a = book.b = book.c = 0; book.A = reinterpret_cast<int*>(bslot + 2); book.B = book.A + dm; book.C = book.B + dm; }
+  else { book.a = book.b = book.c = 0; book.A = reinterpret_cast<int*>(bslot + 2); book.B = book.A + (bkm + 1); book.C = book.B + (bkm + 1); }
 
   uint32_t chunk_cur = 0, chunk_left = 0;   // arena units owned by this block
 
@@ -165,11 +167,15 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
     // a path that visits diagonal k beyond both 0 and kend needs one gap out and one gap back,
     // i.e. costs at least 2o + (|k| + |k - kend|) e, so cells outside the window cannot lie on any
     // path the backtrace can choose while the score stays within the limit.
+    // The budget may be per pair (host auto-tuning from a scored sample): smaller budget, narrower
+    // window, and -- below -- a wavefront that shrinks again once the score passes half the budget.
+    int budget = p.max_score;
+    if (p.budget) budget = min(budget, p.budget[pair]);
     int wlo = -plen, whi = tlen;
     bool feasible = true;
     if constexpr (!BANDED) {
-      if (p.max_score < INT_MAX / 2) {
-        const long long S = p.max_score, o = oe - e;
+      if (budget < INT_MAX / 2) {
+        const long long S = budget, o = oe - e;
         const int ak = kend < 0 ? -kend : kend;
         feasible = (ak ? o + (long long)ak * e : 0) <= S;
         const long long a_hi = S - 2 * o + (long long)kend * e, a_lo = S - 2 * o - (long long)kend * e;
@@ -202,7 +208,7 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
       }
       if constexpr (NW == 1) { book.a = ROW_NONE_A; book.b = (int)WFA_ROW_NONE; book.c = 0; }
       else {
-        for (int i = tid; i < dm; i += NT) { book.A[i] = ROW_NONE_A; book.B[i] = (int)WFA_ROW_NONE; book.C[i] = 0; }
+        for (int i = tid; i <= bkm; i += NT) { book.A[i] = ROW_NONE_A; book.B[i] = (int)WFA_ROW_NONE; book.C[i] = 0; }
         if (tid < 24) red[tid] = (tid & 7) == 6 ? 0 : (((tid & 7) & 1) ? INT_MIN : INT_MAX);
       }
       block_sync<NW>();
@@ -247,33 +253,50 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
       done = block_bcast<NW>(d0, bslot) != 0;
       block_sync<NW>();
 
-      int slot_m = 0, slot_e = 0;    // ring slots of score s
+      // Ring state of score s, all as element offsets that advance by one row per score (no multiply,
+      // no modulo in the loop): the M rows of s, s-x, s-(o+e) and the I/D rows of s, s-e.  The row book
+      // is indexed by (score & bkm); its entries for scores < 0 still hold the "no wavefront" reset value.
+      const int m_lim = dm * rs, e_lim = de * rs;
+      int off_m = 0, off_x = (dm - x) * rs, off_oe = (dm - oe) * rs, off_ec = 0, off_ep = (de - e) * rs;
       int hist_lo = 0, hist_hi = 0;  // widest limits so far (exact mode: bounds of the NULL guard cells)
+      // From a cell of score s on diagonal k the end is at least |k - kend| more gap bases away (an I or
+      // D cell may sit inside the gap that is already open, so no opening cost can be assumed), so within
+      // the budget only |k - kend| <= (budget - s) / e can still matter (exact, same argument as the
+      // window).  reach_q / reach_r track that quotient and remainder without a division per score.
+      const bool bounded = !BANDED && budget < INT_MAX / 2;
+      int reach_n = bounded ? budget : 0;                     // budget - s at s = 0
+      int reach_q = (bounded && reach_n >= 0) ? reach_n / e : 0;
+      int reach_r = (bounded && reach_n >= 0) ? reach_n - reach_q * e : 0;
       // ---- score loop ----------------------------------------------------------------------------
       while (!done && status == WFA_ST_DONE) {
         ++s;
-        if (s > p.max_score) { status = WFA_ST_SCORE; break; }
+        if (s > budget) { status = WFA_ST_SCORE; break; }
+        if (bounded) {
+          --reach_n;
+          if (reach_r == 0) { --reach_q; reach_r = e - 1; } else --reach_r;
+        }
         if constexpr (NW > 1) {
           // reduction slot of the NEXT score (nobody reads it any more: its readers passed barrier s-1)
           if (tid < 8) red[8 * ((s + 1) % 3) + tid] = (tid == 6) ? 0 : ((tid & 1) ? INT_MIN : INT_MAX);
         }
-        slot_m = (slot_m + 1 == dm) ? 0 : slot_m + 1;
-        slot_e = (slot_e + 1 == de) ? 0 : slot_e + 1;
+        off_m += rs;  if (off_m == m_lim) off_m = 0;
+        off_x += rs;  if (off_x == m_lim) off_x = 0;
+        off_oe += rs; if (off_oe == m_lim) off_oe = 0;
+        off_ec += rs; if (off_ec == e_lim) off_ec = 0;
+        off_ep += rs; if (off_ep == e_lim) off_ep = 0;
+        const int bk_s = s & bkm, bk_x = (s - x) & bkm, bk_oe = (s - oe) & bkm, bk_e = (s - e) & bkm;
         // predecessor rows: s-x and s-(o+e) of M, s-e of I and D
-        int sl_x = slot_m - x;   if (sl_x < 0) sl_x += dm;
-        int sl_oe = slot_m - oe; if (sl_oe < 0) sl_oe += dm;
-        int sl_me = slot_m - e;  if (sl_me < 0) sl_me += dm;   // M-ring slot of score s-e (bookkeeping)
-        int sl_e = slot_e - e;   if (sl_e < 0) sl_e += de;     // I/D-ring slot of score s-e (data)
-        const int a_x = (s >= x) ? book.get_a(sl_x) : ROW_NONE_A;
-        const int a_oe = (s >= oe) ? book.get_a(sl_oe) : ROW_NONE_A;
-        const int a_e = (s >= e) ? book.get_a(sl_me) : ROW_NONE_A;
-        const int c_e = (s >= e) ? book.get_c(sl_me) : 0;
+        const int a_x = book.get_a(bk_x);
+        const int a_oe = book.get_a(bk_oe);
+        const int a_e = book.get_a(bk_e);
+        const int c_e = book.get_c(bk_e);
         const int mxlo = range_lo(a_x), mxhi = range_hi(a_x), molo = range_lo(a_oe), mohi = range_hi(a_oe);
         int ielo = 1, iehi = -1, delo = 1, dehi = -1;
         if (c_e & 1) { ielo = range_lo(a_e); iehi = range_hi(a_e); }
         if (c_e & 2) { delo = range_lo(a_e); dehi = range_hi(a_e); }
         if (c_e & 4) {   // trimmed limits (some value ran past a sequence end at that score)
-          ielo = side[sl_me]; iehi = side[dm + sl_me]; delo = side[2 * dm + sl_me]; dehi = side[3 * dm + sl_me];
+          const int se = (s - e) & sdm;
+          ielo = side[se]; iehi = side[(sdm + 1) + se]; delo = side[2 * (sdm + 1) + se]; dehi = side[3 * (sdm + 1) + se];
         }
         const bool mx_null = mxlo > mxhi, mo_null = molo > mohi, ie_null = ielo > iehi, de_null = delo > dehi;
         // limits (wavefront_compute.c:41-71; null rows carry lo=1, hi=-1)
@@ -281,13 +304,19 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
         lo = min(lo, molo - 1); hi = max(hi, mohi + 1);
         lo = min(lo, ielo + 1); hi = max(hi, iehi + 1);
         lo = min(lo, delo - 1); hi = max(hi, dehi - 1);
-        if constexpr (!BANDED) { lo = max(lo, wlo); hi = min(hi, whi); }
-        OffT* out_m = Mr + (size_t)slot_m * rs;
-        OffT* out_i = Mr + (size_t)(i_off + slot_e * rs);
-        OffT* out_d = Mr + (size_t)(d_off + slot_e * rs);
+        if constexpr (!BANDED) {
+          lo = max(lo, wlo); hi = min(hi, whi);
+          if (bounded) {
+            const int reach = reach_n >= 0 ? reach_q : 0;
+            lo = max(lo, kend - reach); hi = min(hi, kend + reach);
+          }
+        }
+        OffT* out_m = Mr + off_m;
+        OffT* out_i = Mr + (i_off + off_ec);
+        OffT* out_d = Mr + (d_off + off_ec);
         if ((mx_null && mo_null && ie_null && de_null) || lo > hi) {
           // no wavefront at this score (wavefront_compute_affine.c:236-243)
-          book.set(slot_m, ROW_NONE_A, (int)WFA_ROW_NONE, 0);
+          book.set(bk_s, ROW_NONE_A, (int)WFA_ROW_NONE, 0);
           if constexpr (!BANDED) {
             const int f0 = max(wlo - 1, hist_lo - dm), f1 = min(whi + 1, hist_hi + dm);
             for (int q = f0 + tid; q <= f1; q += NT) {
@@ -308,7 +337,7 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
           if (excess > 0) {
             bool recentred = false;
             if (!mx_null && (s % p.band_period) == 0) {
-              const OffT* rowc = Mr + (size_t)sl_x * rs;
+              const OffT* rowc = Mr + off_x;
               uint32_t best = 0xFFFFFFFFu;
               for (int kk = mxlo + tid; kk <= mxhi; kk += NT) {
                 const int off = (int)rowc[kk - mxlo];
@@ -359,17 +388,17 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
             chunk_cur = base; chunk_left = grab;
           }
           row_s = chunk_cur; chunk_cur += need; chunk_left -= need;
-          const uint32_t r_x = (s >= x) ? (uint32_t)book.get_b(sl_x) : WFA_ROW_NONE;
-          const uint32_t r_oe = (s >= oe) ? (uint32_t)book.get_b(sl_oe) : WFA_ROW_NONE;
-          const uint32_t r_e = (s >= e) ? (uint32_t)book.get_b(sl_me) : WFA_ROW_NONE;
+          const uint32_t r_x = (uint32_t)book.get_b(bk_x);
+          const uint32_t r_oe = (uint32_t)book.get_b(bk_oe);
+          const uint32_t r_e = (uint32_t)book.get_b(bk_e);
           if (tid == 0) *reinterpret_cast<uint4*>(p.arena + (size_t)row_s * 16) = make_uint4((uint32_t)lo, r_x, r_oe, r_e);
           codes = p.arena + (size_t)row_s * 16 + 16;
         }
 
-        const OffT* row_mx = Mr + (size_t)sl_x * rs;
-        const OffT* row_mo = Mr + (size_t)sl_oe * rs;
-        const OffT* row_ie = Mr + (size_t)(i_off + sl_e * rs);
-        const OffT* row_de = Mr + (size_t)(d_off + sl_e * rs);
+        const OffT* row_mx = Mr + off_x;
+        const OffT* row_mo = Mr + off_oe;
+        const OffT* row_ie = Mr + (i_off + off_ep);
+        const OffT* row_de = Mr + (d_off + off_ep);
         const int wbase = BANDED ? -lo : kidx0;   // index of diagonal 0 in the rows written now
 
         if constexpr (!BANDED) {
@@ -528,7 +557,8 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
           if (r[0] > r[1]) { r[0] = 1; r[1] = -1; }
           if (r[2] > r[3]) { r[2] = 1; r[3] = -1; }
           // every thread stores the same values and later reads its own copy back
-          side[slot_m] = r[0]; side[dm + slot_m] = r[1]; side[2 * dm + slot_m] = r[2]; side[3 * dm + slot_m] = r[3];
+          const int ss = s & sdm;
+          side[ss] = r[0]; side[(sdm + 1) + ss] = r[1]; side[2 * (sdm + 1) + ss] = r[2]; side[3 * (sdm + 1) + ss] = r[3];
           cflags = 7;
           if constexpr (!BANDED) {
             // trimmed-away cells read as NULL from now on (wavefront_compute.c:480-520)
@@ -539,7 +569,7 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
             if constexpr (NW > 1) __syncthreads();
           }
         }
-        book.set(slot_m, pack_range(lo, hi), (int)row_s, cflags);
+        book.set(bk_s, pack_range(lo, hi), (int)row_s, cflags);
         if constexpr (NW == 1) block_sync<NW>();
       }
       if (tid == 0 && status == WFA_ST_DONE) {
@@ -620,8 +650,9 @@ size_t wfa_align_lds_bytes(const WfaAlignParams& p, int tier) {
   size_t ring = 0;
   if (tier != 3) ring = (((size_t)(p.dm + 2 * p.de) * p.rs * sizeof(int16_t)) + 15) & ~(size_t)15;
   const size_t seq = (size_t)2 * p.seq_words_cap * 4;
-  // side table [4][dm] + reduction slots [24] + broadcast [2] + (NW > 1) row book [3][dm]
-  const size_t meta = (size_t)(4 * p.dm + 24 + 2 + (tier == 0 ? 0 : 3 * p.dm)) * 4;
+  // side table [4][book] + reduction slots [24] + broadcast [2] + (NW > 1) row book [3][book]
+  const size_t bk = (size_t)p.book_mask + 1;
+  const size_t meta = (size_t)(4 * ((size_t)p.side_mask + 1) + 24 + 2 + (tier == 0 ? 0 : 3 * bk)) * 4;
   return ((ring + seq + meta) + 15) & ~(size_t)15;
 }
 

@@ -62,8 +62,11 @@ struct WfaAlignParams {
   uint32_t work_shards;          // 1 or 8 of them in use
   int x, oe, e;                  // penalties: mismatch, open+extend, extend
   int dm, de;                    // ring depths: max(x,oe)+1 rows of M, e+1 rows of I and D
+  int book_mask;                 // row-book entries - 1 (power of two >= max(dm, 64))
+  int side_mask;                 // side-table entries - 1 (power of two >= dm)
   int rs;                        // row stride (elements), even: widest diagonal window + 3
   int max_score;                 // give up (WFA_ST_SCORE) beyond this score
+  const int32_t* budget;         // optional per-pair score budget (auto-tuned), capped by max_score
   int band_width;                // > 0: adaptive band, diagonals kept per wavefront (banded kernels)
   int band_period;               //      re-centre the band every this many scores
   int seq_words_cap;             // LDS words reserved per packed sequence

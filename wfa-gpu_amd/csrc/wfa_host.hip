@@ -126,6 +126,33 @@ __global__ void __launch_bounds__(256) k_trace_bounds(const uint32_t* __restrict
   }
 }
 
+// every stride-th pair whose status is in `mask` -> sample list
+__global__ void k_sample(const uint32_t* __restrict__ status, uint32_t n_s, uint32_t stride, uint32_t mask,
+                         uint32_t* __restrict__ out, unsigned long long* __restrict__ out_count) {
+  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n_s) return;
+  const uint32_t pair = gid * stride;
+  if ((mask >> status[pair]) & 1u) out[atomicAdd(out_count, 1ull)] = pair;
+}
+
+// score per 1024 bases of the longer sequence (INT_MAX for pairs that did not finish)
+__global__ void k_ratio(const uint32_t* __restrict__ list, uint32_t n, const uint32_t* __restrict__ status,
+                        const int32_t* __restrict__ score, const WfaSeqPair* __restrict__ meta, int32_t* __restrict__ out) {
+  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n) return;
+  const uint32_t pair = list[gid];
+  const unsigned len = max(1u, max(meta[pair].pattern_len, meta[pair].text_len));
+  out[gid] = (status[pair] == WFA_ST_DONE) ? (int32_t)(((long long)score[pair] * 1024 + len - 1) / len) : INT_MAX;
+}
+
+// per-pair budget = 1.02 * q/1024 * length + slack
+__global__ void k_budget(const WfaSeqPair* __restrict__ meta, uint32_t n, int q, int slack, int32_t* __restrict__ out) {
+  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n) return;
+  const unsigned len = max(meta[gid].pattern_len, meta[gid].text_len);
+  out[gid] = (int32_t)min(0x3FFFFFFFll, ((long long)q * len * 102 / 100) / 1024 + slack);
+}
+
 __global__ void k_set_pending(const uint32_t* __restrict__ work, uint32_t n, uint32_t* __restrict__ status) {
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
   if (gid < n) status[work ? work[gid] : gid] = WFA_ST_PENDING;
@@ -142,7 +169,7 @@ struct wfagpu_amd_ctx {
   int num_cus = 0;
   size_t lds_per_block_max = 0;
   size_t arena_cfg = 0, text_cfg = 0, arena_limit = 0;
-  DevBuf packed, flags, status, cells, bt_final, list_a, list_b, list_c, list_d, work_ctr, counters, arena, ops, text, cig_off, cig_len, gring;
+  DevBuf packed, flags, status, cells, bt_final, list_a, list_b, list_c, list_d, work_ctr, sample, ratio, budget, counters, arena, ops, text, cig_off, cig_len, gring;
   unsigned long long* h_counters = nullptr;  // pinned
   hipEvent_t ev_start = nullptr, ev_pack = nullptr, ev_a0 = nullptr, ev_a1 = nullptr, ev_t0 = nullptr, ev_t1 = nullptr, ev_end = nullptr;
   wfagpu_amd_stats_t stats{};
@@ -190,7 +217,7 @@ void wfagpu_amd_destroy(wfagpu_amd_ctx_t* c) {
   if (!c) return;
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
-  for (DevBuf* b : {&c->packed, &c->flags, &c->status, &c->cells, &c->bt_final, &c->list_a, &c->list_b, &c->list_c, &c->list_d, &c->work_ctr,
+  for (DevBuf* b : {&c->packed, &c->flags, &c->status, &c->cells, &c->bt_final, &c->list_a, &c->list_b, &c->list_c, &c->list_d, &c->work_ctr, &c->sample, &c->ratio, &c->budget,
                     &c->counters, &c->arena, &c->ops, &c->text, &c->cig_off, &c->cig_len, &c->gring})
     b->release();
   if (c->h_counters) hipHostFree(c->h_counters);
@@ -334,6 +361,8 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   ap.x = pen.x; ap.oe = oe; ap.e = pen.e;
   ap.dm = std::max(pen.x, oe) + 1;
   ap.de = pen.e + 1;
+  { int bk = 64; while (bk < ap.dm) bk <<= 1; ap.book_mask = bk - 1; }
+  { int sd = 1; while (sd < ap.dm) sd <<= 1; ap.side_mask = sd - 1; }
   ap.seq_words_cap = (int)((max_len + 15) / 16 + 1);
   ap.score = d_scores;
   ap.status = static_cast<uint32_t*>(c->status.p);
@@ -379,22 +408,15 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   unsigned long long text_used = 0;
   int rc = 0;
 
-  // two classes of pairs: ACGT-only (2-bit packed kernels) and the rest (byte-compare kernels)
-  for (int cls = 0; cls < 2; ++cls) {
-  const bool raw = cls == 1;
-  if (zero_counter(c, CT_LIST)) return -1;
-  uint32_t* pending = static_cast<uint32_t*>(c->list_c.p);
-  hipLaunchKernelGGL(k_compact, dim3(cdiv(n, 256)), dim3(256), 0, st, (const uint32_t*)nullptr, n,
-                     static_cast<const uint32_t*>(c->status.p), raw ? MASK(WFA_ST_ALPHABET) : MASK(WFA_ST_PENDING), pending,
-                     ct + CT_LIST);
-  if (read_counters(c)) return -1;
-  uint32_t n_pending = (uint32_t)c->h_counters[CT_LIST];
-  if (raw) {
-    c->stats.pairs_raw = n_pending;
-    ap.packed = reinterpret_cast<const uint32_t*>(b->d_sequences);
-    ap.seq_words_cap = (int)((max_len + 3) / 4 + 1);
-  }
+  // Runs one list of pairs to completion: passes bounded by the arena, tier escalation inside a pass,
+  // backtrace + CIGAR text for what finished.  `budgets` (optional, per pair) is tried first.
+  auto run_list = [&](uint32_t* pending, uint32_t n_pending, const bool raw, const int32_t* budgets, const int budget_cap) -> int {
   grid_cap = UINT32_MAX;
+  if (budgets) {
+    // tight budgets make the wavefront a diamond: at most half the budget square of origin bytes
+    const double B = budget_cap;
+    est_pair_bytes = 0.5 * (B + 1) * (B + 1) + 16.0 * B + 2048.0;
+  }
   while (n_pending > 0) {
     c->stats.sub_batches++;
     // pairs launched in this pass: what the arena is expected to hold (at least one wave of workgroups)
@@ -409,11 +431,13 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
     uint32_t n_cur = n_pass;
     uint32_t* spare[2] = {static_cast<uint32_t*>(c->list_a.p), static_cast<uint32_t*>(c->list_b.p)};
     int flip = 0;
-    int max_score = max_error;
+    int max_score = budgets ? std::min(budget_cap, max_error) : max_error;
+    bool budget_round = budgets != nullptr;
     for (int round = 0; n_cur > 0; ++round) {
       TierPlan tp;
+      ap.budget = budget_round ? budgets : nullptr;
       // banded first attempt (packed class only); whatever it cannot finish goes to the exact tiers
-      ap.band_width = (want_band && !raw && round == 0) ? band_width : 0;
+      ap.band_width = (want_band && !raw && round == 0 && !budgets) ? band_width : 0;
       ap.band_period = band;
       if (ap.band_width > 0 && !plan_tier(c, ap, std::min(max_score, 30000), max_len, compute_cigar, raw, &tp)) ap.band_width = 0;
       if (ap.band_width > 0) c->stats.pairs_banded += n_cur;
@@ -427,7 +451,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         if (c->gring.ensure(stride * grid, st)) return -1;
         ap.gring = c->gring.p; ap.gring_stride = stride;
       }
-      if (round == 0 && c->stats.sub_batches == 1) { c->stats.lds_bytes_tier0 = tp.lds; c->stats.blocks_per_cu_tier0 = tp.blocks_per_cu; }
+      if (round == 0) { c->stats.lds_bytes_tier0 = tp.lds; c->stats.blocks_per_cu_tier0 = tp.blocks_per_cu; }
       ap.work = cur; ap.n_work = n_cur;
       const int grid = (int)std::min<uint32_t>(std::min<uint32_t>(n_cur, grid_cap), (uint32_t)(c->num_cus * tp.blocks_per_cu));
       // arena refill size: as large as lets every workgroup hold a few chunks -- each refill is a
@@ -459,6 +483,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       }
       cur = nxt; n_cur = n_next;
       if (ap.band_width > 0) { c->stats.pairs_banded -= n_next; continue; }   // banded misses: exact tiers from the start
+      if (budget_round) { budget_round = false; max_score = max_error; c->stats.pairs_budget_missed += n_next; continue; }   // auto-budget misses: the caller's budget
       // widen: 4x the score budget (and with it the diagonal window); beyond what 16-bit offsets
       // allow the last resort is the unbounded 32-bit tier
       if (max_score >= 30000 || max_len > 32766u) max_score = INT_MAX;
@@ -540,12 +565,70 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
     c->stats.arena_units = std::max<unsigned long long>(c->stats.arena_units, c->h_counters[CT_ARENA]);
     c->stats.cells = c->h_counters[CT_CELLS];
     // refine the per-pair estimate from this pass, then queue what was not launched behind the re-runs
-    if (compute_cigar && n_pass > n_nomem)
+    if (compute_cigar && n_pass - n_nomem >= 65536u)   // (few pairs per workgroup: refill slack would dominate)
       est_pair_bytes = std::max(256.0, 1.15 * 16.0 * (double)c->h_counters[CT_ARENA] / (double)(n_pass - n_nomem));
     if (n_pending > n_pass)
       HIP_TRY(hipMemcpyAsync(nxt_pending + n_nomem, pending + n_pass, (size_t)4 * (n_pending - n_pass), hipMemcpyDeviceToDevice, st));
     pending = nxt_pending; n_pending = n_nomem + (n_pending - n_pass);
   }
+  return 0;
+  };
+
+  // two classes of pairs: ACGT-only (2-bit packed kernels) and the rest (byte-compare kernels)
+  for (int cls = 0; cls < 2; ++cls) {
+  const bool raw = cls == 1;
+  if (raw) {
+    ap.packed = reinterpret_cast<const uint32_t*>(b->d_sequences);
+    ap.seq_words_cap = (int)((max_len + 3) / 4 + 1);
+  }
+  const uint32_t class_mask = raw ? MASK(WFA_ST_ALPHABET) : MASK(WFA_ST_PENDING);
+  // ---- auto-tuned score budgets -----------------------------------------
+  // max_error is a ceiling the caller guesses (the CLI default is 10 % of the length times the largest
+  // penalty); the scores of a batch usually sit far below it.  A strided sample is aligned with the
+  // caller's budget, the 98th percentile of score/length sets a per-pair budget for everyone else, and
+  // whoever exceeds it is re-run with the caller's budget.  Results are exact either way; a tight
+  // budget halves both the LDS ring and the number of wavefront cells (the wavefront becomes a diamond).
+  const int32_t* budgets = nullptr;
+  int budget_cap = max_error;
+  const bool try_budget = !raw && !want_band && n >= 16384 && !getenv("WFAGPU_NO_AUTOBUDGET") &&
+                          window_width(max_error, pen.o, pen.e, max_len) > 128;
+  if (try_budget) {
+    const uint32_t n_s = 4096, stride_s = n / n_s;
+    if (c->sample.ensure((size_t)4 * n_s, st)) return -1;
+    if (c->ratio.ensure((size_t)4 * n_s, st)) return -1;
+    if (c->budget.ensure((size_t)4 * n, st)) return -1;
+    if (zero_counter(c, CT_LIST)) return -1;
+    hipLaunchKernelGGL(k_sample, dim3(cdiv(n_s, 256)), dim3(256), 0, st, static_cast<const uint32_t*>(c->status.p), n_s, stride_s,
+                       class_mask, static_cast<uint32_t*>(c->sample.p), ct + CT_LIST);
+    if (read_counters(c)) return -1;
+    const uint32_t got = (uint32_t)c->h_counters[CT_LIST];
+    if (got >= 256) {
+      if (run_list(static_cast<uint32_t*>(c->sample.p), got, raw, nullptr, max_error)) return -1;
+      hipLaunchKernelGGL(k_ratio, dim3(cdiv(got, 256)), dim3(256), 0, st, static_cast<const uint32_t*>(c->sample.p), got,
+                         static_cast<const uint32_t*>(c->status.p), (const int32_t*)d_scores, ap.meta, static_cast<int32_t*>(c->ratio.p));
+      std::vector<int32_t> hr(got);
+      HIP_TRY(hipMemcpyAsync(hr.data(), c->ratio.p, (size_t)4 * got, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      std::sort(hr.begin(), hr.end());
+      const size_t valid = std::lower_bound(hr.begin(), hr.end(), INT_MAX) - hr.begin();
+      if (valid >= got / 2) {
+        const int q = hr[std::min(valid - 1, (size_t)(0.98 * valid))];      // score per 1024 bases
+        const int slack = pen.o + pen.e + pen.x + 2;
+        hipLaunchKernelGGL(k_budget, dim3(cdiv(n, 256)), dim3(256), 0, st, ap.meta, n, q, slack, static_cast<int32_t*>(c->budget.p));
+        budgets = static_cast<const int32_t*>(c->budget.p);
+        budget_cap = (int)std::min<long long>(max_error, ((long long)q * max_len * 102 / 100) / 1024 + slack);
+        c->stats.auto_budget = budget_cap;
+      }
+    }
+  }
+  if (zero_counter(c, CT_LIST)) return -1;
+  uint32_t* pending = static_cast<uint32_t*>(c->list_c.p);
+  hipLaunchKernelGGL(k_compact, dim3(cdiv(n, 256)), dim3(256), 0, st, (const uint32_t*)nullptr, n,
+                     static_cast<const uint32_t*>(c->status.p), class_mask, pending, ct + CT_LIST);
+  if (read_counters(c)) return -1;
+  const uint32_t n_pending = (uint32_t)c->h_counters[CT_LIST];
+  if (raw) c->stats.pairs_raw = n_pending;
+  if (run_list(pending, n_pending, raw, budgets, budget_cap)) return -1;
   }  // class loop
   HIP_TRY(hipEventRecord(c->ev_end, st));
   HIP_TRY(hipStreamSynchronize(st));

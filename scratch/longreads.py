@@ -3,7 +3,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "wfa-gpu_amd", "bindings")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch, wfagpu, oracle_lib
 al = wfagpu.DeviceAligner(0)
-for tag, n, L, err, e, cig, nchk in (("cfg4-10k-3%", 4096, 10000, 0.03, 3000, True, 8), ("cfg4-10k-3% score", 4096, 10000, 0.03, 3000, False, 8),
+for tag, n, L, err, e, cig, nchk in (("cfg4-10k-3%", 16384, 10000, 0.03, 3000, True, 8), ("cfg4-10k-3% score", 16384, 10000, 0.03, 3000, False, 8),
                                     ("cfg5-30k-10%", 256, 30000, 0.10, 9000, True, 2), ("cfg5-30k-10% score", 256, 30000, 0.10, 9000, False, 2),
                                     ("10k-3% e=1000", 4096, 10000, 0.03, 1000, True, 0)):
     buf, meta = wfagpu.generate_pairs(n, L, err, seed=5)

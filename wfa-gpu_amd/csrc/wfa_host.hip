@@ -590,10 +590,10 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   // budget halves both the LDS ring and the number of wavefront cells (the wavefront becomes a diamond).
   const int32_t* budgets = nullptr;
   int budget_cap = max_error;
-  const bool try_budget = !raw && !want_band && n >= 16384 && !getenv("WFAGPU_NO_AUTOBUDGET") &&
+  const bool try_budget = !raw && !want_band && n >= 8192 && !getenv("WFAGPU_NO_AUTOBUDGET") &&
                           window_width(max_error, pen.o, pen.e, max_len) > 128;
   if (try_budget) {
-    const uint32_t n_s = 4096, stride_s = n / n_s;
+    const uint32_t n_s = std::min<uint32_t>(4096u, std::max<uint32_t>(512u, n / 16u)), stride_s = n / n_s;
     if (c->sample.ensure((size_t)4 * n_s, st)) return -1;
     if (c->ratio.ensure((size_t)4 * n_s, st)) return -1;
     if (c->budget.ensure((size_t)4 * n, st)) return -1;
@@ -602,7 +602,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
                        class_mask, static_cast<uint32_t*>(c->sample.p), ct + CT_LIST);
     if (read_counters(c)) return -1;
     const uint32_t got = (uint32_t)c->h_counters[CT_LIST];
-    if (got >= 256) {
+    if (got >= n_s / 2) {
       if (run_list(static_cast<uint32_t*>(c->sample.p), got, raw, nullptr, max_error)) return -1;
       hipLaunchKernelGGL(k_ratio, dim3(cdiv(got, 256)), dim3(256), 0, st, static_cast<const uint32_t*>(c->sample.p), got,
                          static_cast<const uint32_t*>(c->status.p), (const int32_t*)d_scores, ap.meta, static_cast<int32_t*>(c->ratio.p));

@@ -52,38 +52,40 @@ def algorithmic_bytes(meta, cells, cigar_bytes, compute_cigar):
     return total, kernel
 
 
-def pmc_traffic_bytes(workload):
-    """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary of this same
-    command (profiles/rNN/<workload>_pmc_counters.csv; separate --pmc passes).  (FETCH_SIZE*2 + WRITE_SIZE) KB:
-    FETCH_SIZE counts half of a wide coalesced read on gfx950 (MI355X_MICROARCH.md, HBM section).  None if absent."""
+def _pmc_per_launch(workload, counters):
+    """Per-launch averages of `counters` for wfa_align_kernel from the newest committed rocprofv3 PMC summary of this
+    same command (profiles/rNN/<workload>_pmc_counters.csv; separate --pmc passes over one step).  A step launches
+    the kernel several times (sample, main, retries): values are summed over the launches of the pass and divided
+    by their number, the same averaging as `kernel_ms_avg`."""
     import csv
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"{workload}_pmc_counters.csv")))
     if not files:
         return None, None
-    fetch = write = None
+    tot = {c: 0.0 for c in counters}
+    cnt = {c: 0 for c in counters}
     for r in csv.DictReader(open(files[-1])):
-        if "wfa_align_kernel" in r["kernel"]:
-            if r["counter"] == "FETCH_SIZE":
-                fetch = float(r["value"])
-            elif r["counter"] == "WRITE_SIZE":
-                write = float(r["value"])
-    if fetch is None or write is None:
+        if "wfa_align_kernel" in r["kernel"] and r["counter"] in tot:
+            tot[r["counter"]] += float(r["value"])
+            cnt[r["counter"]] += 1
+    if any(cnt[c] == 0 for c in counters):
         return None, None
-    return int((2.0 * fetch + write) * 1024), os.path.relpath(files[-1], ROOT)
+    return {c: tot[c] / cnt[c] for c in counters}, os.path.relpath(files[-1], ROOT)
+
+
+def pmc_traffic_bytes(workload):
+    """HBM bytes per launch of the dominant kernel: (FETCH_SIZE*2 + WRITE_SIZE) KB -- FETCH_SIZE counts half of a
+    wide coalesced read on gfx950 (MI355X_MICROARCH.md, HBM section).  None if no summary is committed."""
+    v, src = _pmc_per_launch(workload, ["FETCH_SIZE", "WRITE_SIZE"])
+    if v is None:
+        return None, None
+    return int((2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024), src
 
 
 def pmc_valu_insts(workload):
     """SQ_INSTS_VALU of the dominant kernel from the same committed PMC summary (wave-instructions per launch)."""
-    import csv
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"{workload}_pmc_counters.csv")))
-    if not files:
-        return None
-    for r in csv.DictReader(open(files[-1])):
-        if "wfa_align_kernel" in r["kernel"] and r["counter"] == "SQ_INSTS_VALU":
-            return float(r["value"])
-    return None
+    v, _ = _pmc_per_launch(workload, ["SQ_INSTS_VALU"])
+    return None if v is None else v["SQ_INSTS_VALU"]
 
 
 def usable_cores():

@@ -12,13 +12,13 @@ for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU 
 done
 cd $R
 python3 - <<PY
-import csv,glob
+import csv,glob,re
 rows=[]
 for f in sorted(glob.glob('$O/pmc/*/pmc_counter_collection.csv')):
     for r in csv.DictReader(open(f)):
         kn=r['Kernel_Name']
         if 'wfa_' in kn:
-            k=kn.split('(')[0].replace('void (anonymous namespace)::','').replace('(anonymous namespace)::','')
+            k=re.search(r'wfa_\\w+(<[^>]*>)?',kn).group(0)
             rows.append((k,r['Counter_Name'],r['Counter_Value'],(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e6,r['Grid_Size'],r['Workgroup_Size'],r['VGPR_Count'],r['SGPR_Count']))
 with open('$O/pmc_counters.csv','w') as f:
     w=csv.writer(f); w.writerow(['kernel','counter','value','kernel_ms_under_pmc','grid','wg','vgpr','sgpr'])

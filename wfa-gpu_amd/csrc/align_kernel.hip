@@ -72,33 +72,47 @@ template <int NW> __device__ __forceinline__ uint32_t block_bcast(uint32_t v, ui
   }
 }
 
-// Per-row bookkeeping of the ring, indexed by M-ring slot:
-//   A = limits of the row, lo in the low and hi in the high 16 bits (lo > hi: no wavefront)
-//   B = arena unit of the row's backtrace record
-//   C = bit 0: I row exists, bit 1: D row exists, bit 2: their limits were trimmed (then they are
-//       in the LDS side table)
-// NW == 1 keeps A, B, C in one VGPR each (lane = slot): reading is one v_readlane, no LDS round trip.
+// Per-score bookkeeping of the ring, indexed by (score & book_mask):
+//   A    = limits of the row as computed, lo in the low and hi in the high 16 bits (lo > hi: no wavefront)
+//   I, D = limits of the I and D components (the computed ones, or the trimmed ones when a value ran
+//          past a sequence end; lo = 1, hi = -1 when the component does not exist)
+//   B    = arena unit of the row's backtrace record
+// NW == 1 keeps each in one VGPR (lane = slot): reading is one v_readlane, no LDS round trip, and
+// everything derived from it stays on the scalar unit.
 constexpr int ROW_NONE_A = (int)0xFFFF0001u;   // lo = 1, hi = -1
 __device__ __forceinline__ int pack_range(int lo, int hi) { return (lo & 0xFFFF) | (int)((unsigned)hi << 16); }
 __device__ __forceinline__ int range_lo(int a) { return (int)(int16_t)(a & 0xFFFF); }
 __device__ __forceinline__ int range_hi(int a) { return a >> 16; }
 
 template <int NW> struct RowBook {
-  int a, b, c;          // NW == 1
-  int *A, *B, *C;       // NW > 1 (LDS)
+  int a, i, d, b;       // NW == 1
+  int *A, *I, *D, *B;   // NW > 1 (LDS)
   __device__ __forceinline__ int get_a(int slot) const { if constexpr (NW == 1) return __builtin_amdgcn_readlane(a, slot); else return A[slot]; }
+  __device__ __forceinline__ int get_i(int slot) const { if constexpr (NW == 1) return __builtin_amdgcn_readlane(i, slot); else return I[slot]; }
+  __device__ __forceinline__ int get_d(int slot) const { if constexpr (NW == 1) return __builtin_amdgcn_readlane(d, slot); else return D[slot]; }
   __device__ __forceinline__ int get_b(int slot) const { if constexpr (NW == 1) return __builtin_amdgcn_readlane(b, slot); else return B[slot]; }
-  __device__ __forceinline__ int get_c(int slot) const { if constexpr (NW == 1) return __builtin_amdgcn_readlane(c, slot); else return C[slot]; }
+  __device__ __forceinline__ void reset() { a = i = d = ROW_NONE_A; b = (int)WFA_ROW_NONE; }
   // every thread calls set with the same values (NW > 1: same-value stores, each thread reads back its own)
-  __device__ __forceinline__ void set(int slot, int va, int vb, int vc) {
+  __device__ __forceinline__ void set(int slot, int va, int vi, int vd, int vb) {
     if constexpr (NW == 1) {
       const bool mine = (int)(threadIdx.x & 63) == slot;
-      a = mine ? va : a; b = mine ? vb : b; c = mine ? vc : c;
+      a = mine ? va : a; i = mine ? vi : i; d = mine ? vd : d; b = mine ? vb : b;
     } else {
-      A[slot] = va; B[slot] = vb; C[slot] = vc;
+      A[slot] = va; I[slot] = vi; D[slot] = vd; B[slot] = vb;
     }
   }
 };
+
+// Kernel arguments that are only needed between alignments (work list, result arrays, arena
+// bookkeeping) are re-read from the kernarg segment where they are used instead of being held in
+// SGPRs across the score loop: the loop needs every scalar register it can get (spilled SGPRs come
+// back through v_readlane, i.e. through the vector unit this kernel saturates).
+typedef const WfaAlignParams __attribute__((address_space(4)))* ColdParams;
+__device__ __forceinline__ ColdParams cold_params() {
+  unsigned long long v = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(v));
+  return (ColdParams)v;
+}
 
 template <int NW, bool BT, typename OffT, bool GLOBAL_RING, bool RAW, bool BANDED>
 __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams p) {
@@ -122,13 +136,12 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
   uint32_t* Pw = reinterpret_cast<uint32_t*>(sp);
   uint32_t* Tw = Pw + p.seq_words_cap;
   const int bkm = p.book_mask;                                // row book: 64 (or more) entries indexed by score & bkm
-  const int sdm = p.side_mask;                                // side table: power of two >= dm entries, score & sdm
-  int* side = reinterpret_cast<int*>(Tw + p.seq_words_cap);   // [4][sdm+1] trimmed I/D limits (rare)
-  int* red = side + 4 * (sdm + 1);                            // [3][8] per-score reduction slots (NW > 1)
+  int* red = reinterpret_cast<int*>(Tw + p.seq_words_cap);    // [3][8] per-score reduction slots (NW > 1)
   uint32_t* bslot = reinterpret_cast<uint32_t*>(red + 24);    // [2] broadcast slots
   RowBook<NW> book;
-  if constexpr (NW == 1) { book.a = ROW_NONE_A; book.b = (int)WFA_ROW_NONE; book.c = 0; book.A = book.B = book.C = nullptr; }
-  else { book.a = book.b = book.c = 0; book.A = reinterpret_cast<int*>(bslot + 2); book.B = book.A + (bkm + 1); book.C = book.B + (bkm + 1); }
+  book.reset();
+  if constexpr (NW == 1) { book.A = book.I = book.D = book.B = nullptr; }
+  else { book.A = reinterpret_cast<int*>(bslot + 2); book.I = book.A + (bkm + 1); book.D = book.I + (bkm + 1); book.B = book.D + (bkm + 1); }
 
   uint32_t chunk_cur = 0, chunk_left = 0;   // arena units owned by this block
 
@@ -136,22 +149,26 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
   // own cache line; a block starts on shard blockIdx % 8 and moves on when a shard is empty.  One
   // counter word serves only ~88 claims per microsecond, which capped short-read batches
   // (BASELINE configs[1]) at 1.2 ms per 100k pairs.
-  const uint32_t nsh = p.work_shards;              // 1 or 8
-  uint32_t shard = blockIdx.x & (nsh - 1u), shards_left = nsh;
+  uint32_t shard = blockIdx.x & (cold_params()->work_shards - 1u), shards_left = cold_params()->work_shards;   // 1 or 8
   for (;;) {
     uint32_t w = 0xFFFFFFFFu;
-    while (shards_left) {
-      const uint32_t lo_w = (uint32_t)(((unsigned long long)p.n_work * shard) / nsh);
-      const uint32_t hi_w = (uint32_t)(((unsigned long long)p.n_work * (shard + 1)) / nsh);
-      uint32_t c = 0;
-      if (tid == 0) c = atomicAdd(p.work_counter + shard * 16, 1u);
-      c = block_bcast<NW>(c, bslot);
-      if (c < hi_w - lo_w) { w = lo_w + c; break; }
-      shard = (shard + 1) & (nsh - 1u); --shards_left;
+    {
+      ColdParams cp = cold_params();
+      const uint32_t nsh = cp->work_shards, n_work = cp->n_work;
+      while (shards_left) {
+        const uint32_t lo_w = (uint32_t)(((unsigned long long)n_work * shard) / nsh);
+        const uint32_t hi_w = (uint32_t)(((unsigned long long)n_work * (shard + 1)) / nsh);
+        uint32_t c = 0;
+        if (tid == 0) c = atomicAdd(cp->work_counter + shard * 16, 1u);
+        c = block_bcast<NW>(c, bslot);
+        if (c < hi_w - lo_w) { w = lo_w + c; break; }
+        shard = (shard + 1) & (nsh - 1u); --shards_left;
+      }
     }
     if (w == 0xFFFFFFFFu) break;
-    const uint32_t pair = p.work ? p.work[w] : w;
-    const WfaSeqPair mp = p.meta[pair];
+    const uint32_t* work = cold_params()->work;
+    const uint32_t pair = work ? work[w] : w;
+    const WfaSeqPair mp = cold_params()->meta[pair];
     const int plen = (int)mp.pattern_len, tlen = (int)mp.text_len;
     const int kend = tlen - plen;
     const int pwords = RAW ? ((plen + 3) >> 2) + 1 : ((plen + 15) >> 4) + 1;
@@ -169,8 +186,8 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
     // path the backtrace can choose while the score stays within the limit.
     // The budget may be per pair (host auto-tuning from a scored sample): smaller budget, narrower
     // window, and -- below -- a wavefront that shrinks again once the score passes half the budget.
-    int budget = p.max_score;
-    if (p.budget) budget = min(budget, p.budget[pair]);
+    int budget = cold_params()->max_score;
+    { const int32_t* pb = cold_params()->budget; if (pb) budget = min(budget, pb[pair]); }
     int wlo = -plen, whi = tlen;
     bool feasible = true;
     if constexpr (!BANDED) {
@@ -193,22 +210,21 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
       status = WFA_ST_BAND;
     } else {
       // ---- stage the sequences, reset the ring ---------------------------------------------
-      const uint32_t* __restrict__ gp = p.packed + ((RAW ? mp.pattern_offset : mp.pattern_offset_packed) >> 2);
-      const uint32_t* __restrict__ gt = p.packed + ((RAW ? mp.text_offset : mp.text_offset_packed) >> 2);
+      const uint32_t* packed = cold_params()->packed;
+      const uint32_t* __restrict__ gp = packed + ((RAW ? mp.pattern_offset : mp.pattern_offset_packed) >> 2);
+      const uint32_t* __restrict__ gt = packed + ((RAW ? mp.text_offset : mp.text_offset_packed) >> 2);
       for (int i = tid; i < pwords; i += NT) Pw[i] = gp[i];
       for (int i = tid; i < twords; i += NT) Tw[i] = gt[i];
       if constexpr (!BANDED) {
         // rows that no score has written yet must read as NULL: that is |k| <= dm + 1
         const int f0 = max(wlo - 1, -(dm + 1)), f1 = min(whi + 1, dm + 1);
-        const int nf = f1 - f0 + 1;
-        for (int i = tid; i < (dm + 2 * de) * nf; i += NT) {
-          const int r = i / nf, q = f0 + (i - r * nf);
-          Mr[(size_t)r * rs + kidx0 + q] = (OffT)OFF_NULL;   // rows of M, I, D are contiguous
-        }
+        OffT* cell = Mr + kidx0 + f0;                          // rows of M, I, D are contiguous
+        for (int r = 0; r < dm + 2 * de; ++r, cell += rs)
+          for (int q = tid; q <= f1 - f0; q += NT) cell[q] = (OffT)OFF_NULL;
       }
-      if constexpr (NW == 1) { book.a = ROW_NONE_A; book.b = (int)WFA_ROW_NONE; book.c = 0; }
+      if constexpr (NW == 1) book.reset();
       else {
-        for (int i = tid; i <= bkm; i += NT) { book.A[i] = ROW_NONE_A; book.B[i] = (int)WFA_ROW_NONE; book.C[i] = 0; }
+        for (int i = tid; i <= bkm; i += NT) { book.A[i] = book.I[i] = book.D[i] = ROW_NONE_A; book.B[i] = (int)WFA_ROW_NONE; }
         if (tid < 24) red[tid] = (tid & 7) == 6 ? 0 : (((tid & 7) & 1) ? INT_MIN : INT_MAX);
       }
       block_sync<NW>();
@@ -216,11 +232,12 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
       // ---- score 0: M[0][0] = extend(0) ------------------------------------------------------
       if constexpr (BT) {
         if (chunk_left < 2) {
-          const uint32_t grab = max(2u, p.chunk_units);
+          ColdParams cp = cold_params();
+          const uint32_t grab = max(2u, cp->chunk_units);
           uint32_t base = WFA_ROW_NONE;
           if (tid == 0) {
-            const unsigned long long b = atomicAdd(p.arena_top, (unsigned long long)grab);
-            if (b + grab <= p.arena_units) base = (uint32_t)b;
+            const unsigned long long b = atomicAdd(cp->arena_top, (unsigned long long)grab);
+            if (b + grab <= cp->arena_units) base = (uint32_t)b;
           }
           base = block_bcast<NW>(base, bslot);
           if (base == WFA_ROW_NONE) status = WFA_ST_NOMEM;
@@ -249,7 +266,7 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
         Mr[BANDED ? 0 : kidx0] = (OffT)h0;
         d0 = (kend == 0 && h0 >= tlen) ? 1u : 0u;
       }
-      book.set(0, pack_range(0, 0), (int)row_s, 0);
+      book.set(0, pack_range(0, 0), ROW_NONE_A, ROW_NONE_A, (int)row_s);
       done = block_bcast<NW>(d0, bslot) != 0;
       block_sync<NW>();
 
@@ -288,21 +305,18 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
         // predecessor rows: s-x and s-(o+e) of M, s-e of I and D
         const int a_x = book.get_a(bk_x);
         const int a_oe = book.get_a(bk_oe);
-        const int a_e = book.get_a(bk_e);
-        const int c_e = book.get_c(bk_e);
+        const int bi_e = book.get_i(bk_e);
+        const int bd_e = book.get_d(bk_e);
         const int mxlo = range_lo(a_x), mxhi = range_hi(a_x), molo = range_lo(a_oe), mohi = range_hi(a_oe);
-        int ielo = 1, iehi = -1, delo = 1, dehi = -1;
-        if (c_e & 1) { ielo = range_lo(a_e); iehi = range_hi(a_e); }
-        if (c_e & 2) { delo = range_lo(a_e); dehi = range_hi(a_e); }
-        if (c_e & 4) {   // trimmed limits (some value ran past a sequence end at that score)
-          const int se = (s - e) & sdm;
-          ielo = side[se]; iehi = side[(sdm + 1) + se]; delo = side[2 * (sdm + 1) + se]; dehi = side[3 * (sdm + 1) + se];
-        }
+        const int ielo = range_lo(bi_e), iehi = range_hi(bi_e), delo = range_lo(bd_e), dehi = range_hi(bd_e);
         const bool mx_null = mxlo > mxhi, mo_null = molo > mohi, ie_null = ielo > iehi, de_null = delo > dehi;
         // limits (wavefront_compute.c:41-71; null rows carry lo=1, hi=-1)
         int lo = mxlo, hi = mxhi;
+        // (the empty asm keeps the chains on the scalar unit: min(min(a,b),c) would be matched to v_min3)
         lo = min(lo, molo - 1); hi = max(hi, mohi + 1);
+        if constexpr (NW == 1 && !BANDED) asm volatile("" : "+s"(lo), "+s"(hi));
         lo = min(lo, ielo + 1); hi = max(hi, iehi + 1);
+        if constexpr (NW == 1 && !BANDED) asm volatile("" : "+s"(lo), "+s"(hi));
         lo = min(lo, delo - 1); hi = max(hi, dehi - 1);
         if constexpr (!BANDED) {
           lo = max(lo, wlo); hi = min(hi, whi);
@@ -316,7 +330,7 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
         OffT* out_d = Mr + (d_off + off_ec);
         if ((mx_null && mo_null && ie_null && de_null) || lo > hi) {
           // no wavefront at this score (wavefront_compute_affine.c:236-243)
-          book.set(bk_s, ROW_NONE_A, (int)WFA_ROW_NONE, 0);
+          book.set(bk_s, ROW_NONE_A, ROW_NONE_A, ROW_NONE_A, (int)WFA_ROW_NONE);
           if constexpr (!BANDED) {
             const int f0 = max(wlo - 1, hist_lo - dm), f1 = min(whi + 1, hist_hi + dm);
             for (int q = f0 + tid; q <= f1; q += NT) {
@@ -326,7 +340,7 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
           block_sync<NW>();
           continue;
         }
-        const int base_mx = BANDED ? mxlo : 0, base_mo = BANDED ? molo : 0, base_e = BANDED ? range_lo(a_e) : 0;
+        const int base_mx = BANDED ? mxlo : 0, base_mo = BANDED ? molo : 0, base_e = BANDED ? range_lo(book.get_a(bk_e)) : 0;
         if constexpr (BANDED) {
           // Adaptive band (reference: sequence_distance_kernel_aband.cu:104-130): keep at most
           // band_width diagonals; every band_period scores re-centre the window on the diagonal of
@@ -377,11 +391,12 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
         if constexpr (BT) {
           const uint32_t need = 1u + (((uint32_t)width + 15u) >> 4);
           if (need > chunk_left) {
-            const uint32_t grab = max(need, p.chunk_units);
+            ColdParams cp = cold_params();
+            const uint32_t grab = max(need, cp->chunk_units);
             uint32_t base = WFA_ROW_NONE;
             if (tid == 0) {
-              const unsigned long long b = atomicAdd(p.arena_top, (unsigned long long)grab);
-              if (b + grab <= p.arena_units) base = (uint32_t)b;
+              const unsigned long long b = atomicAdd(cp->arena_top, (unsigned long long)grab);
+              if (b + grab <= cp->arena_units) base = (uint32_t)b;
             }
             base = block_bcast<NW>(base, bslot);
             if (base == WFA_ROW_NONE) { status = WFA_ST_NOMEM; chunk_left = 0; break; }
@@ -425,7 +440,6 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
         OffT* wb_m = out_m + wbase;
         OffT* wb_i = out_i + wbase;
         OffT* wb_d = out_d + wbase;
-        uint8_t* cb = BT ? codes - lo : nullptr;
         bool my_over = false;
         for (int k0 = lo; k0 <= hi; k0 += NT) {
           const int k = min(k0 + tid, hi);
@@ -461,9 +475,9 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
             // tie-breaks: gap extension wins over gap open on equal offsets
             // (wavefront_compute_affine.c:135-143,153-161); for M: mismatch, then deletion, then
             // insertion (wavefront_backtrace.c:48-59)
+            // (the M origin of a cell that is not valid is never read: the backtrace only visits valid cells)
             code = (i_e >= m_ol ? BT_I_EXT : 0u) | (d_e >= m_or ? BT_D_EXT : 0u);
-            const uint32_t org = (mis == mv0) ? BT_M_X : ((del == mv0) ? BT_M_D : BT_M_I);
-            code |= ok ? org : 0u;
+            code |= (mis == mv0) ? BT_M_X : ((del == mv0) ? BT_M_D : BT_M_I);
           }
           // An I (D) value can only be out of range by running past the text (pattern) end; such
           // values are rare (last scores only) and send the row through the exact trimming pass
@@ -508,7 +522,7 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
           wb_m[k] = (OffT)mv;
           wb_i[k] = off_store<OffT>(ins);
           wb_d[k] = (OffT)del;
-          if constexpr (BT) cb[k] = (uint8_t)code;
+          if constexpr (BT) codes[(uint32_t)(k - lo)] = (uint8_t)code;
         }
         bool any_over = false;
         {
@@ -523,12 +537,12 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
             any_over = (acc[6] & 2) != 0;
           }
           // termination (wavefront_extend.c:47-67): every lane reads the same cell
-          done = (kend >= lo && kend <= hi) && (int)wb_m[kend] >= tlen;
+          done = (kend >= lo && kend <= hi) && __builtin_amdgcn_readfirstlane((int)wb_m[kend]) >= tlen;
         }
         // Limits recorded for the row: the computed ones.  Cells that are not valid hold NULL or a
         // negative value, which is all a reader needs; only values past a sequence end need the
         // exact per-component trimming (wavefront_compute.c:570-603): first/last in-range cell.
-        int cflags = (have_i ? 1 : 0) | (have_d ? 2 : 0);
+        int lim_i = have_i ? pack_range(lo, hi) : ROW_NONE_A, lim_d = have_d ? pack_range(lo, hi) : ROW_NONE_A;
         if (any_over) {
           const int wave = (NW == 1) ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6);
           int r[4] = {INT_MAX, INT_MIN, INT_MAX, INT_MIN};
@@ -556,10 +570,7 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
           }
           if (r[0] > r[1]) { r[0] = 1; r[1] = -1; }
           if (r[2] > r[3]) { r[2] = 1; r[3] = -1; }
-          // every thread stores the same values and later reads its own copy back
-          const int ss = s & sdm;
-          side[ss] = r[0]; side[(sdm + 1) + ss] = r[1]; side[2 * (sdm + 1) + ss] = r[2]; side[3 * (sdm + 1) + ss] = r[3];
-          cflags = 7;
+          lim_i = pack_range(r[0], r[1]); lim_d = pack_range(r[2], r[3]);
           if constexpr (!BANDED) {
             // trimmed-away cells read as NULL from now on (wavefront_compute.c:480-520)
             for (int q = lo + tid; q <= hi; q += NT) {
@@ -569,17 +580,18 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
             if constexpr (NW > 1) __syncthreads();
           }
         }
-        book.set(bk_s, pack_range(lo, hi), (int)row_s, cflags);
+        book.set(bk_s, pack_range(lo, hi), lim_i, lim_d, (int)row_s);
         if constexpr (NW == 1) block_sync<NW>();
       }
       if (tid == 0 && status == WFA_ST_DONE) {
-        if constexpr (BT) p.bt_final_row[pair] = row_s;
+        if constexpr (BT) cold_params()->bt_final_row[pair] = row_s;
       }
     }
     if (tid == 0) {
-      p.score[pair] = (status == WFA_ST_DONE) ? s : -1;
-      p.status[pair] = status;
-      if (p.cells) p.cells[pair] = ncells;
+      ColdParams cp = cold_params();
+      cp->score[pair] = (status == WFA_ST_DONE) ? s : -1;
+      cp->status[pair] = status;
+      if (cp->cells) cp->cells[pair] = ncells;
     }
     block_sync<NW>();
   }
@@ -650,9 +662,9 @@ size_t wfa_align_lds_bytes(const WfaAlignParams& p, int tier) {
   size_t ring = 0;
   if (tier != 3) ring = (((size_t)(p.dm + 2 * p.de) * p.rs * sizeof(int16_t)) + 15) & ~(size_t)15;
   const size_t seq = (size_t)2 * p.seq_words_cap * 4;
-  // side table [4][book] + reduction slots [24] + broadcast [2] + (NW > 1) row book [3][book]
+  // reduction slots [24] + broadcast [2] + (NW > 1) row book [4][book]
   const size_t bk = (size_t)p.book_mask + 1;
-  const size_t meta = (size_t)(4 * ((size_t)p.side_mask + 1) + 24 + 2 + (tier == 0 ? 0 : 3 * bk)) * 4;
+  const size_t meta = (size_t)(24 + 2 + (tier == 0 ? 0 : 4 * bk)) * 4;
   return ((ring + seq + meta) + 15) & ~(size_t)15;
 }
 

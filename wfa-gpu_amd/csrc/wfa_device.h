@@ -63,7 +63,6 @@ struct WfaAlignParams {
   int x, oe, e;                  // penalties: mismatch, open+extend, extend
   int dm, de;                    // ring depths: max(x,oe)+1 rows of M, e+1 rows of I and D
   int book_mask;                 // row-book entries - 1 (power of two >= max(dm, 64))
-  int side_mask;                 // side-table entries - 1 (power of two >= dm)
   int rs;                        // row stride (elements), even: widest diagonal window + 3
   int max_score;                 // give up (WFA_ST_SCORE) beyond this score
   const int32_t* budget;         // optional per-pair score budget (auto-tuned), capped by max_score

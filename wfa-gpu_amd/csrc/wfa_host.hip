@@ -362,7 +362,6 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   ap.dm = std::max(pen.x, oe) + 1;
   ap.de = pen.e + 1;
   { int bk = 64; while (bk < ap.dm) bk <<= 1; ap.book_mask = bk - 1; }
-  { int sd = 1; while (sd < ap.dm) sd <<= 1; ap.side_mask = sd - 1; }
   ap.seq_words_cap = (int)((max_len + 15) / 16 + 1);
   ap.score = d_scores;
   ap.status = static_cast<uint32_t*>(c->status.p);

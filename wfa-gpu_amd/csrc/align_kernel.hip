@@ -279,19 +279,20 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
       // From a cell of score s on diagonal k the end is at least |k - kend| more gap bases away (an I or
       // D cell may sit inside the gap that is already open, so no opening cost can be assumed), so within
       // the budget only |k - kend| <= (budget - s) / e can still matter (exact, same argument as the
-      // window).  reach_q / reach_r track that quotient and remainder without a division per score.
+      // window).  [rlo, rhi] is that interval; it loses a diagonal on each side whenever the quotient
+      // drops, tracked through the remainder reach_r without a division per score.
       const bool bounded = !BANDED && budget < INT_MAX / 2;
-      int reach_n = bounded ? budget : 0;                     // budget - s at s = 0
-      int reach_q = (bounded && reach_n >= 0) ? reach_n / e : 0;
-      int reach_r = (bounded && reach_n >= 0) ? reach_n - reach_q * e : 0;
+      int reach_r = bounded ? budget % e : INT_MAX;
+      int rlo = bounded ? kend - budget / e : INT_MIN / 2, rhi = bounded ? kend + budget / e : INT_MAX / 2;
+      // Number of consecutive scores up to s-1 whose wavefront exists with all three components and
+      // untrimmed limits.  Once that covers every row the recurrences read, the limits follow from the M
+      // limits alone and none of the "no wavefront" cases of wavefront_compute.c:41-71 can occur.
+      int regular = 0;
       // ---- score loop ----------------------------------------------------------------------------
       while (!done && status == WFA_ST_DONE) {
         ++s;
         if (s > budget) { status = WFA_ST_SCORE; break; }
-        if (bounded) {
-          --reach_n;
-          if (reach_r == 0) { --reach_q; reach_r = e - 1; } else --reach_r;
-        }
+        if (reach_r == 0) { ++rlo; --rhi; reach_r = e - 1; } else --reach_r;
         if constexpr (NW > 1) {
           // reduction slot of the NEXT score (nobody reads it any more: its readers passed barrier s-1)
           if (tid < 8) red[8 * ((s + 1) % 3) + tid] = (tid == 6) ? 0 : ((tid & 1) ? INT_MIN : INT_MAX);
@@ -305,31 +306,39 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
         // predecessor rows: s-x and s-(o+e) of M, s-e of I and D
         const int a_x = book.get_a(bk_x);
         const int a_oe = book.get_a(bk_oe);
-        const int bi_e = book.get_i(bk_e);
-        const int bd_e = book.get_d(bk_e);
         const int mxlo = range_lo(a_x), mxhi = range_hi(a_x), molo = range_lo(a_oe), mohi = range_hi(a_oe);
-        const int ielo = range_lo(bi_e), iehi = range_hi(bi_e), delo = range_lo(bd_e), dehi = range_hi(bd_e);
-        const bool mx_null = mxlo > mxhi, mo_null = molo > mohi, ie_null = ielo > iehi, de_null = delo > dehi;
         // limits (wavefront_compute.c:41-71; null rows carry lo=1, hi=-1)
-        int lo = mxlo, hi = mxhi;
         // (the empty asm keeps the chains on the scalar unit: min(min(a,b),c) would be matched to v_min3)
-        lo = min(lo, molo - 1); hi = max(hi, mohi + 1);
+        int lo = min(mxlo, molo - 1), hi = max(mxhi, mohi + 1);
         if constexpr (NW == 1 && !BANDED) asm volatile("" : "+s"(lo), "+s"(hi));
-        lo = min(lo, ielo + 1); hi = max(hi, iehi + 1);
-        if constexpr (NW == 1 && !BANDED) asm volatile("" : "+s"(lo), "+s"(hi));
-        lo = min(lo, delo - 1); hi = max(hi, dehi - 1);
+        bool mx_null = false, mo_null = false, ie_null = false, de_null = false;
+        int ielo, iehi, delo, dehi;
+        if (!BANDED && regular >= dm - 1) {
+          // I and D of s-e span the M limits of s-e: min(lo+1, lo-1), max(hi+1, hi-1)
+          const int a_e = book.get_a(bk_e);
+          ielo = delo = range_lo(a_e); iehi = dehi = range_hi(a_e);
+          lo = min(lo, ielo - 1); hi = max(hi, iehi + 1);
+        } else {
+          const int bi_e = book.get_i(bk_e);
+          const int bd_e = book.get_d(bk_e);
+          ielo = range_lo(bi_e); iehi = range_hi(bi_e); delo = range_lo(bd_e); dehi = range_hi(bd_e);
+          mx_null = mxlo > mxhi; mo_null = molo > mohi; ie_null = ielo > iehi; de_null = delo > dehi;
+          lo = min(lo, ielo + 1); hi = max(hi, iehi + 1);
+          if constexpr (NW == 1 && !BANDED) asm volatile("" : "+s"(lo), "+s"(hi));
+          lo = min(lo, delo - 1); hi = max(hi, dehi - 1);
+        }
         if constexpr (!BANDED) {
+          if constexpr (NW == 1) asm volatile("" : "+s"(lo), "+s"(hi));
           lo = max(lo, wlo); hi = min(hi, whi);
-          if (bounded) {
-            const int reach = reach_n >= 0 ? reach_q : 0;
-            lo = max(lo, kend - reach); hi = min(hi, kend + reach);
-          }
+          if constexpr (NW == 1) asm volatile("" : "+s"(lo), "+s"(hi));
+          lo = max(lo, rlo); hi = min(hi, rhi);
         }
         OffT* out_m = Mr + off_m;
         OffT* out_i = Mr + (i_off + off_ec);
         OffT* out_d = Mr + (d_off + off_ec);
         if ((mx_null && mo_null && ie_null && de_null) || lo > hi) {
           // no wavefront at this score (wavefront_compute_affine.c:236-243)
+          regular = 0;
           book.set(bk_s, ROW_NONE_A, ROW_NONE_A, ROW_NONE_A, (int)WFA_ROW_NONE);
           if constexpr (!BANDED) {
             const int f0 = max(wlo - 1, hist_lo - dm), f1 = min(whi + 1, hist_hi + dm);
@@ -580,6 +589,7 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
             if constexpr (NW > 1) __syncthreads();
           }
         }
+        regular = (have_i && have_d && !any_over) ? regular + 1 : 0;
         book.set(bk_s, pack_range(lo, hi), lim_i, lim_d, (int)row_s);
         if constexpr (NW == 1) block_sync<NW>();
       }

@@ -31,7 +31,7 @@
 //   * extend(): two 32-bit LDS words per sequence, v_alignbit_b32 to the base position, XOR,
 //     count-trailing-zeros: 16 bases per iteration (4 bytes in the byte-compare instantiation).
 //   * For CIGARs each cell emits ONE origin byte (64 consecutive bytes per wavefront store) into a
-//     bump-allocated arena; rows are linked backwards through a 16-byte header.  No
+//     bump-allocated arena; a per-alignment row table (8 bytes per score) locates the rows.  No
 //     O(max_error^2) per-alignment reservation and nothing to memset between alignments.
 //   * A last-resort instantiation keeps a 32-bit ring in HBM/L2 for wavefronts too wide for LDS.
 #include "wfa_device.h"
@@ -76,7 +76,6 @@ template <int NW> __device__ __forceinline__ uint32_t block_bcast(uint32_t v, ui
 //   A    = limits of the row as computed, lo in the low and hi in the high 16 bits (lo > hi: no wavefront)
 //   I, D = limits of the I and D components (the computed ones, or the trimmed ones when a value ran
 //          past a sequence end; lo = 1, hi = -1 when the component does not exist)
-//   B    = arena unit of the row's backtrace record
 // NW == 1 keeps each in one VGPR (lane = slot): reading is one v_readlane, no LDS round trip, and
 // everything derived from it stays on the scalar unit.
 constexpr int ROW_NONE_A = (int)0xFFFF0001u;   // lo = 1, hi = -1
@@ -85,20 +84,19 @@ __device__ __forceinline__ int range_lo(int a) { return (int)(int16_t)(a & 0xFFF
 __device__ __forceinline__ int range_hi(int a) { return a >> 16; }
 
 template <int NW> struct RowBook {
-  int a, i, d, b;       // NW == 1
-  int *A, *I, *D, *B;   // NW > 1 (LDS)
+  int a, i, d;          // NW == 1
+  int *A, *I, *D;       // NW > 1 (LDS)
   __device__ __forceinline__ int get_a(int slot) const { if constexpr (NW == 1) return __builtin_amdgcn_readlane(a, slot); else return A[slot]; }
   __device__ __forceinline__ int get_i(int slot) const { if constexpr (NW == 1) return __builtin_amdgcn_readlane(i, slot); else return I[slot]; }
   __device__ __forceinline__ int get_d(int slot) const { if constexpr (NW == 1) return __builtin_amdgcn_readlane(d, slot); else return D[slot]; }
-  __device__ __forceinline__ int get_b(int slot) const { if constexpr (NW == 1) return __builtin_amdgcn_readlane(b, slot); else return B[slot]; }
-  __device__ __forceinline__ void reset() { a = i = d = ROW_NONE_A; b = (int)WFA_ROW_NONE; }
+  __device__ __forceinline__ void reset() { a = i = d = ROW_NONE_A; }
   // every thread calls set with the same values (NW > 1: same-value stores, each thread reads back its own)
-  __device__ __forceinline__ void set(int slot, int va, int vi, int vd, int vb) {
+  __device__ __forceinline__ void set(int slot, int va, int vi, int vd) {
     if constexpr (NW == 1) {
       const bool mine = (int)(threadIdx.x & 63) == slot;
-      a = mine ? va : a; i = mine ? vi : i; d = mine ? vd : d; b = mine ? vb : b;
+      a = mine ? va : a; i = mine ? vi : i; d = mine ? vd : d;
     } else {
-      A[slot] = va; I[slot] = vi; D[slot] = vd; B[slot] = vb;
+      A[slot] = va; I[slot] = vi; D[slot] = vd;
     }
   }
 };
@@ -140,8 +138,8 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
   uint32_t* bslot = reinterpret_cast<uint32_t*>(red + 24);    // [2] broadcast slots
   RowBook<NW> book;
   book.reset();
-  if constexpr (NW == 1) { book.A = book.I = book.D = book.B = nullptr; }
-  else { book.A = reinterpret_cast<int*>(bslot + 2); book.I = book.A + (bkm + 1); book.D = book.I + (bkm + 1); book.B = book.D + (bkm + 1); }
+  if constexpr (NW == 1) { book.A = book.I = book.D = nullptr; }
+  else { book.A = reinterpret_cast<int*>(bslot + 2); book.I = book.A + (bkm + 1); book.D = book.I + (bkm + 1); }
 
   uint32_t chunk_cur = 0, chunk_left = 0;   // arena units owned by this block
 
@@ -178,7 +176,8 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
     int s = 0;
     uint32_t ncells = 1;
     bool done = false;
-    uint32_t row_s = WFA_ROW_NONE;
+    uint32_t row_s = WFA_ROW_NONE, tab_base = WFA_ROW_NONE;
+    uint2* tab = nullptr;                   // backtrace row table of this pair: [score] = {arena unit, lo}
 
     // Diagonal window that can hold an alignment of score <= max_score (exact, not a heuristic):
     // a path that visits diagonal k beyond both 0 and kend needs one gap out and one gap back,
@@ -188,6 +187,12 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
     // window, and -- below -- a wavefront that shrinks again once the score passes half the budget.
     int budget = cold_params()->max_score;
     { const int32_t* pb = cold_params()->budget; if (pb) budget = min(budget, pb[pair]); }
+    {
+      // no optimal alignment costs more than min(P,T) mismatches plus one gap of |T - P| (that alignment
+      // always exists); it bounds the backtrace row table
+      const long long worst = (long long)x * min(plen, tlen) + (kend ? oe + (long long)e * (abs(kend) - 1) : 0);
+      budget = (int)min((long long)budget, worst);
+    }
     int wlo = -plen, whi = tlen;
     bool feasible = true;
     if constexpr (!BANDED) {
@@ -224,16 +229,18 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
       }
       if constexpr (NW == 1) book.reset();
       else {
-        for (int i = tid; i <= bkm; i += NT) { book.A[i] = book.I[i] = book.D[i] = ROW_NONE_A; book.B[i] = (int)WFA_ROW_NONE; }
+        for (int i = tid; i <= bkm; i += NT) { book.A[i] = book.I[i] = book.D[i] = ROW_NONE_A; }
         if (tid < 24) red[tid] = (tid & 7) == 6 ? 0 : (((tid & 7) & 1) ? INT_MIN : INT_MAX);
       }
       block_sync<NW>();
 
       // ---- score 0: M[0][0] = extend(0) ------------------------------------------------------
       if constexpr (BT) {
-        if (chunk_left < 2) {
+        // the row table (8 bytes per score up to the budget) and the one-cell row of score 0
+        const uint32_t tab_units = (uint32_t)(((long long)budget + 2) >> 1);
+        if (chunk_left < tab_units + 1) {
           ColdParams cp = cold_params();
-          const uint32_t grab = max(2u, cp->chunk_units);
+          const uint32_t grab = max(tab_units + 1, cp->chunk_units);
           uint32_t base = WFA_ROW_NONE;
           if (tid == 0) {
             const unsigned long long b = atomicAdd(cp->arena_top, (unsigned long long)grab);
@@ -244,11 +251,11 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
           chunk_cur = base; chunk_left = (base == WFA_ROW_NONE) ? 0 : grab;
         }
         if (status == WFA_ST_DONE) {
-          row_s = chunk_cur; chunk_cur += 2; chunk_left -= 2;
+          tab_base = chunk_cur; row_s = chunk_cur + tab_units; chunk_cur += tab_units + 1; chunk_left -= tab_units + 1;
+          tab = reinterpret_cast<uint2*>(p.arena + (size_t)tab_base * 16);
           if (tid == 0) {
-            WfaBtRowHdr* hdr = reinterpret_cast<WfaBtRowHdr*>(p.arena + (size_t)row_s * 16);
-            hdr->lo = 0; hdr->prev_x = WFA_ROW_NONE; hdr->prev_oe = WFA_ROW_NONE; hdr->prev_e = WFA_ROW_NONE;
-            p.arena[(size_t)row_s * 16 + 16] = 0;
+            tab[0] = make_uint2(row_s, 0u);
+            p.arena[(size_t)row_s * 16] = 0;
           }
         }
       }
@@ -266,7 +273,7 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
         Mr[BANDED ? 0 : kidx0] = (OffT)h0;
         d0 = (kend == 0 && h0 >= tlen) ? 1u : 0u;
       }
-      book.set(0, pack_range(0, 0), ROW_NONE_A, ROW_NONE_A, (int)row_s);
+      book.set(0, pack_range(0, 0), ROW_NONE_A, ROW_NONE_A);
       done = block_bcast<NW>(d0, bslot) != 0;
       block_sync<NW>();
 
@@ -339,7 +346,7 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
         if ((mx_null && mo_null && ie_null && de_null) || lo > hi) {
           // no wavefront at this score (wavefront_compute_affine.c:236-243)
           regular = 0;
-          book.set(bk_s, ROW_NONE_A, ROW_NONE_A, ROW_NONE_A, (int)WFA_ROW_NONE);
+          book.set(bk_s, ROW_NONE_A, ROW_NONE_A, ROW_NONE_A);
           if constexpr (!BANDED) {
             const int f0 = max(wlo - 1, hist_lo - dm), f1 = min(whi + 1, hist_hi + dm);
             for (int q = f0 + tid; q <= f1; q += NT) {
@@ -398,7 +405,7 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
 
         uint8_t* codes = nullptr;
         if constexpr (BT) {
-          const uint32_t need = 1u + (((uint32_t)width + 15u) >> 4);
+          const uint32_t need = ((uint32_t)width + 15u) >> 4;
           if (need > chunk_left) {
             ColdParams cp = cold_params();
             const uint32_t grab = max(need, cp->chunk_units);
@@ -412,11 +419,8 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
             chunk_cur = base; chunk_left = grab;
           }
           row_s = chunk_cur; chunk_cur += need; chunk_left -= need;
-          const uint32_t r_x = (uint32_t)book.get_b(bk_x);
-          const uint32_t r_oe = (uint32_t)book.get_b(bk_oe);
-          const uint32_t r_e = (uint32_t)book.get_b(bk_e);
-          if (tid == 0) *reinterpret_cast<uint4*>(p.arena + (size_t)row_s * 16) = make_uint4((uint32_t)lo, r_x, r_oe, r_e);
-          codes = p.arena + (size_t)row_s * 16 + 16;
+          if (tid == 0) tab[s] = make_uint2(row_s, (uint32_t)lo);
+          codes = p.arena + (size_t)row_s * 16;
         }
 
         const OffT* row_mx = Mr + off_x;
@@ -590,11 +594,11 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
           }
         }
         regular = (have_i && have_d && !any_over) ? regular + 1 : 0;
-        book.set(bk_s, pack_range(lo, hi), lim_i, lim_d, (int)row_s);
+        book.set(bk_s, pack_range(lo, hi), lim_i, lim_d);
         if constexpr (NW == 1) block_sync<NW>();
       }
       if (tid == 0 && status == WFA_ST_DONE) {
-        if constexpr (BT) cold_params()->bt_final_row[pair] = row_s;
+        if constexpr (BT) cold_params()->bt_final_row[pair] = tab_base;
       }
     }
     if (tid == 0) {
@@ -672,9 +676,9 @@ size_t wfa_align_lds_bytes(const WfaAlignParams& p, int tier) {
   size_t ring = 0;
   if (tier != 3) ring = (((size_t)(p.dm + 2 * p.de) * p.rs * sizeof(int16_t)) + 15) & ~(size_t)15;
   const size_t seq = (size_t)2 * p.seq_words_cap * 4;
-  // reduction slots [24] + broadcast [2] + (NW > 1) row book [4][book]
+  // reduction slots [24] + broadcast [2] + (NW > 1) row book [3][book]
   const size_t bk = (size_t)p.book_mask + 1;
-  const size_t meta = (size_t)(24 + 2 + (tier == 0 ? 0 : 4 * bk)) * 4;
+  const size_t meta = (size_t)(24 + 2 + (tier == 0 ? 0 : 3 * bk)) * 4;
   return ((ring + seq + meta) + 15) & ~(size_t)15;
 }
 

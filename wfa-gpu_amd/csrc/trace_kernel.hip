@@ -142,30 +142,30 @@ __global__ void __launch_bounds__(TRACE_THREADS) wfa_walk_kernel(const WfaTraceP
   uint8_t* q_end = p.ops + ops_off + need_ops;
   uint8_t* q = q_end;
   if (active && !fail) {
-    uint32_t row = p.bt_final_row[pair];
+    // row table of the pair: [score] = {arena unit of the origin bytes, lo}
+    const uint2* tab = reinterpret_cast<const uint2*>(p.arena + (size_t)p.bt_final_row[pair] * 16);
     int k = tlen - plen, s = score;
     int state = 0;  // 0: M, 1: I, 2: D
     while (s > 0) {
-      if (row == WFA_ROW_NONE || q == p.ops + ops_off) { fail = true; break; }
-      const uint8_t* rp = p.arena + (size_t)row * 16;
-      const uint4 hdr = *reinterpret_cast<const uint4*>(rp);
-      const uint32_t code = rp[16 + (k - (int)hdr.x)];
+      if (q == p.ops + ops_off) { fail = true; break; }
+      const uint2 row = tab[s];
+      const uint32_t code = p.arena[(size_t)row.x * 16 + (uint32_t)(k - (int)row.y)];
       if (state == 0) {
         const uint32_t org = code & 3u;
-        if (org == BT_M_X) { *--q = OP_X | OP_EXT_AFTER; row = hdr.y; s -= p.x; }
+        if (org == BT_M_X) { *--q = OP_X | OP_EXT_AFTER; s -= p.x; }
         else if (org == BT_M_I) {
           *--q = OP_I | OP_EXT_AFTER; --k;
-          if (code & BT_I_EXT) { row = hdr.w; s -= p.e; state = 1; } else { row = hdr.z; s -= p.oe; }
+          if (code & BT_I_EXT) { s -= p.e; state = 1; } else { s -= p.oe; }
         } else if (org == BT_M_D) {
           *--q = OP_D | OP_EXT_AFTER; ++k;
-          if (code & BT_D_EXT) { row = hdr.w; s -= p.e; state = 2; } else { row = hdr.z; s -= p.oe; }
+          if (code & BT_D_EXT) { s -= p.e; state = 2; } else { s -= p.oe; }
         } else { fail = true; break; }
       } else if (state == 1) {
         *--q = OP_I; --k;
-        if (code & BT_I_EXT) { row = hdr.w; s -= p.e; } else { row = hdr.z; s -= p.oe; state = 0; }
+        if (code & BT_I_EXT) { s -= p.e; } else { s -= p.oe; state = 0; }
       } else {
         *--q = OP_D; ++k;
-        if (code & BT_D_EXT) { row = hdr.w; s -= p.e; } else { row = hdr.z; s -= p.oe; state = 0; }
+        if (code & BT_D_EXT) { s -= p.e; } else { s -= p.oe; state = 0; }
       }
     }
     if (s != 0 || state != 0 || k != 0) fail = true;

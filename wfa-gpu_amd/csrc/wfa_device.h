@@ -7,9 +7,9 @@
 //                    base i of a sequence in bits [2*(i%16)+1 : 2*(i%16)]
 //                    (little-endian inside the word so one v_alignbit_b32
 //                    yields the 16 bases starting at any position).
-//   * Backtrace arena: rows of {16-byte header, one origin byte per diagonal},
-//                    bump-allocated in 16-byte units, linked backwards by
-//                    the header (no per-alignment worst-case reservation).
+//   * Backtrace arena: per alignment a row table (8 bytes per score) and rows
+//                    of one origin byte per diagonal, bump-allocated in
+//                    16-byte units (no per-alignment worst-case reservation).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -45,14 +45,9 @@ enum : uint32_t { BT_M_NONE = 0, BT_M_X = 1, BT_M_I = 2, BT_M_D = 3, BT_I_EXT = 
 
 #define WFA_ROW_NONE 0xFFFFFFFFu
 
-// Row header in the backtrace arena (16 bytes = one allocation unit).
-struct WfaBtRowHdr {
-  int32_t lo;          // diagonal of codes[0]
-  uint32_t prev_x;     // unit offset of row s-x     (WFA_ROW_NONE if that score has no wavefront)
-  uint32_t prev_oe;    // unit offset of row s-(o+e)
-  uint32_t prev_e;     // unit offset of row s-e
-};
-
+// Backtrace arena, 16-byte units.  Per alignment: a row table [score] = {unit of the row, lo} (8 bytes
+// per score up to the score budget) followed, wherever the block's bump allocator puts them, by one
+// row of origin bytes per score (byte j = diagonal lo + j).
 struct WfaAlignParams {
   const uint32_t* packed;        // packed sequences (word base); RAW kernels: the ASCII buffer
   const WfaSeqPair* meta;
@@ -77,7 +72,7 @@ struct WfaAlignParams {
   unsigned long long arena_units;        // capacity in 16-byte units
   unsigned long long* arena_top;         // bump pointer (units)
   uint32_t chunk_units;          // refill granularity
-  uint32_t* bt_final_row;        // [pair] out: unit offset of the last row
+  uint32_t* bt_final_row;        // [pair] out: unit offset of the pair's row table
   // global-memory ring (only the GLOBAL_RING instantiation)
   void* gring;                   // per-block slices of gring_stride bytes
   unsigned long long gring_stride;

@@ -82,12 +82,6 @@ def pmc_traffic_bytes(workload):
     return int((2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024), src
 
 
-def pmc_valu_insts(workload):
-    """SQ_INSTS_VALU of the dominant kernel from the same committed PMC summary (wave-instructions per launch)."""
-    v, _ = _pmc_per_launch(workload, ["SQ_INSTS_VALU"])
-    return None if v is None else v["SQ_INSTS_VALU"]
-
-
 def usable_cores():
     """Host cores this process may really use: affinity mask capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -206,15 +200,24 @@ def main():
                     "cells_per_step": int(st.cells), "cells_per_s": round(st.cells / (acc["align_ms"] / args.steps * 1e-3), 1)
                     if acc["align_ms"] > 0 else None,
                     "note": "LDS-resident integer kernel: HBM fraction is low by construction, see DESIGN.md"}
-        valu = pmc_valu_insts(args.workload) if not args.pairs and not args.max_error else None
-        if valu and k_ms > 0:
-            # the unit this kernel saturates: integer wave64 VALU issue, 1 instruction per 4 cycles per SIMD
-            # (scratch/valu_rate.hip measures 4.04-4.17 cycles), 1024 SIMDs, 2.4 GHz max clock
+        issue, _ = _pmc_per_launch(args.workload, ["SQ_INSTS_VALU", "SQ_INSTS_SALU"]) \
+            if not args.pairs and not args.max_error else (None, None)
+        if issue and k_ms > 0:
+            # What this kernel really saturates: instruction issue.  A SIMD issues at most one vector and one
+            # scalar instruction per 4 cycles (scratch/valu_rate.hip measures 4.04-4.17 cycles per integer
+            # wave64 op; the CU's scalar unit serves its 4 SIMDs in turn): 1024 SIMDs at 2.4 GHz.
             peak = 1024 * 0.25 * 2.4e9 / 1e9
-            ach = valu / (k_ms * 1e-3) / 1e9
-            roofline["valu_issue"] = {"achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instr/s",
-                                      "frac": round(ach / peak, 3), "insts_per_launch": int(valu),
-                                      "source": "SQ_INSTS_VALU from the committed PMC pass of this command"}
+            roofline["issue"] = {"unit": "G wave-instr/s", "peak_per_pipe": round(peak, 1),
+                                 "source": "SQ_INSTS_VALU / SQ_INSTS_SALU from the committed PMC pass of this command"}
+            for pipe, key in (("valu", "SQ_INSTS_VALU"), ("salu", "SQ_INSTS_SALU")):
+                ach = issue[key] / (k_ms * 1e-3) / 1e9
+                roofline["issue"][pipe] = {"achieved": round(ach, 1), "frac": round(ach / peak, 3),
+                                           "insts_per_launch": int(issue[key])}
+        # LDS side of SURVEY.md section 8(d): 16 B of wavefront offsets per cell against 256 CU x 128 B/clk
+        if acc["align_ms"] > 0:
+            lds_ach = 16.0 * st.cells / (acc["align_ms"] / args.steps * 1e-3) / 1e9
+            roofline["lds"] = {"achieved": round(lds_ach, 1), "peak": round(256 * 128 * 2.4, 1), "unit": "GB/s",
+                               "frac": round(lds_ach / (256 * 128 * 2.4), 4), "bytes_per_cell": 16}
         out = {
             "metric": "alignments_per_sec", "value": round(value, 1), "unit": "alignments/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -130,7 +130,6 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
     Mr = reinterpret_cast<OffT*>(sp);
     sp += (((size_t)(dm + 2 * de) * rs * sizeof(OffT)) + 15) & ~(size_t)15;
   }
-  const int i_off = dm * rs, d_off = (dm + de) * rs;     // element offsets of the I and D rings
   uint32_t* Pw = reinterpret_cast<uint32_t*>(sp);
   uint32_t* Tw = Pw + p.seq_words_cap;
   const int bkm = p.book_mask;                                // row book: 64 (or more) entries indexed by score & bkm
@@ -277,11 +276,17 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
       done = block_bcast<NW>(d0, bslot) != 0;
       block_sync<NW>();
 
-      // Ring state of score s, all as element offsets that advance by one row per score (no multiply,
-      // no modulo in the loop): the M rows of s, s-x, s-(o+e) and the I/D rows of s, s-e.  The row book
-      // is indexed by (score & bkm); its entries for scores < 0 still hold the "no wavefront" reset value.
-      const int m_lim = dm * rs, e_lim = de * rs;
-      int off_m = 0, off_x = (dm - x) * rs, off_oe = (dm - oe) * rs, off_ec = 0, off_ep = (de - e) * rs;
+      // Ring state of score s, as row pointers that advance by one row per score (no multiply, no modulo
+      // in the loop): the M rows of s, s-x, s-(o+e) and the I rows of s, s-e (the D ring sits de rows
+      // behind the I ring).  In exact mode the pointers address diagonal 0 of their row.  The row book is
+      // indexed by (score & bkm); its entries for scores < 0 still hold the "no wavefront" reset value.
+      OffT* const m_first = Mr + (BANDED ? 0 : kidx0);
+      OffT* const m_end = m_first + dm * rs;
+      OffT* const i_first = m_end;
+      OffT* const i_end = i_first + de * rs;
+      const int d_off = de * rs;
+      OffT* p_m = m_first; OffT* p_x = m_first + (dm - x) * rs; OffT* p_oe = m_first + (dm - oe) * rs;
+      OffT* p_ic = i_first; OffT* p_ip = i_first + (de - e) * rs;
       int hist_lo = 0, hist_hi = 0;  // widest limits so far (exact mode: bounds of the NULL guard cells)
       // From a cell of score s on diagonal k the end is at least |k - kend| more gap bases away (an I or
       // D cell may sit inside the gap that is already open, so no opening cost can be assumed), so within
@@ -304,11 +309,11 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
           // reduction slot of the NEXT score (nobody reads it any more: its readers passed barrier s-1)
           if (tid < 8) red[8 * ((s + 1) % 3) + tid] = (tid == 6) ? 0 : ((tid & 1) ? INT_MIN : INT_MAX);
         }
-        off_m += rs;  if (off_m == m_lim) off_m = 0;
-        off_x += rs;  if (off_x == m_lim) off_x = 0;
-        off_oe += rs; if (off_oe == m_lim) off_oe = 0;
-        off_ec += rs; if (off_ec == e_lim) off_ec = 0;
-        off_ep += rs; if (off_ep == e_lim) off_ep = 0;
+        p_m += rs;  if (p_m == m_end) p_m = m_first;
+        p_x += rs;  if (p_x == m_end) p_x = m_first;
+        p_oe += rs; if (p_oe == m_end) p_oe = m_first;
+        p_ic += rs; if (p_ic == i_end) p_ic = i_first;
+        p_ip += rs; if (p_ip == i_end) p_ip = i_first;
         const int bk_s = s & bkm, bk_x = (s - x) & bkm, bk_oe = (s - oe) & bkm, bk_e = (s - e) & bkm;
         // predecessor rows: s-x and s-(o+e) of M, s-e of I and D
         const int a_x = book.get_a(bk_x);
@@ -318,7 +323,8 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
         // (the empty asm keeps the chains on the scalar unit: min(min(a,b),c) would be matched to v_min3)
         int lo = min(mxlo, molo - 1), hi = max(mxhi, mohi + 1);
         if constexpr (NW == 1 && !BANDED) asm volatile("" : "+s"(lo), "+s"(hi));
-        bool mx_null = false, mo_null = false, ie_null = false, de_null = false;
+        bool mx_null = false, mo_null = false, ie_null = false, de_null = false;   // (read by the banded cells)
+        bool all_null = false, have_i = true, have_d = true;
         int ielo, iehi, delo, dehi;
         if (!BANDED && regular >= dm - 1) {
           // I and D of s-e span the M limits of s-e: min(lo+1, lo-1), max(hi+1, hi-1)
@@ -330,6 +336,8 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
           const int bd_e = book.get_d(bk_e);
           ielo = range_lo(bi_e); iehi = range_hi(bi_e); delo = range_lo(bd_e); dehi = range_hi(bd_e);
           mx_null = mxlo > mxhi; mo_null = molo > mohi; ie_null = ielo > iehi; de_null = delo > dehi;
+          all_null = mx_null && mo_null && ie_null && de_null;
+          have_i = !(mo_null && ie_null); have_d = !(mo_null && de_null);
           lo = min(lo, ielo + 1); hi = max(hi, iehi + 1);
           if constexpr (NW == 1 && !BANDED) asm volatile("" : "+s"(lo), "+s"(hi));
           lo = min(lo, delo - 1); hi = max(hi, dehi - 1);
@@ -340,17 +348,17 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
           if constexpr (NW == 1) asm volatile("" : "+s"(lo), "+s"(hi));
           lo = max(lo, rlo); hi = min(hi, rhi);
         }
-        OffT* out_m = Mr + off_m;
-        OffT* out_i = Mr + (i_off + off_ec);
-        OffT* out_d = Mr + (d_off + off_ec);
-        if ((mx_null && mo_null && ie_null && de_null) || lo > hi) {
+        OffT* out_m = p_m;             // exact mode: [q] = diagonal q
+        OffT* out_i = p_ic;
+        OffT* out_d = p_ic + d_off;
+        if (all_null || lo > hi) {
           // no wavefront at this score (wavefront_compute_affine.c:236-243)
           regular = 0;
           book.set(bk_s, ROW_NONE_A, ROW_NONE_A, ROW_NONE_A);
           if constexpr (!BANDED) {
             const int f0 = max(wlo - 1, hist_lo - dm), f1 = min(whi + 1, hist_hi + dm);
             for (int q = f0 + tid; q <= f1; q += NT) {
-              out_m[kidx0 + q] = (OffT)OFF_NULL; out_i[kidx0 + q] = (OffT)OFF_NULL; out_d[kidx0 + q] = (OffT)OFF_NULL;
+              out_m[q] = (OffT)OFF_NULL; out_i[q] = (OffT)OFF_NULL; out_d[q] = (OffT)OFF_NULL;
             }
           }
           block_sync<NW>();
@@ -367,7 +375,7 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
           if (excess > 0) {
             bool recentred = false;
             if (!mx_null && (s % p.band_period) == 0) {
-              const OffT* rowc = Mr + off_x;
+              const OffT* rowc = p_x;
               uint32_t best = 0xFFFFFFFFu;
               for (int kk = mxlo + tid; kk <= mxhi; kk += NT) {
                 const int off = (int)rowc[kk - mxlo];
@@ -398,8 +406,6 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
             if (!recentred) { hi -= (excess + 1) / 2; lo += excess / 2; }
           }
         }
-        const bool have_i = !(mo_null && ie_null);
-        const bool have_d = !(mo_null && de_null);
         const int width = hi - lo + 1;
         ncells += (uint32_t)width;
 
@@ -423,11 +429,11 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
           codes = p.arena + (size_t)row_s * 16;
         }
 
-        const OffT* row_mx = Mr + off_x;
-        const OffT* row_mo = Mr + off_oe;
-        const OffT* row_ie = Mr + (i_off + off_ep);
-        const OffT* row_de = Mr + (d_off + off_ep);
-        const int wbase = BANDED ? -lo : kidx0;   // index of diagonal 0 in the rows written now
+        const OffT* row_mx = p_x;
+        const OffT* row_mo = p_oe;
+        const OffT* row_ie = p_ip;
+        const OffT* row_de = p_ip + d_off;
+        const int wbase = BANDED ? -lo : 0;       // index of diagonal 0 in the rows written now
 
         if constexpr (!BANDED) {
           // NULL guard cells on both sides of the computed range: every diagonal a later score can
@@ -437,7 +443,7 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
           const int nlo = lo - f0, ntot = nlo + (f1 - hi);
           for (int j = tid; j < ntot; j += NT) {
             const int q = (j < nlo) ? f0 + j : hi + 1 + (j - nlo);
-            out_m[kidx0 + q] = (OffT)OFF_NULL; out_i[kidx0 + q] = (OffT)OFF_NULL; out_d[kidx0 + q] = (OffT)OFF_NULL;
+            out_m[q] = (OffT)OFF_NULL; out_i[q] = (OffT)OFF_NULL; out_d[q] = (OffT)OFF_NULL;
           }
         }
 
@@ -446,10 +452,10 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
         // The vector ALU is the unit this kernel saturates (one integer wave64 instruction holds its
         // SIMD for 4 cycles), so everything uniform is folded into scalar row bases: each LDS address
         // is one v_lshl_add of the diagonal.
-        const OffT* rb_mx = row_mx + (BANDED ? -base_mx : kidx0);          // [k]
-        const OffT* rb_mo = row_mo + (BANDED ? -base_mo : kidx0) - 1;      // [k] = k-1, [k+2] = k+1
-        const OffT* rb_ie = row_ie + (BANDED ? -base_e : kidx0) - 1;       // [k] = k-1
-        const OffT* rb_de = row_de + (BANDED ? -base_e : kidx0) + 1;       // [k] = k+1
+        const OffT* rb_mx = row_mx + (BANDED ? -base_mx : 0);          // [k]
+        const OffT* rb_mo = row_mo + (BANDED ? -base_mo : 0) - 1;      // [k] = k-1, [k+2] = k+1
+        const OffT* rb_ie = row_ie + (BANDED ? -base_e : 0) - 1;       // [k] = k-1
+        const OffT* rb_de = row_de + (BANDED ? -base_e : 0) + 1;       // [k] = k+1
         OffT* wb_m = out_m + wbase;
         OffT* wb_i = out_i + wbase;
         OffT* wb_d = out_d + wbase;
@@ -587,8 +593,8 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
           if constexpr (!BANDED) {
             // trimmed-away cells read as NULL from now on (wavefront_compute.c:480-520)
             for (int q = lo + tid; q <= hi; q += NT) {
-              if (q < r[0] || q > r[1]) out_i[kidx0 + q] = (OffT)OFF_NULL;
-              if (q < r[2] || q > r[3]) out_d[kidx0 + q] = (OffT)OFF_NULL;
+              if (q < r[0] || q > r[1]) out_i[q] = (OffT)OFF_NULL;
+              if (q < r[2] || q > r[3]) out_d[q] = (OffT)OFF_NULL;
             }
             if constexpr (NW > 1) __syncthreads();
           }

@@ -220,11 +220,17 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
       for (int i = tid; i < pwords; i += NT) Pw[i] = gp[i];
       for (int i = tid; i < twords; i += NT) Tw[i] = gt[i];
       if constexpr (!BANDED) {
-        // rows that no score has written yet must read as NULL: that is |k| <= dm + 1
-        const int f0 = max(wlo - 1, -(dm + 1)), f1 = min(whi + 1, dm + 1);
-        OffT* cell = Mr + kidx0 + f0;                          // rows of M, I, D are contiguous
-        for (int r = 0; r < dm + 2 * de; ++r, cell += rs)
-          for (int q = tid; q <= f1 - f0; q += NT) cell[q] = (OffT)OFF_NULL;
+        // Ring invariant (exact mode): a row holds NULL everywhere outside the limits it was last written
+        // with, so reads next to a row's ends need no predicate and no per-score guard fill.  It starts
+        // here (rows of M, I, D are contiguous) and is kept by clearing, whenever a row is overwritten,
+        // what the previous occupant of its slot had beyond the new limits.
+        const int cells = (dm + 2 * de) * rs;     // rs is even
+        if constexpr (sizeof(OffT) == 2) {
+          uint32_t* w = reinterpret_cast<uint32_t*>(Mr);
+          for (int i = tid; i < (cells >> 1); i += NT) w[i] = 0x80008000u;
+        } else {
+          for (int i = tid; i < cells; i += NT) Mr[i] = (OffT)OFF_NULL;
+        }
       }
       if constexpr (NW == 1) book.reset();
       else {
@@ -287,7 +293,6 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
       const int d_off = de * rs;
       OffT* p_m = m_first; OffT* p_x = m_first + (dm - x) * rs; OffT* p_oe = m_first + (dm - oe) * rs;
       OffT* p_ic = i_first; OffT* p_ip = i_first + (de - e) * rs;
-      int hist_lo = 0, hist_hi = 0;  // widest limits so far (exact mode: bounds of the NULL guard cells)
       // From a cell of score s on diagonal k the end is at least |k - kend| more gap bases away (an I or
       // D cell may sit inside the gap that is already open, so no opening cost can be assumed), so within
       // the budget only |k - kend| <= (budget - s) / e can still matter (exact, same argument as the
@@ -356,7 +361,9 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
           regular = 0;
           book.set(bk_s, ROW_NONE_A, ROW_NONE_A, ROW_NONE_A);
           if constexpr (!BANDED) {
-            const int f0 = max(wlo - 1, hist_lo - dm), f1 = min(whi + 1, hist_hi + dm);
+            // the slots this score would have written: clear what their previous occupants left
+            const int o_m = book.get_a((s - dm) & bkm), o_e = book.get_a((s - de) & bkm);
+            const int f0 = min(range_lo(o_m), range_lo(o_e)), f1 = max(range_hi(o_m), range_hi(o_e));
             for (int q = f0 + tid; q <= f1; q += NT) {
               out_m[q] = (OffT)OFF_NULL; out_i[q] = (OffT)OFF_NULL; out_d[q] = (OffT)OFF_NULL;
             }
@@ -436,14 +443,16 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
         const int wbase = BANDED ? -lo : 0;       // index of diagonal 0 in the rows written now
 
         if constexpr (!BANDED) {
-          // NULL guard cells on both sides of the computed range: every diagonal a later score can
-          // read from this row (limits move by at most one diagonal per score, a row lives dm scores)
-          hist_lo = min(hist_lo, lo); hist_hi = max(hist_hi, hi);
-          const int f0 = max(wlo - 1, hist_lo - dm), f1 = min(whi + 1, hist_hi + dm);
-          const int nlo = lo - f0, ntot = nlo + (f1 - hi);
-          for (int j = tid; j < ntot; j += NT) {
-            const int q = (j < nlo) ? f0 + j : hi + 1 + (j - nlo);
-            out_m[q] = (OffT)OFF_NULL; out_i[q] = (OffT)OFF_NULL; out_d[q] = (OffT)OFF_NULL;
+          // Keep the ring invariant: the M slot last held score s-dm, the I/D slots score s-e-1; whatever
+          // those rows had beyond [lo, hi] becomes NULL again (nothing while the wavefront grows).
+          const int o_m = book.get_a((s - dm) & bkm), o_e = book.get_a((s - de) & bkm);
+          const int f0 = min(range_lo(o_m), range_lo(o_e)), f1 = max(range_hi(o_m), range_hi(o_e));
+          const int nlo = max(lo - f0, 0), ntot = nlo + max(f1 - hi, 0);
+          if (ntot > 0) {
+            for (int j = tid; j < ntot; j += NT) {
+              const int q = (j < nlo) ? f0 + j : hi + 1 + (j - nlo);
+              out_m[q] = (OffT)OFF_NULL; out_i[q] = (OffT)OFF_NULL; out_d[q] = (OffT)OFF_NULL;
+            }
           }
         }
 

@@ -113,7 +113,8 @@ __device__ __forceinline__ ColdParams cold_params() {
 }
 
 template <int NW, bool BT, typename OffT, bool GLOBAL_RING, bool RAW, bool BANDED>
-__global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams p) {
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 1 ? 8 : 1, NW == 1 ? 8 : 8)))
+wfa_align_kernel(const WfaAlignParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NT = NW * 64;
   const int tid = threadIdx.x;
@@ -164,9 +165,10 @@ __global__ void __launch_bounds__(NW * 64) wfa_align_kernel(const WfaAlignParams
     }
     if (w == 0xFFFFFFFFu) break;
     const uint32_t* work = cold_params()->work;
-    const uint32_t pair = work ? work[w] : w;
+    // (every thread loads the same words; readfirstlane tells the compiler so)
+    const uint32_t pair = __builtin_amdgcn_readfirstlane(work ? work[w] : w);
     const WfaSeqPair mp = cold_params()->meta[pair];
-    const int plen = (int)mp.pattern_len, tlen = (int)mp.text_len;
+    const int plen = __builtin_amdgcn_readfirstlane((int)mp.pattern_len), tlen = __builtin_amdgcn_readfirstlane((int)mp.text_len);
     const int kend = tlen - plen;
     const int pwords = RAW ? ((plen + 3) >> 2) + 1 : ((plen + 15) >> 4) + 1;
     const int twords = RAW ? ((tlen + 3) >> 2) + 1 : ((tlen + 15) >> 4) + 1;

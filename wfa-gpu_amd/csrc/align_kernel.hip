@@ -308,9 +308,10 @@ wfa_align_kernel(const WfaAlignParams p) {
       // limits alone and none of the "no wavefront" cases of wavefront_compute.c:41-71 can occur.
       int regular = 0;
       // ---- score loop ----------------------------------------------------------------------------
-      while (!done && status == WFA_ST_DONE) {
+      if (!done && status == WFA_ST_DONE) for (;;) {
         ++s;
-        if (s > budget) { status = WFA_ST_SCORE; break; }
+        // (exact mode: past the budget the reach interval is empty, so the test sits on the "no wavefront" path)
+        if constexpr (BANDED) { if (s > budget) { status = WFA_ST_SCORE; break; } }
         if (reach_r == 0) { ++rlo; --rhi; reach_r = e - 1; } else --reach_r;
         if constexpr (NW > 1) {
           // reduction slot of the NEXT score (nobody reads it any more: its readers passed barrier s-1)
@@ -360,6 +361,7 @@ wfa_align_kernel(const WfaAlignParams p) {
         OffT* out_d = p_ic + d_off;
         if (all_null || lo > hi) {
           // no wavefront at this score (wavefront_compute_affine.c:236-243)
+          if constexpr (!BANDED) { if (s > budget) { status = WFA_ST_SCORE; break; } }
           regular = 0;
           book.set(bk_s, ROW_NONE_A, ROW_NONE_A, ROW_NONE_A);
           if constexpr (!BANDED) {
@@ -556,7 +558,7 @@ wfa_align_kernel(const WfaAlignParams p) {
         }
         bool any_over = false;
         {
-          const bool wave_over = __ballot(my_over) != 0ull;
+          const bool wave_over = __builtin_amdgcn_ballot_w64(my_over) != 0ull;
           if constexpr (NW == 1) {
             block_sync<NW>();
             any_over = wave_over;
@@ -567,7 +569,7 @@ wfa_align_kernel(const WfaAlignParams p) {
             any_over = (acc[6] & 2) != 0;
           }
           // termination (wavefront_extend.c:47-67): every lane reads the same cell
-          done = (kend >= lo && kend <= hi) && __builtin_amdgcn_readfirstlane((int)wb_m[kend]) >= tlen;
+          done = ((unsigned)(kend - lo) <= (unsigned)(hi - lo)) && __builtin_amdgcn_readfirstlane((int)wb_m[kend]) >= tlen;
         }
         // Limits recorded for the row: the computed ones.  Cells that are not valid hold NULL or a
         // negative value, which is all a reader needs; only values past a sequence end need the
@@ -613,6 +615,7 @@ wfa_align_kernel(const WfaAlignParams p) {
         regular = (have_i && have_d && !any_over) ? regular + 1 : 0;
         book.set(bk_s, pack_range(lo, hi), lim_i, lim_d);
         if constexpr (NW == 1) block_sync<NW>();
+        if (done) break;
       }
       if (tid == 0 && status == WFA_ST_DONE) {
         if constexpr (BT) cold_params()->bt_final_row[pair] = tab_base;

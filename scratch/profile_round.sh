@@ -2,8 +2,6 @@
 # Collects the round's evidence on the GPU box: bench lines, rocprofv3 kernel stats, PMC passes.
 TAG=${1:-r01}
 R=$PWD; O=$R/gpurun_out/final_$TAG; mkdir -p $O
-python bench.py --steps 3 --warmup 1 2>/dev/null | tail -1 > $O/bench_cfg3.json
-python bench.py --workload cfg2 --steps 10 --warmup 3 2>/dev/null | tail -1 > $O/bench_cfg2.json
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o cfg3 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/stats.log 2>&1
 for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_WAVES" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
@@ -25,4 +23,8 @@ with open('$O/pmc_counters.csv','w') as f:
     for r in rows: w.writerow(r)
 print(len(rows),'pmc rows')
 PY
+mkdir -p $R/profiles/$TAG && cp $O/pmc_counters.csv $R/profiles/$TAG/cfg3_pmc_counters.csv   # bench.py reads traffic / issue counts from it
+cp $O/pmc_counters.csv $O/cfg3_pmc_counters.csv
+python bench.py --steps 3 --warmup 1 2>/dev/null | tail -1 > $O/bench_cfg3.json
+python bench.py --workload cfg2 --steps 10 --warmup 3 2>/dev/null | tail -1 > $O/bench_cfg2.json
 cat $O/bench_cfg3.json; echo; cat $O/bench_cfg2.json; echo; head -8 $O/stats/*kernel_stats.csv

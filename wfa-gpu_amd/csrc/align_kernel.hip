@@ -21,13 +21,14 @@
 //     both 2-bit packed sequences live in LDS.  Only the diagonals an alignment within the score
 //     budget can visit are kept (see "window" below), which halves the ring against the
 //     reference's |k| <= max_error sizing.
-//   * Rows are kept physically NULL wherever a later score may read them (guard cells), so the five
-//     reads per cell need no range predicate, and lanes past the end of a row recompute its last
-//     cell, so no store needs an exec mask: the per-cell code is straight-line, the only inner
+//   * Ring invariant: a row holds NULL everywhere outside the limits it was last written with (set up
+//     once per alignment, kept by clearing what a slot's previous occupant had beyond the new limits),
+//     so the five reads per cell need no range predicate, and lanes past the end of a row recompute its
+//     last cell, so no store needs an exec mask: the per-cell code is straight-line, the only inner
 //     loop (extend) is wave-uniform.  Validity ballots happen once per score, not per chunk.
 //   * NW == 1: no barrier anywhere in the score loop (LDS operations of one wavefront execute in
-//     order) and the per-row bookkeeping lives in three VGPRs indexed by lane (v_readlane /
-//     v_writelane), not in memory.  NW > 1: one barrier per score.
+//     order) and the per-score bookkeeping lives in three VGPRs indexed by lane (v_readlane), not in
+//     memory; the kernel is compiled for 8 waves per SIMD.  NW > 1: one barrier per score.
 //   * extend(): two 32-bit LDS words per sequence, v_alignbit_b32 to the base position, XOR,
 //     count-trailing-zeros: 16 bases per iteration (4 bytes in the byte-compare instantiation).
 //   * For CIGARs each cell emits ONE origin byte (64 consecutive bytes per wavefront store) into a

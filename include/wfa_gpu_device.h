@@ -98,6 +98,11 @@ void wfagpu_amd_last_stats(const wfagpu_amd_ctx_t* ctx, wfagpu_amd_stats_t* out)
  * visible).  Results stay in input order. */
 void wfagpu_amd_set_num_devices(int n);
 
+/* launch_alignments* keep their per-device state (context, backtrace arena,
+ * input buffers, pinned result staging) for the next call of the process:
+ * allocating it is most of the cost of a cold call.  This frees it. */
+void wfagpu_amd_release_cache(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,28 @@
+"""Times launch_alignments* (the reference's host seam: pageable host buffers in, host results out) on a
+synthetic batch, the way the CLI's wall-time line does (tools/aligner.c:450-474 of the reference)."""
+import ctypes as C
+import os
+import sys
+import time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "wfa-gpu_amd", "bindings"))
+import numpy as np
+import wfagpu
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+length = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+err = float(sys.argv[3]) if len(sys.argv) > 3 else 0.05
+cigar = (sys.argv[4] != "score") if len(sys.argv) > 4 else True
+reps = int(sys.argv[5]) if len(sys.argv) > 5 else 2
+lib = wfagpu.load()
+buf, meta = wfagpu.generate_pairs(n, length, err, seed=7, nthreads=16)
+res = C.POINTER(wfagpu.AlignmentResult)()
+assert lib.initialize_wfa_results(C.byref(res), n, 256)
+opt = wfagpu.Options(max_error=int(length * 0.1 * 3), threads_per_block=64, num_workers=0, band=-1, batch_size=n,
+                     num_alignments=n, penalties=wfagpu.Penalties(2, 3, 1), compute_cigar=cigar)
+fn = lib.launch_alignments if cigar else lib.launch_alignments_distance
+for r in range(reps):
+    t0 = time.perf_counter()
+    fn(buf.ctypes.data, buf.nbytes, meta.ctypes.data, res, opt, False)
+    dt = time.perf_counter() - t0
+    print(f"call {r}: {dt*1e3:.1f} ms  {n/dt/1e6:.2f} M alignments/s  ({'CIGAR' if cigar else 'score'})", flush=True)
+print("first:", res[0].error, C.string_at(res[0].cigar.buffer)[:60] if cigar and res[0].cigar.buffer else "")

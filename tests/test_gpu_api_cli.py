@@ -153,3 +153,21 @@ def test_api_longest_supported_sequences():
     so, co, _ = oracle_lib.oracle_batch(buf, meta, (2, 3, 1), cigar=True, nthreads=4)
     s, c = _api_align(pairs, (2, 3, 1), cigar=True, max_error=200)
     assert np.array_equal(s, so) and c == co
+
+
+def test_cached_device_state_survives_mode_and_size_changes(golden_dir):
+    """launch_alignments* keep per-device state between calls: score-only and CIGAR calls of growing and
+    shrinking batch sizes, with the cache dropped in between, must all give the same answers."""
+    lib = wfagpu.load()
+    lib.wfagpu_amd_release_cache.restype = None
+    pairs = wfagpu.read_seq_file(os.path.join(golden_dir, "seq1k.seq"))[:240]
+    buf, meta = wfagpu.layout_pairs(pairs)
+    so, co, _ = oracle_lib.oracle_batch(buf, meta, (2, 3, 1), cigar=True, nthreads=8)
+    for step, (cigar, batch) in enumerate([(False, 30), (True, 100), (True, 7), (False, None), (True, None), (True, 64)]):
+        if step == 3:
+            lib.wfagpu_amd_release_cache()
+        s, c = _api_align(pairs, (2, 3, 1), cigar=cigar, batch=batch)
+        assert np.array_equal(s, np.asarray(so)), (step, cigar, batch)
+        if cigar:
+            assert c == co, (step, batch)
+    lib.wfagpu_amd_release_cache()

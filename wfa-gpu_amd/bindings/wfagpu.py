@@ -70,7 +70,7 @@ ABI_SYMBOLS = [
     "wfagpu_set_batch_size", "wfagpu_align", "wfagpu_destroy_aligner",
     # include/wfa_gpu_device.h
     "wfagpu_amd_create", "wfagpu_amd_destroy", "wfagpu_amd_fill_packed_offsets", "wfagpu_amd_pack_device",
-    "wfagpu_amd_align_device", "wfagpu_amd_last_stats", "wfagpu_amd_set_num_devices",
+    "wfagpu_amd_align_device", "wfagpu_amd_last_stats", "wfagpu_amd_set_num_devices", "wfagpu_amd_release_cache",
 ]
 
 _lib = None

@@ -15,6 +15,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -94,110 +97,262 @@ int check_batch(const CallArgs& a, size_t from, size_t to, int batch_idx) {
   return incorrect.load() ? 1 : 0;
 }
 
-// One pipeline lane: its own context (stream, device buffers) working through every `stride`-th batch of
-// the shard.  Two lanes per device give the overlap the reference builds by hand with two streams
-// (lib/align.cu:63-68,177-385): while one lane's kernels run, the other lane uploads its next batch or
-// scatters its previous results on the host.
-int run_lane(const CallArgs& a, const Shard& sh, size_t bs, size_t first, size_t stride) {
+// Per-device state that outlives a call: the context (stream, arena, scratch), two input buffers,
+// two sets of pinned result staging.  Allocating them is most of the cost of a cold call (device memory
+// ~33 ms per GiB, pinned host memory similar), so they are kept for the next call of the process and
+// freed by wfagpu_amd_release_cache() or at exit by the OS.  Calls are single-threaded by contract
+// (lib/aligner.h of the reference is not re-entrant); a mutex guards the cache anyway.
+struct DevState {
+  int device = -1;
   wfagpu_amd_ctx_t* ctx = nullptr;
-  wfagpu_amd_config_t cfg{};
-  cfg.device = sh.device;
-  // one-shot call: allocating device memory costs ~33 ms per GiB, so keep the backtrace arena small and
-  // let big batches run in several passes
-  cfg.arena_limit_bytes = (size_t)4 << 30;
-  if (wfagpu_amd_create(&ctx, &cfg)) return -1;
-  HIP_OK(hipSetDevice(sh.device));
-  char* d_seq = nullptr; size_t d_seq_cap = 0;
-  sequence_pair_t* d_meta = nullptr; size_t d_meta_cap = 0;
-  int32_t* d_scores = nullptr; size_t d_scores_cap = 0;
-  std::vector<sequence_pair_t> hm;
-  std::vector<int32_t> hs;
-  std::vector<unsigned long long> hoff;
-  std::vector<unsigned int> hlen;
-  std::vector<char> htext;
-  int rc = 0;
-  for (size_t batch_idx = first; sh.from + batch_idx * bs < sh.to && rc == 0; batch_idx += stride) {
-    const size_t from = sh.from + batch_idx * bs;
-    const size_t to = std::min(sh.to, from + bs);
-    const size_t n = to - from;
-    // span of the batch inside the caller's buffer (lib/align.cu:80-93 takes
-    // it from the first/last record; scanning is robust to any record order)
-    size_t lo = SIZE_MAX, hi = 0;
-    unsigned max_len = 0;
-    for (size_t i = from; i < to; ++i) {
-      const sequence_pair_t& m = a.meta[i];
-      lo = std::min(lo, std::min(m.pattern_offset, m.text_offset));
-      hi = std::max(hi, std::max(m.pattern_offset + m.pattern_len, m.text_offset + m.text_len));
-      max_len = std::max(max_len, std::max(m.pattern_len, m.text_len));
-    }
-    lo &= ~(size_t)3;
-    hi = std::min(a.seq_bytes, (hi + 4) & ~(size_t)3);
-    const size_t span = hi - lo;
-    // packed offsets: written into the caller's metadata like the reference
-    // (lib/align.cu:103-115,363-377), relative to the batch
-    const size_t packed_bytes = wfagpu_amd_fill_packed_offsets(a.meta + from, n);
-    hm.assign(a.meta + from, a.meta + to);
-    for (auto& m : hm) { m.pattern_offset -= lo; m.text_offset -= lo; }
-    if (span + 16 > d_seq_cap) { if (d_seq) hipFree(d_seq); d_seq_cap = span + span / 2 + 16; HIP_OK(hipMalloc(&d_seq, d_seq_cap)); }
-    if (n > d_meta_cap) { if (d_meta) hipFree(d_meta); d_meta_cap = n + n / 2; HIP_OK(hipMalloc(&d_meta, d_meta_cap * sizeof(sequence_pair_t))); }
-    if (n > d_scores_cap) { if (d_scores) hipFree(d_scores); d_scores_cap = n + n / 2; HIP_OK(hipMalloc(&d_scores, d_scores_cap * sizeof(int32_t))); }
-    HIP_OK(hipMemcpy(d_seq, a.seq + lo, span, hipMemcpyHostToDevice));
-    HIP_OK(hipMemcpy(d_meta, hm.data(), n * sizeof(sequence_pair_t), hipMemcpyHostToDevice));
-    wfagpu_amd_batch_t b{};
-    b.d_sequences = d_seq; b.sequences_bytes = span; b.d_metadata = d_meta; b.num_pairs = n;
-    b.packed_bytes = packed_bytes; b.max_seq_len = max_len;
-    const char* d_text = nullptr; const unsigned long long* d_off = nullptr; const unsigned int* d_len = nullptr;
-    const int arc = wfagpu_amd_align_device(ctx, &b, a.opt.penalties, a.opt.max_error, a.opt.band, a.opt.threads_per_block, a.cigar, d_scores,
-                                            &d_text, &d_off, &d_len);
-    if (arc) { rc = arc; break; }
-    hs.resize(n);
-    HIP_OK(hipMemcpy(hs.data(), d_scores, n * sizeof(int32_t), hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < n; ++i) a.results[from + i].error = (unsigned int)hs[i];
-    if (a.cigar) {
-      wfagpu_amd_stats_t stt; wfagpu_amd_last_stats(ctx, &stt);
-      hoff.resize(n); hlen.resize(n); htext.resize(stt.text_bytes + 1);
-      HIP_OK(hipMemcpy(hoff.data(), d_off, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-      HIP_OK(hipMemcpy(hlen.data(), d_len, n * sizeof(unsigned int), hipMemcpyDeviceToHost));
-      if (stt.text_bytes) HIP_OK(hipMemcpy(htext.data(), d_text, stt.text_bytes, hipMemcpyDeviceToHost));
-      for (size_t i = 0; i < n; ++i) {
-        wfa_cigar_t& cg = a.results[from + i].cigar;
-        if (hlen[i] == 0xFFFFFFFFu) { LOG_ERROR("CIGAR recovery failed for pair %zu", from + i); rc = -1; continue; }
-        const size_t need = (size_t)hlen[i] + 1;
-        if (need > cg.buffer_size || !cg.buffer) {
-          char* nb = static_cast<char*>(realloc(cg.buffer, need));
-          if (!nb) { LOG_ERROR("Can not realloc CIGAR buffer"); exit(-1); }   // utils/wfa_cpu.c:77-80
-          cg.buffer = nb; cg.buffer_size = need;
-        }
-        memcpy(cg.buffer, htext.data() + hoff[i], need);
-        cg.last_free_position = hlen[i];
-      }
-    }
-    if (a.check && rc == 0) check_batch(a, from, to, (int)batch_idx);
+  hipStream_t up = nullptr, down = nullptr;   // copy streams (H2D of the next batch, D2H of the last)
+  struct In { char* d_seq = nullptr; size_t seq_cap = 0; sequence_pair_t* d_meta = nullptr; size_t meta_cap = 0; } in[2];
+  int32_t* d_scores = nullptr; size_t scores_cap = 0;
+  struct Out {
+    char* text = nullptr; size_t text_cap = 0;
+    unsigned long long* off = nullptr; unsigned int* len = nullptr; size_t cig_cap = 0;   // CIGAR calls only
+    int32_t* score = nullptr; size_t n_cap = 0;
+  } out[2];
+};
+constexpr int MAX_DEV = 64;
+DevState g_dev[MAX_DEV];
+std::mutex g_dev_mu[MAX_DEV];   // one per device: the shards of a call run concurrently
+
+void release_dev(DevState& d) {
+  if (d.device < 0) return;
+  (void)hipSetDevice(d.device);
+  for (auto& in : d.in) { if (in.d_seq) (void)hipFree(in.d_seq); if (in.d_meta) (void)hipFree(in.d_meta); in = {}; }
+  if (d.d_scores) (void)hipFree(d.d_scores);
+  for (auto& o : d.out) {
+    if (o.text) (void)hipHostFree(o.text);
+    if (o.off) (void)hipHostFree(o.off);
+    if (o.len) (void)hipHostFree(o.len);
+    if (o.score) (void)hipHostFree(o.score);
+    o = {};
   }
-  if (d_seq) hipFree(d_seq);
-  if (d_meta) hipFree(d_meta);
-  if (d_scores) hipFree(d_scores);
-  wfagpu_amd_destroy(ctx);
-  return rc;
+  if (d.up) (void)hipStreamDestroy(d.up);
+  if (d.down) (void)hipStreamDestroy(d.down);
+  if (d.ctx) wfagpu_amd_destroy(d.ctx);
+  d.device = -1; d.ctx = nullptr; d.up = d.down = nullptr; d.d_scores = nullptr; d.scores_cap = 0;
 }
 
+int acquire_dev(int device, DevState** out) {
+  if (device < 0 || device >= MAX_DEV) return -1;
+  DevState& d = g_dev[device];
+  if (d.device == device && d.ctx) { *out = &d; return 0; }
+  HIP_OK(hipSetDevice(device));
+  wfagpu_amd_config_t cfg{};
+  cfg.device = device;
+  // device allocation costs ~33 ms per GiB, so keep the backtrace arena small and let big batches run in
+  // several passes
+  cfg.arena_limit_bytes = (size_t)4 << 30;
+  if (const char* e = getenv("WFAGPU_ARENA_LIMIT_MB")) cfg.arena_limit_bytes = (size_t)atol(e) << 20;
+  if (wfagpu_amd_create(&d.ctx, &cfg)) return -1;
+  d.device = device;
+  HIP_OK(hipStreamCreateWithFlags(&d.up, hipStreamNonBlocking));
+  HIP_OK(hipStreamCreateWithFlags(&d.down, hipStreamNonBlocking));
+  *out = &d;
+  return 0;
+}
+
+template <typename T> int grow_pinned(T** p, size_t want_elems) {
+  if (*p) (void)hipHostFree(*p);
+  *p = nullptr;
+  HIP_OK(hipHostMalloc(reinterpret_cast<void**>(p), want_elems * sizeof(T), hipHostMallocDefault));
+  return 0;
+}
+
+struct BatchPlan {
+  size_t from, to, lo, span, packed_bytes;
+  unsigned max_len;
+  unsigned long long text_bytes = 0;
+};
+
+// One device's slice of a call as a three-stage pipeline over its batches (the reference overlaps the
+// same phases by hand with two streams, lib/align.cu:63-68,177-385):
+//   uploader thread : packed offsets + metadata rebasing + H2D into input buffer i % 2
+//   this thread     : wfagpu_amd_align_device (all kernels), then D2H into pinned staging i % 2
+//   scatter thread  : staging -> the caller's wfa_alignment_result_t records (+ the -c check)
 int run_shard(const CallArgs& a, Shard& sh) {
   if (sh.from >= sh.to) return 0;
-  const size_t n = sh.to - sh.from;
-  size_t bs = a.opt.batch_size ? std::min<size_t>(a.opt.batch_size, n) : n;
+  const bool timing = getenv("WFAGPU_TIMING") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_begin = now();
+  if (sh.device < 0 || sh.device >= MAX_DEV) return -1;
+  std::lock_guard<std::mutex> guard(g_dev_mu[sh.device]);
+  DevState* dp = nullptr;
+  if (acquire_dev(sh.device, &dp)) return -1;
+  DevState& d = *dp;
+  HIP_OK(hipSetDevice(sh.device));
+  const double t_created = now();
+
+  const size_t n_all = sh.to - sh.from;
+  size_t bs = a.opt.batch_size ? std::min<size_t>(a.opt.batch_size, n_all) : n_all;
   bs = std::max<size_t>(1, bs);
-  // a single huge batch is cut in four so that the two lanes have something to overlap
-  if (bs == n && n >= ((size_t)1 << 18) && !a.cigar) bs = (n + 3) / 4;
-  const size_t nbatches = (n + bs - 1) / bs;
-  // CIGAR mode allocates a backtrace arena per lane, and device allocation (~33 ms per GiB) is not
-  // something a second lane can hide: measured 0.27 s (one lane) vs 0.39 s (two) per 1M 1 kbp pairs;
-  // score-only runs gain from the overlap (0.174 -> 0.156 s)
-  if (nbatches < 2 || a.cigar) return run_lane(a, sh, bs, 0, 1);
-  int rc[2] = {0, 0};
-  std::thread other([&] { rc[1] = run_lane(a, sh, bs, 1, 2); });
-  rc[0] = run_lane(a, sh, bs, 0, 2);
-  other.join();
-  return rc[0] ? rc[0] : rc[1];
+  // a single huge batch is cut in four so that the stages have something to overlap
+  if (bs == n_all && n_all >= ((size_t)1 << 17)) bs = (n_all + 3) / 4;
+  std::vector<BatchPlan> plan;
+  for (size_t from = sh.from; from < sh.to; from += bs) { BatchPlan b{}; b.from = from; b.to = std::min(sh.to, from + bs); plan.push_back(b); }
+  const int nb = (int)plan.size();
+
+  std::mutex mu;
+  std::condition_variable cv;
+  int uploaded = 0, computed = 0, scattered = 0;   // batches that finished each stage
+  std::atomic<int> rc{0};
+  double t_up = 0, t_dev = 0, t_d2h = 0, t_scatter = 0;
+  auto advance = [&](int& counter) { { std::lock_guard<std::mutex> l(mu); ++counter; } cv.notify_all(); };
+  auto wait_for = [&](const int& counter, int at_least) {
+    std::unique_lock<std::mutex> l(mu);
+    cv.wait(l, [&] { return counter >= at_least || rc.load() != 0; });
+    return rc.load() == 0;
+  };
+  auto fail = [&](int code) { rc.store(code); cv.notify_all(); };
+
+  std::thread uploader([&] {
+    if (hipSetDevice(sh.device) != hipSuccess) { fail(-1); return; }
+    std::vector<sequence_pair_t> hm;
+    for (int i = 0; i < nb; ++i) {
+      if (!wait_for(computed, i - 1)) return;           // input buffer i % 2 is free once batch i-2 has been computed
+      const double t0 = now();
+      BatchPlan& b = plan[i];
+      const size_t n = b.to - b.from;
+      // span of the batch inside the caller's buffer (lib/align.cu:80-93 takes it from the first/last
+      // record; scanning is robust to any record order)
+      size_t lo = SIZE_MAX, hi = 0;
+      unsigned max_len = 0;
+      for (size_t j = b.from; j < b.to; ++j) {
+        const sequence_pair_t& m = a.meta[j];
+        lo = std::min(lo, std::min(m.pattern_offset, m.text_offset));
+        hi = std::max(hi, std::max(m.pattern_offset + m.pattern_len, m.text_offset + m.text_len));
+        max_len = std::max(max_len, std::max(m.pattern_len, m.text_len));
+      }
+      lo &= ~(size_t)3;
+      hi = std::min(a.seq_bytes, (hi + 4) & ~(size_t)3);
+      b.lo = lo; b.span = hi - lo; b.max_len = max_len;
+      // packed offsets: written into the caller's metadata like the reference
+      // (lib/align.cu:103-115,363-377), relative to the batch
+      b.packed_bytes = wfagpu_amd_fill_packed_offsets(a.meta + b.from, n);
+      hm.assign(a.meta + b.from, a.meta + b.to);
+      for (auto& m : hm) { m.pattern_offset -= lo; m.text_offset -= lo; }
+      DevState::In& in = d.in[i & 1];
+      auto ok = [&](hipError_t e, const char* what) { if (e != hipSuccess) { LOG_ERROR("HIP call %s failed: %s", what, hipGetErrorString(e)); fail(-1); return false; } return true; };
+      if (b.span + 16 > in.seq_cap) {
+        if (in.d_seq) (void)hipFree(in.d_seq);
+        in.d_seq = nullptr; in.seq_cap = b.span + b.span / 8 + 16;
+        if (!ok(hipMalloc(&in.d_seq, in.seq_cap), "hipMalloc(sequences)")) return;
+      }
+      if (n > in.meta_cap) {
+        if (in.d_meta) (void)hipFree(in.d_meta);
+        in.d_meta = nullptr; in.meta_cap = n + n / 8;
+        if (!ok(hipMalloc(&in.d_meta, in.meta_cap * sizeof(sequence_pair_t)), "hipMalloc(metadata)")) return;
+      }
+      if (!ok(hipMemcpyAsync(in.d_seq, a.seq + lo, b.span, hipMemcpyHostToDevice, d.up), "H2D sequences")) return;
+      if (!ok(hipMemcpyAsync(in.d_meta, hm.data(), n * sizeof(sequence_pair_t), hipMemcpyHostToDevice, d.up), "H2D metadata")) return;
+      if (!ok(hipStreamSynchronize(d.up), "H2D sync")) return;
+      t_up += now() - t0;
+      advance(uploaded);
+    }
+  });
+
+  std::thread scatterer([&] {
+    for (int i = 0; i < nb; ++i) {
+      if (!wait_for(computed, i + 1)) return;
+      const double t0 = now();
+      const BatchPlan& b = plan[i];
+      const size_t n = b.to - b.from;
+      const DevState::Out& o = d.out[i & 1];
+      std::atomic<int> bad{0};
+      auto work = [&](size_t j0, size_t j1) {
+        for (size_t j = j0; j < j1; ++j) {
+          wfa_alignment_result_t& r = a.results[b.from + j];
+          r.error = (unsigned int)o.score[j];
+          if (!a.cigar) continue;
+          if (o.len[j] == 0xFFFFFFFFu) { LOG_ERROR("CIGAR recovery failed for pair %zu", b.from + j); bad.store(1); continue; }
+          wfa_cigar_t& cg = r.cigar;
+          const size_t need = (size_t)o.len[j] + 1;
+          if (need > cg.buffer_size || !cg.buffer) {
+            char* nbuf = static_cast<char*>(realloc(cg.buffer, need));
+            if (!nbuf) { LOG_ERROR("Can not realloc CIGAR buffer"); exit(-1); }   // utils/wfa_cpu.c:77-80
+            cg.buffer = nbuf; cg.buffer_size = need;
+          }
+          memcpy(cg.buffer, o.text + o.off[j], need);
+          cg.last_free_position = o.len[j];
+        }
+      };
+      const unsigned nt = a.cigar ? (unsigned)std::min<size_t>(std::max(1u, std::min(8u, std::thread::hardware_concurrency())), (n + 8191) / 8192) : 1u;
+      if (nt <= 1) work(0, n);
+      else {
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < nt; ++t) pool.emplace_back(work, n * t / nt, n * (t + 1) / nt);
+        work(0, n / nt);
+        for (auto& t : pool) t.join();
+      }
+      if (bad.load()) { fail(-1); return; }
+      if (a.check) check_batch(a, b.from, b.to, i);
+      t_scatter += now() - t0;
+      advance(scattered);
+    }
+  });
+
+  auto compute = [&]() -> int {
+    for (int i = 0; i < nb; ++i) {
+      if (!wait_for(uploaded, i + 1)) return rc.load();
+      double t0 = now();
+      BatchPlan& b = plan[i];
+      const size_t n = b.to - b.from;
+      DevState::In& in = d.in[i & 1];
+      if (n > d.scores_cap) {
+        if (d.d_scores) (void)hipFree(d.d_scores);
+        d.d_scores = nullptr; d.scores_cap = n + n / 8;
+        HIP_OK(hipMalloc(&d.d_scores, d.scores_cap * sizeof(int32_t)));
+      }
+      wfagpu_amd_batch_t wb{};
+      wb.d_sequences = in.d_seq; wb.sequences_bytes = b.span; wb.d_metadata = in.d_meta; wb.num_pairs = n;
+      wb.packed_bytes = b.packed_bytes; wb.max_seq_len = b.max_len;
+      const char* d_text = nullptr; const unsigned long long* d_off = nullptr; const unsigned int* d_len = nullptr;
+      const int arc = wfagpu_amd_align_device(d.ctx, &wb, a.opt.penalties, a.opt.max_error, a.opt.band, a.opt.threads_per_block, a.cigar,
+                                              d.d_scores, &d_text, &d_off, &d_len);
+      if (arc) return arc;
+      t_dev += now() - t0; t0 = now();
+      if (!wait_for(scattered, i - 1)) return rc.load();   // staging i % 2 is free once batch i-2 has been scattered
+      DevState::Out& o = d.out[i & 1];
+      if (n > o.n_cap) {
+        const size_t cap = n + n / 8;
+        if (grow_pinned(&o.score, cap)) return -1;
+        o.n_cap = cap;
+      }
+      if (a.cigar && n > o.cig_cap) {
+        const size_t cap = n + n / 8;
+        if (grow_pinned(&o.off, cap) || grow_pinned(&o.len, cap)) return -1;
+        o.cig_cap = cap;
+      }
+      HIP_OK(hipMemcpyAsync(o.score, d.d_scores, n * sizeof(int32_t), hipMemcpyDeviceToHost, d.down));
+      if (a.cigar) {
+        wfagpu_amd_stats_t stt; wfagpu_amd_last_stats(d.ctx, &stt);
+        b.text_bytes = stt.text_bytes;
+        if (stt.text_bytes + 1 > o.text_cap) {
+          const size_t cap = (size_t)stt.text_bytes + (size_t)stt.text_bytes / 8 + 4096;
+          if (grow_pinned(&o.text, cap)) return -1;
+          o.text_cap = cap;
+        }
+        HIP_OK(hipMemcpyAsync(o.off, d_off, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, d.down));
+        HIP_OK(hipMemcpyAsync(o.len, d_len, n * sizeof(unsigned int), hipMemcpyDeviceToHost, d.down));
+        if (stt.text_bytes) HIP_OK(hipMemcpyAsync(o.text, d_text, stt.text_bytes, hipMemcpyDeviceToHost, d.down));
+      }
+      HIP_OK(hipStreamSynchronize(d.down));
+      t_d2h += now() - t0;
+      advance(computed);
+    }
+    return 0;
+  };
+  const int crc = compute();
+  if (crc) fail(crc);
+  uploader.join();
+  scatterer.join();
+  if (timing)
+    fprintf(stderr, "[wfagpu timing] device %d: %d batches, acquire %.1f ms, upload %.1f, device %.1f, d2h %.1f, scatter %.1f (overlapped), total %.1f\n",
+            sh.device, nb, t_created - t_begin, t_up, t_dev, t_d2h, t_scatter, now() - t_begin);
+  return rc.load();
 }
 
 void launch_impl(char* seq, size_t seq_bytes, sequence_pair_t* meta, wfa_alignment_result_t* results,
@@ -236,6 +391,13 @@ void launch_impl(char* seq, size_t seq_bytes, sequence_pair_t* meta, wfa_alignme
 extern "C" {
 
 void wfagpu_amd_set_num_devices(int n) { g_num_devices.store(n < 0 ? 0 : n); }
+
+void wfagpu_amd_release_cache(void) {
+  for (int i = 0; i < MAX_DEV; ++i) {
+    std::lock_guard<std::mutex> guard(g_dev_mu[i]);
+    release_dev(g_dev[i]);
+  }
+}
 
 void launch_alignments(char* sequences_buffer, const size_t sequences_buffer_size,
                        sequence_pair_t* const sequences_metadata,

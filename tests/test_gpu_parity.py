@@ -266,3 +266,51 @@ def test_randomised_penalties_and_shapes(aligner):
             assert c == co, (pen, max_error)
         s2, _ = _run(aligner, buf, meta, pen, max_error=40, cigar=False)
         assert np.array_equal(s2, so), pen
+
+
+@pytest.mark.parametrize("min_tier", [1, 2, 3])
+def test_every_tier_gives_the_same_answers(min_tier, monkeypatch):
+    """The 4-wave, 16-wave and HBM-ring (16-bit offsets) instantiations on a ragged set that the one-wave tier
+    normally takes: WFAGPU_MIN_TIER makes the planner skip the smaller tiers."""
+    monkeypatch.setenv("WFAGPU_MIN_TIER", str(min_tier))
+    rng = random.Random(1234 + min_tier)
+    pairs = _rand_pairs(rng, 96, 400, err=0.08)
+    pairs += [(b"ACGT" * 50, b"ACGT" * 20), (b"", b"ACGTAC"), (b"GATTACA", b""), (b"A" * 300, b"A" * 299 + b"C")]
+    buf, meta = wfagpu.layout_pairs(pairs)
+    for pen in ((2, 3, 1), (4, 6, 2)):
+        so, co, _ = oracle_lib.oracle_batch(buf, meta, pen, cigar=True, nthreads=8)
+        al = wfagpu.DeviceAligner(0)
+        try:
+            s, c = _run(al, buf, meta, pen, max_error=600)
+            st = al.stats()
+            assert sum(st.pairs_tier[t] for t in range(min_tier)) == 0, list(st.pairs_tier)
+            assert np.array_equal(s, so) and c == co, (min_tier, pen)
+            s2, _ = _run(al, buf, meta, pen, max_error=600, cigar=False)
+            assert np.array_equal(s2, so)
+        finally:
+            al.close()
+
+
+def test_sequences_beyond_16_bit_offsets():
+    """A pair longer than 32766 bases cannot use 16-bit offsets: the HBM-ring tier with 32-bit offsets takes it."""
+    rng = random.Random(99)
+    base = bytes(rng.choice(b"ACGT") for _ in range(33500))
+    other = bytearray(base)
+    for pos in sorted(rng.sample(range(100, 33000), 12), reverse=True):
+        r = rng.random()
+        if r < 0.4:
+            other[pos] = ord("A") if other[pos] != ord("A") else ord("C")
+        elif r < 0.7:
+            del other[pos]
+        else:
+            other.insert(pos, ord("G"))
+    pairs = [(base, bytes(other)), (base[:2000], bytes(other[:2100]))]
+    buf, meta = wfagpu.layout_pairs(pairs)
+    so, co, _ = oracle_lib.oracle_batch(buf, meta, (2, 3, 1), cigar=True, nthreads=2)
+    al = wfagpu.DeviceAligner(0)
+    try:
+        s, c = _run(al, buf, meta, (2, 3, 1), max_error=200)
+        assert list(al.stats().pairs_tier)[3] >= 1
+        assert np.array_equal(s, so) and c == co
+    finally:
+        al.close()

@@ -662,7 +662,10 @@ void launch_tier(const WfaAlignParams& p, int tier, size_t lds, int grid, hipStr
     case 0: launch_inst<1, BT, int16_t, false, RAW, false>(p, lds, grid, stream); break;
     case 1: launch_inst<4, BT, int16_t, false, RAW, false>(p, lds, grid, stream); break;
     case 2: launch_inst<16, BT, int16_t, false, RAW, false>(p, lds, grid, stream); break;
-    default: launch_inst<16, BT, int32_t, true, RAW, false>(p, lds, grid, stream); break;
+    default:
+      if (p.ring16) launch_inst<16, BT, int16_t, true, RAW, false>(p, lds, grid, stream);
+      else launch_inst<16, BT, int32_t, true, RAW, false>(p, lds, grid, stream);
+      break;
   }
 }
 template <bool BT>

@@ -75,6 +75,7 @@ struct WfaAlignParams {
   uint32_t* bt_final_row;        // [pair] out: unit offset of the pair's row table
   // global-memory ring (only the GLOBAL_RING instantiation)
   void* gring;                   // per-block slices of gring_stride bytes
+  int ring16;                    //   16-bit offsets in it (sequences <= 32766 bases), else 32-bit
   unsigned long long gring_stride;
 };
 
@@ -106,7 +107,7 @@ struct WfaTraceParams {
 void wfa_launch_pack(const char* d_ascii, const WfaSeqPair* d_meta, uint32_t n_pairs,
                      uint32_t* d_packed, uint8_t* d_flags, hipStream_t stream);
 // tier: 0 -> 1 wave/alignment (LDS ring), 1 -> 4 waves (LDS), 2 -> 16 waves (LDS),
-//       3 -> 16 waves, int32 ring in HBM.  Returns the dynamic LDS bytes used.
+//       3 -> 16 waves, ring in HBM (int16 or int32 offsets, WfaAlignParams::ring16).  Returns the dynamic LDS bytes used.
 size_t wfa_align_lds_bytes(const WfaAlignParams& p, int tier);
 void wfa_launch_align(const WfaAlignParams& p, int tier, bool with_bt, bool raw, int grid, hipStream_t stream);
 int wfa_align_max_blocks_per_cu(int tier, bool with_bt, bool raw, bool banded, size_t lds_bytes);

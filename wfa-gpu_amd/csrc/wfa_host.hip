@@ -285,7 +285,9 @@ bool plan_tier(const wfagpu_amd_ctx* c, WfaAlignParams& p, int max_score, unsign
   p.rs = (width + 3 + 1) & ~1;
   const bool i16_ok = max_seq_len <= 32766u && max_score <= 30000;
   const size_t budget[3] = {40u << 10, 80u << 10, c->lds_per_block_max};
-  for (int t = 0; t < 3 && i16_ok; ++t) {
+  // WFAGPU_MIN_TIER (tests): skip the smaller tiers so that the rarely needed ones get exercised
+  const char* env_min = getenv("WFAGPU_MIN_TIER");
+  for (int t = env_min ? atoi(env_min) : 0; t < 3 && i16_ok; ++t) {
     const size_t lds = wfa_align_lds_bytes(p, t);
     if (lds > budget[t]) continue;
     // a single wavefront sweeps up to ~16 chunks per score before more waves pay off
@@ -445,7 +447,8 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         return -1;
       }
       if (tp.tier == 3) {
-        const size_t stride = (((size_t)(ap.dm + 2 * ap.de) * ap.rs * 4) + 255) & ~(size_t)255;
+        ap.ring16 = max_len <= 32766u ? 1 : 0;
+        const size_t stride = (((size_t)(ap.dm + 2 * ap.de) * ap.rs * (ap.ring16 ? 2 : 4)) + 255) & ~(size_t)255;
         const int grid = (int)std::min<uint32_t>(n_cur, (uint32_t)(c->num_cus * tp.blocks_per_cu));
         if (c->gring.ensure(stride * grid, st)) return -1;
         ap.gring = c->gring.p; ap.gring_stride = stride;

@@ -9,8 +9,8 @@
 // (external/WFA/alignment/cigar.c:394-426): run-length "nM nX nI nD" items.
 //
 // One lane per alignment.  Phase 1 walks the origin bytes written by the
-// align kernel backwards (row headers link score s to s-x / s-o-e / s-e) and
-// pushes one byte per edit operation.  Phase 2 replays the operations
+// align kernel backwards (the alignment's row table locates the rows of
+// scores s-x / s-o-e / s-e) and pushes one byte per edit operation.  Phase 2 replays the operations
 // forwards, re-deriving every match run as a longest-common-prefix on the
 // packed sequences -- identical to the extension the forward pass did, so no
 // offsets had to be stored -- first to size the text, then to write it.

@@ -1,0 +1,60 @@
+"""Randomised differential soak against the oracle (scores and CIGARs), wider than tests/test_gpu_parity.py's
+stress test: more penalty triples, lengths, error rates, budgets; score-only and CIGAR; tier override."""
+import os, random, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "wfa-gpu_amd", "bindings")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch, wfagpu, oracle_lib
+
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+rng = random.Random(seed)
+
+
+def rand_pairs(n, maxlen, err):
+    out = []
+    for _ in range(n):
+        L = rng.randint(0, maxlen)
+        t = bytes(rng.choice(b"ACGT") for _ in range(L))
+        p = bytearray(t)
+        for _ in range(int(L * err) + rng.randint(0, 2)):
+            op = rng.randint(0, 3)
+            if op == 0 and p:
+                p[rng.randrange(len(p))] = rng.choice(b"ACGT")
+            elif op == 1 and p:
+                a = rng.randrange(len(p)); del p[a:a + rng.randint(1, 6)]
+            elif op == 2:
+                a = rng.randint(0, len(p)); p[a:a] = bytes(rng.choice(b"ACGT") for _ in range(rng.randint(1, 6)))
+            else:
+                p.insert(rng.randint(0, len(p)), rng.choice(b"ACGT"))
+        out.append((bytes(p), t) if rng.random() < 0.5 else (t, bytes(p)))
+    return out
+
+
+al = wfagpu.DeviceAligner(0)
+bad = 0
+t0 = time.time()
+for it in range(iters):
+    pen = (rng.randint(1, 12), rng.randint(0, 15), rng.randint(1, 8))
+    maxlen = rng.choice([40, 150, 400, 900, 2500])
+    pairs = rand_pairs(rng.choice([64, 200, 600]), maxlen, rng.choice([0.0, 0.02, 0.08, 0.2, 0.5]))
+    pairs += [(b"", b""), (b"A", b""), (b"", b"ACGT" * 5), (b"ACGT" * 30, b"TGCA" * 30)]
+    if rng.random() < 0.3:
+        pairs += [(bytes(rng.choice(b"ACGTN") for _ in range(rng.randint(1, 200))), bytes(rng.choice(b"ACGTNacgt") for _ in range(rng.randint(1, 200)))) for _ in range(20)]
+    buf, meta = wfagpu.layout_pairs(pairs)
+    so, co, _ = oracle_lib.oracle_batch(buf, meta, pen, cigar=True, nthreads=16)
+    os.environ.pop("WFAGPU_MIN_TIER", None)
+    if rng.random() < 0.25:
+        os.environ["WFAGPU_MIN_TIER"] = str(rng.randint(1, 3))
+    batch = al.upload(buf, meta)
+    for max_error in (rng.choice([1, 5, 20]), rng.choice([60, 200, 1000]), 20000):
+        s, c = al.align(batch, pen, max_error=max_error, compute_cigar=True)
+        if not np.array_equal(s, so) or c != co:
+            bad += 1
+            k = next(i for i in range(len(pairs)) if s[i] != so[i] or c[i] != co[i])
+            print("MISMATCH it", it, "pen", pen, "max_error", max_error, "tier", os.environ.get("WFAGPU_MIN_TIER"), "pair", k, pairs[k], s[k], so[k], c[k], co[k], flush=True)
+    s2, _ = al.align(batch, pen, max_error=rng.choice([3, 50, 3000]), compute_cigar=False)
+    if not np.array_equal(s2, so):
+        bad += 1
+        print("SCORE MISMATCH it", it, "pen", pen, flush=True)
+print("soak seed", seed, "iterations", iters, "mismatching runs", bad, "%.1f s" % (time.time() - t0))
+sys.exit(1 if bad else 0)

@@ -17,23 +17,22 @@
 
 namespace {
 
-__device__ __forceinline__ uint32_t pack4(uint32_t w) {
-  // four ASCII bytes -> 8 bits, first byte in the low bits
-  uint32_t t = (w >> 1) & 0x03030303u;
-  t = (t | (t >> 6)) & 0x000F000Fu;
+__device__ __forceinline__ uint32_t code4(uint32_t w) {
+  // 2-bit code of each of four ASCII bytes, in place: (c & 6) >> 1
+  return (w >> 1) & 0x03030303u;
+}
+
+__device__ __forceinline__ uint32_t pack4(uint32_t codes) {
+  // four byte-wide codes -> 8 bits, first byte in the low bits
+  uint32_t t = (codes | (codes >> 6)) & 0x000F000Fu;
   t = (t | (t >> 12)) & 0xFFu;
   return t;
 }
 
-__device__ __forceinline__ uint32_t bad4(uint32_t w) {
-  // non-zero if any of the four bytes is not one of A C G T
-  uint32_t bad = 0;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const uint32_t c = (w >> (8 * i)) & 0xFFu;
-    bad |= (c != 'A') & (c != 'C') & (c != 'G') & (c != 'T');
-  }
-  return bad;
+__device__ __forceinline__ bool bad4(uint32_t w, uint32_t codes) {
+  // true if any of the four bytes is not one of A C G T: v_perm_b32 maps every code back to its
+  // letter (byte table "ACTG"), which must reproduce the input
+  return __builtin_amdgcn_perm(0x47544341u, 0x47544341u, codes) != w;
 }
 
 constexpr int PACK_WAVES = 4;
@@ -58,20 +57,30 @@ wfa_pack_kernel(const char* __restrict__ ascii, const WfaSeqPair* __restrict__ m
     uint32_t out = 0;
     if (w < n_words) {
       const uint32_t base = w << 4;             // first base of this word
+      if (base + 16u <= len) {
+        // all 16 bases present: four unconditional dword loads (one 16-byte access)
+        const uint32_t* q4 = src + (base >> 2);
+        const uint32_t a0 = q4[0], a1 = q4[1], a2 = q4[2], a3 = q4[3];
+        const uint32_t c0 = code4(a0), c1 = code4(a1), c2 = code4(a2), c3 = code4(a3);
+        bad |= (bad4(a0, c0) || bad4(a1, c1) || bad4(a2, c2) || bad4(a3, c3)) ? 1u : 0u;
+        out = pack4(c0) | (pack4(c1) << 8) | (pack4(c2) << 16) | (pack4(c3) << 24);
+      } else {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const uint32_t b = base + 4u * q;
-        if (b < len) {
-          uint32_t a = src[(base >> 2) + q];
-          const uint32_t nvalid = len - b;       // >= 1
-          if (nvalid < 4) {
-            // bytes past the end are the buffer's NUL padding or the next
-            // sequence: neutralise them with 'A' (code 0)
-            const uint32_t keep = (1u << (8 * nvalid)) - 1u;
-            a = (a & keep) | (0x41414141u & ~keep);
+        for (int q = 0; q < 4; ++q) {
+          const uint32_t b = base + 4u * q;
+          if (b < len) {
+            uint32_t a = src[(base >> 2) + q];
+            const uint32_t nvalid = len - b;       // >= 1
+            if (nvalid < 4) {
+              // bytes past the end are the buffer's NUL padding or the next
+              // sequence: neutralise them with 'A' (code 0)
+              const uint32_t keep = (1u << (8 * nvalid)) - 1u;
+              a = (a & keep) | (0x41414141u & ~keep);
+            }
+            const uint32_t c4 = code4(a);
+            bad |= bad4(a, c4) ? 1u : 0u;
+            out |= pack4(c4) << (8 * q);
           }
-          bad |= bad4(a);
-          out |= pack4(a) << (8 * q);
         }
       }
     }

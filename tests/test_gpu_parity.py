@@ -314,3 +314,14 @@ def test_sequences_beyond_16_bit_offsets():
         assert np.array_equal(s, so) and c == co
     finally:
         al.close()
+
+
+def test_zero_and_negative_budgets_still_finish(aligner):
+    """max_error is only a sizing hint: 0 or a negative value must not stall the escalation."""
+    rng = random.Random(3)
+    pairs = _rand_pairs(rng, 64, 200, err=0.1) + [(b"", b""), (b"ACGT", b"ACGT")]
+    buf, meta = wfagpu.layout_pairs(pairs)
+    so, co, _ = oracle_lib.oracle_batch(buf, meta, (2, 3, 1), cigar=True, nthreads=8)
+    for me in (0, -5):
+        s, c = _run(aligner, buf, meta, (2, 3, 1), max_error=me)
+        assert np.array_equal(s, so) and c == co, me

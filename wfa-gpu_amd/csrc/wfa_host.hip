@@ -489,7 +489,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       // widen: 4x the score budget (and with it the diagonal window); beyond what 16-bit offsets
       // allow the last resort is the unbounded 32-bit tier
       if (max_score >= 30000 || max_len > 32766u) max_score = INT_MAX;
-      else max_score = (int)std::min<long long>(30000, 4ll * max_score);
+      else max_score = (int)std::min<long long>(30000, std::max<long long>(16, 4ll * max_score));   // (a budget of 0 must grow too)
     }
     // ---- backtrace + CIGAR for everything that finished in this pass ---------
     if (zero_counter(c, CT_SUM_OPS, 2)) return -1;

@@ -1,0 +1,47 @@
+"""Soak of the adaptive-band kernels: every result must be a valid alignment (CIGAR replays onto both sequences,
+its gap-affine cost equals the reported score), never better than the optimum, and identical between two runs
+and between score-only and CIGAR mode."""
+import os, random, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "wfa-gpu_amd", "bindings")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch, wfagpu, oracle_lib
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+rng = random.Random(seed)
+al = wfagpu.DeviceAligner(0)
+bad = 0; worse = 0; total = 0
+for it in range(iters):
+    pen = (rng.randint(1, 8), rng.randint(0, 10), rng.randint(1, 5))
+    L = rng.choice([300, 1200, 4000])
+    n = rng.choice([32, 128])
+    err = rng.choice([0.01, 0.05, 0.15])
+    pairs = []
+    for _ in range(n):
+        t = bytes(rng.choice(b"ACGT") for _ in range(rng.randint(L // 2, L)))
+        p = bytearray(t)
+        for _ in range(int(len(t) * err)):
+            op = rng.randint(0, 2)
+            if op == 0 and p: p[rng.randrange(len(p))] = rng.choice(b"ACGT")
+            elif op == 1 and p:
+                a = rng.randrange(len(p)); del p[a:a + rng.randint(1, 12)]
+            else:
+                a = rng.randint(0, len(p)); p[a:a] = bytes(rng.choice(b"ACGT") for _ in range(rng.randint(1, 12)))
+        pairs.append((bytes(p), t))
+    buf, meta = wfagpu.layout_pairs(pairs)
+    so, _, _ = oracle_lib.oracle_batch(buf, meta, pen, cigar=False, nthreads=16)
+    batch = al.upload(buf, meta)
+    beta = rng.choice([64, 128, 256, 512, 1024]); lam = rng.choice([1, 10, 25, 50, 750])
+    me = int(L * 0.3 * max(pen))
+    s1, c1 = al.align(batch, pen, max_error=me, compute_cigar=True, band=lam, band_width=beta)
+    s2, c2 = al.align(batch, pen, max_error=me, compute_cigar=True, band=lam, band_width=beta)
+    s3, _ = al.align(batch, pen, max_error=me, compute_cigar=False, band=lam, band_width=beta)
+    if not (np.array_equal(s1, s2) and c1 == c2 and np.all(s1 <= s3)):
+        bad += 1; print("NONDETERMINISTIC it", it, pen, beta, lam, flush=True)
+    for (p, t), cg, sc, opt in zip(pairs, c1, s1, so):
+        ok, cost = oracle_lib.check_cigar(p, t, cg, pen)
+        total += 1
+        if not ok or cost != sc or sc < opt:
+            bad += 1; print("INVALID it", it, pen, beta, lam, len(p), len(t), sc, opt, ok, cost, flush=True); break
+        worse += sc > opt
+print("banded soak seed", seed, "iterations", iters, "pairs", total, "failures", bad, "above optimum %.2f %%" % (100.0 * worse / max(1, total)))
+sys.exit(1 if bad else 0)

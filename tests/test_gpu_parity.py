@@ -325,3 +325,35 @@ def test_zero_and_negative_budgets_still_finish(aligner):
     for me in (0, -5):
         s, c = _run(aligner, buf, meta, (2, 3, 1), max_error=me)
         assert np.array_equal(s, so) and c == co, me
+
+
+@pytest.mark.parametrize("pen,beta,lam,err", [((4, 1, 1), 128, 10, 0.15), ((2, 4, 5), 128, 750, 0.15), ((7, 10, 1), 256, 25, 0.15),
+                                               ((4, 2, 5), 64, 1, 0.05)])
+def test_narrow_band_scores_follow_the_returned_alignment(aligner, pen, beta, lam, err):
+    """A narrow adaptive band on divergent pairs with multi-base indels: the band can drop the gap-extension cell, so
+    the wavefront path opens two gaps back to back; printed they are one gap.  The reported score must be the
+    gap-affine cost of the CIGAR that is returned (the reference's -c rule, utils/verification.c:91-146)."""
+    rng = random.Random(hash((pen, beta)) & 0xFFFF)
+    pairs = []
+    for _ in range(96):
+        t = bytes(rng.choice(b"ACGT") for _ in range(rng.randint(2000, 4000)))
+        p = bytearray(t)
+        for _ in range(int(len(t) * err)):
+            op = rng.randint(0, 2)
+            if op == 0:
+                p[rng.randrange(len(p))] = rng.choice(b"ACGT")
+            elif op == 1:
+                a = rng.randrange(len(p)); del p[a:a + rng.randint(1, 12)]
+            else:
+                a = rng.randint(0, len(p)); p[a:a] = bytes(rng.choice(b"ACGT") for _ in range(rng.randint(1, 12)))
+        pairs.append((bytes(p), t))
+    buf, meta = wfagpu.layout_pairs(pairs)
+    so, _, _ = oracle_lib.oracle_batch(buf, meta, pen, cigar=False, nthreads=8)
+    batch = aligner.upload(buf, meta)
+    me = int(4000 * 0.3 * max(pen))
+    s1, c1 = aligner.align(batch, pen, max_error=me, compute_cigar=True, band=lam, band_width=beta)
+    s2, c2 = aligner.align(batch, pen, max_error=me, compute_cigar=True, band=lam, band_width=beta)
+    assert np.array_equal(s1, s2) and c1 == c2
+    for (p, t), cg, sc, opt in zip(pairs, c1, s1, so):
+        ok, cost = oracle_lib.check_cigar(p, t, cg, pen)
+        assert ok and cost == sc and sc >= opt, (len(p), len(t), sc, opt, cost)

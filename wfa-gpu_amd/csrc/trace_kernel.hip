@@ -74,6 +74,8 @@ struct RleSink {
   uint32_t len;
   uint32_t run;
   char op;
+  int x, o, e;    // penalties: the gap-affine cost of the emitted items is accumulated while writing
+  int cost;
   __device__ __forceinline__ void flush() {
     if (run == 0) return;
     const int nd = dec_digits(run);
@@ -81,6 +83,9 @@ struct RleSink {
       uint32_t r = run;
       for (int i = nd - 1; i >= 0; --i) { out[len + i] = (char)('0' + r % 10); r /= 10; }
       out[len + nd] = op;
+      // (utils/verification.c:91-146 of the reference: a new gap wherever the operation changes)
+      if (op == 'X') cost += x * (int)run;
+      else if (op != 'M') cost += o + e * (int)run;
     }
     len += (uint32_t)nd + 1;
     run = 0;
@@ -95,8 +100,8 @@ struct RleSink {
 template <bool RAW>
 __device__ __forceinline__ uint32_t replay(const uint8_t* ops, uint32_t nops,
                                            const uint32_t* Pw, const uint32_t* Tw,
-                                           int plen, int tlen, char* out) {
-  RleSink sink{out, 0, 0, 0};
+                                           int plen, int tlen, char* out, int x, int o, int e, int* cost) {
+  RleSink sink{out, 0, 0, 0, x, o, e, 0};
   int v = 0, h = 0;
   int n = lcp_seq<RAW>(Pw, Tw, plen, tlen, v, h);
   sink.push('M', (uint32_t)n); v += n; h += n;
@@ -113,7 +118,7 @@ __device__ __forceinline__ uint32_t replay(const uint8_t* ops, uint32_t nops,
     }
   }
   sink.flush();
-  if (out) out[sink.len] = '\0';
+  if (out) { out[sink.len] = '\0'; *cost = sink.cost; }
   // a consistent trace ends exactly at the corner
   return (v == plen && h == tlen) ? sink.len : 0xFFFFFFFFu;
 }
@@ -223,7 +228,8 @@ __global__ void __launch_bounds__(TRACE_THREADS) wfa_emit_kernel(const WfaTraceP
   }
   uint32_t len = 0;
   if (active && !fail) {
-    len = p.raw ? replay<true>(q, nops, Pw, Tw, plen, tlen, nullptr) : replay<false>(q, nops, Pw, Tw, plen, tlen, nullptr);
+    len = p.raw ? replay<true>(q, nops, Pw, Tw, plen, tlen, nullptr, 0, 0, 0, nullptr)
+                : replay<false>(q, nops, Pw, Tw, plen, tlen, nullptr, 0, 0, 0, nullptr);
     if (len == 0xFFFFFFFFu) fail = true;
   }
   const uint32_t need_txt = (active && !fail) ? len + 1u : 0u;
@@ -231,10 +237,19 @@ __global__ void __launch_bounds__(TRACE_THREADS) wfa_emit_kernel(const WfaTraceP
   if (active && !fail && txt_off + need_txt > p.text_cap) fail = true;
   if (active) {
     if (!fail) {
-      if (p.raw) replay<true>(q, nops, Pw, Tw, plen, tlen, p.text + txt_off);
-      else replay<false>(q, nops, Pw, Tw, plen, tlen, p.text + txt_off);
+      int cost = 0;
+      if (p.raw) replay<true>(q, nops, Pw, Tw, plen, tlen, p.text + txt_off, p.x, p.oe - p.e, p.e, &cost);
+      else replay<false>(q, nops, Pw, Tw, plen, tlen, p.text + txt_off, p.x, p.oe - p.e, p.e, &cost);
       p.cigar_off[pair] = txt_off;
       p.cigar_len[pair] = len;
+      // The text's own gap-affine cost.  Exact alignments: it equals the wavefront score (checked: a
+      // difference would mean a broken trace).  Adaptive band: a path may open two gaps back to back
+      // where the extension cell had left the band; printed, they are one gap and cost less -- the
+      // reported score follows the alignment that is returned.
+      if (cost != p.score[pair]) {
+        if (p.score_fix) p.score_fix[pair] = cost;
+        else p.cigar_len[pair] = 0xFFFFFFFFu;
+      }
     } else {
       p.cigar_off[pair] = 0;
       p.cigar_len[pair] = 0xFFFFFFFFu;

@@ -88,6 +88,7 @@ struct WfaTraceParams {
   uint32_t n_work;
   int x, oe, e;
   const int32_t* score;
+  int32_t* score_fix;            // banded passes: scores are replaced by the cost of the emitted CIGAR where they differ
   const uint32_t* status;
   const uint8_t* arena;
   const uint32_t* bt_final_row;

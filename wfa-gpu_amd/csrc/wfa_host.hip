@@ -514,6 +514,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       tp.packed = ap.packed; tp.meta = ap.meta; tp.work = pending; tp.n_work = n_pass;
       tp.x = pen.x; tp.oe = oe; tp.e = pen.e;
       tp.score = d_scores; tp.status = static_cast<const uint32_t*>(c->status.p);
+      tp.score_fix = (want_band && !raw) ? d_scores : nullptr;
       tp.arena = ap.arena; tp.bt_final_row = ap.bt_final_row;
       tp.ops = static_cast<uint8_t*>(c->ops.p); tp.ops_cap = c->ops.cap; tp.ops_top = ct + CT_OPS;
       tp.text = static_cast<char*>(c->text.p); tp.text_cap = c->text.cap; tp.text_top = ct + CT_TEXT;

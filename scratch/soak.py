@@ -38,6 +38,15 @@ for it in range(iters):
     maxlen = rng.choice([40, 150, 400, 900, 2500])
     pairs = rand_pairs(rng.choice([64, 200, 600]), maxlen, rng.choice([0.0, 0.02, 0.08, 0.2, 0.5]))
     pairs += [(b"", b""), (b"A", b""), (b"", b"ACGT" * 5), (b"ACGT" * 30, b"TGCA" * 30)]
+    for _ in range(12):   # very different lengths: |kend| large, in both directions
+        a = bytes(rng.choice(b"ACGT") for _ in range(rng.randint(0, 60)))
+        bb = bytes(rng.choice(b"ACGT") for _ in range(rng.randint(100, maxlen + 100)))
+        cut = rng.randint(0, len(bb))
+        emb = bb[:cut] + a + bb[cut:]
+        pairs.append(rng.choice([(a, bb), (bb, a), (bb, emb), (emb, bb)]))
+    for _ in range(6):    # low-complexity
+        u = bytes(rng.choice(b"ACGT") for _ in range(rng.randint(1, 4)))
+        pairs.append((u * rng.randint(1, 80), u * rng.randint(1, 80)))
     if rng.random() < 0.3:
         pairs += [(bytes(rng.choice(b"ACGTN") for _ in range(rng.randint(1, 200))), bytes(rng.choice(b"ACGTNacgt") for _ in range(rng.randint(1, 200)))) for _ in range(20)]
     buf, meta = wfagpu.layout_pairs(pairs)

@@ -171,3 +171,22 @@ def test_cached_device_state_survives_mode_and_size_changes(golden_dir):
         if cigar:
             assert c == co, (step, batch)
     lib.wfagpu_amd_release_cache()
+
+
+@pytest.mark.parametrize("shards,batch", [(2, None), (3, 50), (8, 7)])
+def test_call_sharded_over_several_device_slots(golden_dir, monkeypatch, shards, batch):
+    """launch_alignments* cut a call into contiguous per-device slices, one host thread +
+    context + streams each, results in input order.  WFAGPU_VIRTUAL_DEVICES runs that path with several
+    slices on the one GPU of the test box."""
+    lib = wfagpu.load()
+    lib.wfagpu_amd_release_cache.restype = None
+    monkeypatch.setenv("WFAGPU_VIRTUAL_DEVICES", str(shards))
+    pairs = wfagpu.read_seq_file(os.path.join(golden_dir, "seq1k.seq"))[:301]
+    buf, meta = wfagpu.layout_pairs(pairs)
+    so, co, _ = oracle_lib.oracle_batch(buf, meta, (2, 3, 1), cigar=True, nthreads=8)
+    for cigar in (False, True, True):
+        s, c = _api_align(pairs, (2, 3, 1), cigar=cigar, batch=batch)
+        assert np.array_equal(s, np.asarray(so))
+        if cigar:
+            assert c == co
+    lib.wfagpu_amd_release_cache()

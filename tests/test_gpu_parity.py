@@ -357,3 +357,33 @@ def test_narrow_band_scores_follow_the_returned_alignment(aligner, pen, beta, la
     for (p, t), cg, sc, opt in zip(pairs, c1, s1, so):
         ok, cost = oracle_lib.check_cigar(p, t, cg, pen)
         assert ok and cost == sc and sc >= opt, (len(p), len(t), sc, opt, cost)
+
+
+def test_length_buckets_mixed_batch(aligner):
+    """One call with pairs from 0 to ~9 kbp: the host driver runs them in length buckets (<= 1024, <= 4096, rest);
+    every pair must come back, in input order, with the oracle's score and CIGAR -- with and without non-ACGT pairs."""
+    rng = random.Random(2024)
+    pairs = _rand_pairs(rng, 300, 200, err=0.05) + _rand_pairs(rng, 30, 3000, err=0.05) + [(b"", b""), (b"", b"ACGT"), (b"T", b"")]
+    for _ in range(6):
+        t = bytes(rng.choice(b"ACGT") for _ in range(rng.randint(6000, 9000)))
+        p = bytearray(t)
+        for _ in range(len(t) // 25):
+            a = rng.randrange(len(p))
+            r = rng.random()
+            if r < 0.4:
+                p[a] = rng.choice(b"ACGT")
+            elif r < 0.7:
+                del p[a:a + rng.randint(1, 3)]
+            else:
+                p[a:a] = bytes(rng.choice(b"ACGT") for _ in range(rng.randint(1, 3)))
+        pairs.append((bytes(p), t))
+    pairs += [(b"ACGTNNACGT" * 30, b"ACGTNACGT" * 33), (b"acgt" * 1500, b"acgt" * 1490 + b"ACGT")]
+    rng.shuffle(pairs)
+    buf, meta = wfagpu.layout_pairs(pairs)
+    so, co, _ = oracle_lib.oracle_batch(buf, meta, (2, 3, 1), cigar=True, nthreads=8)
+    for max_error in (50, 2000):
+        s, c = _run(aligner, buf, meta, (2, 3, 1), max_error=max_error)
+        assert np.array_equal(s, so) and c == co, max_error
+        s2, _ = _run(aligner, buf, meta, (2, 3, 1), max_error=max_error, cigar=False)
+        assert np.array_equal(s2, so)
+    assert aligner.stats().sub_batches >= 3

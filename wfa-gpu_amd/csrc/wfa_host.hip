@@ -85,6 +85,26 @@ __global__ void k_compact(const uint32_t* __restrict__ work, uint32_t n, const u
   if (take) out[base + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = pair;
 }
 
+// Same, restricted to pairs whose longer sequence has len_lo <= length <= len_hi (length buckets).
+__global__ void k_compact_len(uint32_t n, const uint32_t* __restrict__ status, uint32_t mask, const WfaSeqPair* __restrict__ meta,
+                              uint32_t len_lo, uint32_t len_hi, uint32_t* __restrict__ out, unsigned long long* __restrict__ out_count) {
+  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  bool take = false;
+  if (gid < n && ((mask >> status[gid]) & 1u)) {
+    const uint32_t len = max(meta[gid].pattern_len, meta[gid].text_len);
+    take = len >= len_lo && len <= len_hi;
+  }
+  const unsigned long long bal = __ballot(take);
+  if (!bal) return;
+  unsigned long long base = 0;
+  const int leader = __builtin_ctzll(bal);
+  if (lane == leader) base = atomicAdd(out_count, (unsigned long long)__builtin_popcountll(bal));
+  const uint32_t blo = __shfl((uint32_t)base, leader), bhi = __shfl((uint32_t)(base >> 32), leader);
+  base = ((unsigned long long)bhi << 32) | blo;
+  if (take) out[base + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = gid;
+}
+
 // flagged (non-ACGT) pairs never enter the 2-bit tiers
 __global__ void k_flag_alphabet(const uint8_t* __restrict__ flags, uint32_t n, uint32_t* __restrict__ status) {
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -126,13 +146,10 @@ __global__ void __launch_bounds__(256) k_trace_bounds(const uint32_t* __restrict
   }
 }
 
-// every stride-th pair whose status is in `mask` -> sample list
-__global__ void k_sample(const uint32_t* __restrict__ status, uint32_t n_s, uint32_t stride, uint32_t mask,
-                         uint32_t* __restrict__ out, unsigned long long* __restrict__ out_count) {
+// every stride-th entry of a pair list -> sample list
+__global__ void k_sample(const uint32_t* __restrict__ list, uint32_t n_s, uint32_t stride, uint32_t* __restrict__ out) {
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= n_s) return;
-  const uint32_t pair = gid * stride;
-  if ((mask >> status[pair]) & 1u) out[atomicAdd(out_count, 1ull)] = pair;
+  if (gid < n_s) out[gid] = list[(size_t)gid * stride];
 }
 
 // score per 1024 bases of the longer sequence (INT_MAX for pairs that did not finish)
@@ -169,7 +186,7 @@ struct wfagpu_amd_ctx {
   int num_cus = 0;
   size_t lds_per_block_max = 0;
   size_t arena_cfg = 0, text_cfg = 0, arena_limit = 0;
-  DevBuf packed, flags, status, cells, bt_final, list_a, list_b, list_c, list_d, work_ctr, sample, ratio, budget, counters, arena, ops, text, cig_off, cig_len, gring;
+  DevBuf packed, flags, status, cells, bt_final, list_a, list_b, list_c, list_d, list_e, work_ctr, sample, ratio, budget, counters, arena, ops, text, cig_off, cig_len, gring;
   unsigned long long* h_counters = nullptr;  // pinned
   hipEvent_t ev_start = nullptr, ev_pack = nullptr, ev_a0 = nullptr, ev_a1 = nullptr, ev_t0 = nullptr, ev_t1 = nullptr, ev_end = nullptr;
   wfagpu_amd_stats_t stats{};
@@ -217,7 +234,7 @@ void wfagpu_amd_destroy(wfagpu_amd_ctx_t* c) {
   if (!c) return;
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
-  for (DevBuf* b : {&c->packed, &c->flags, &c->status, &c->cells, &c->bt_final, &c->list_a, &c->list_b, &c->list_c, &c->list_d, &c->work_ctr, &c->sample, &c->ratio, &c->budget,
+  for (DevBuf* b : {&c->packed, &c->flags, &c->status, &c->cells, &c->bt_final, &c->list_a, &c->list_b, &c->list_c, &c->list_d, &c->list_e, &c->work_ctr, &c->sample, &c->ratio, &c->budget,
                     &c->counters, &c->arena, &c->ops, &c->text, &c->cig_off, &c->cig_len, &c->gring})
     b->release();
   if (c->h_counters) hipHostFree(c->h_counters);
@@ -354,7 +371,8 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
     if (c->cig_off.ensure((size_t)8 * n, st)) return -1;
     if (c->cig_len.ensure((size_t)4 * n, st)) return -1;
   }
-  const unsigned max_len = std::max(1u, b->max_seq_len);
+  const unsigned batch_max_len = std::max(1u, b->max_seq_len);
+  unsigned max_len = batch_max_len;    // of the pairs being run: the whole batch, or one length bucket of it
   const int oe = pen.o + pen.e;
 
   WfaAlignParams ap{};
@@ -580,58 +598,75 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   // two classes of pairs: ACGT-only (2-bit packed kernels) and the rest (byte-compare kernels)
   for (int cls = 0; cls < 2; ++cls) {
   const bool raw = cls == 1;
-  if (raw) {
-    ap.packed = reinterpret_cast<const uint32_t*>(b->d_sequences);
-    ap.seq_words_cap = (int)((max_len + 3) / 4 + 1);
-  }
+  max_len = batch_max_len;
+  if (raw) ap.packed = reinterpret_cast<const uint32_t*>(b->d_sequences);
+  ap.seq_words_cap = raw ? (int)((max_len + 3) / 4 + 1) : (int)((max_len + 15) / 16 + 1);
   const uint32_t class_mask = raw ? MASK(WFA_ST_ALPHABET) : MASK(WFA_ST_PENDING);
-  // ---- auto-tuned score budgets -----------------------------------------
-  // max_error is a ceiling the caller guesses (the CLI default is 10 % of the length times the largest
-  // penalty); the scores of a batch usually sit far below it.  A strided sample is aligned with the
-  // caller's budget, the 98th percentile of score/length sets a per-pair budget for everyone else, and
-  // whoever exceeds it is re-run with the caller's budget.  Results are exact either way; a tight
-  // budget halves both the LDS ring and the number of wavefront cells (the wavefront becomes a diamond).
-  const int32_t* budgets = nullptr;
-  int budget_cap = max_error;
-  const bool try_budget = !raw && !want_band && n >= 8192 && !getenv("WFAGPU_NO_AUTOBUDGET") &&
-                          window_width(max_error, pen.o, pen.e, max_len) > 128;
-  if (try_budget) {
-    const uint32_t n_s = std::min<uint32_t>(4096u, std::max<uint32_t>(512u, n / 16u)), stride_s = n / n_s;
-    if (c->sample.ensure((size_t)4 * n_s, st)) return -1;
-    if (c->ratio.ensure((size_t)4 * n_s, st)) return -1;
-    if (c->budget.ensure((size_t)4 * n, st)) return -1;
+  // Length buckets (the reference assumes the pairs of a batch have similar lengths).
+  // LDS staging, ring width and with them the tier and the residency are sized by the longest pair that is
+  // launched together, so a batch that spans more than 4x in length runs in buckets of 4x each
+  // (<= 1024, <= 4096, ...): a few long reads no longer shrink the residency of all the short ones.
+  unsigned bucket_lo = 0;
+  for (unsigned bucket_hi = batch_max_len > 4096u ? 1024u : batch_max_len; ; bucket_hi = bucket_hi * 4u) {
+    if (bucket_hi >= batch_max_len / 2u || bucket_hi > (1u << 30)) bucket_hi = batch_max_len;   // last bucket takes the rest
+    uint32_t* pending = static_cast<uint32_t*>(c->list_c.p);
     if (zero_counter(c, CT_LIST)) return -1;
-    hipLaunchKernelGGL(k_sample, dim3(cdiv(n_s, 256)), dim3(256), 0, st, static_cast<const uint32_t*>(c->status.p), n_s, stride_s,
-                       class_mask, static_cast<uint32_t*>(c->sample.p), ct + CT_LIST);
+    hipLaunchKernelGGL(k_compact_len, dim3(cdiv(n, 256)), dim3(256), 0, st, n, static_cast<const uint32_t*>(c->status.p), class_mask,
+                       ap.meta, bucket_lo, bucket_hi, pending, ct + CT_LIST);
     if (read_counters(c)) return -1;
-    const uint32_t got = (uint32_t)c->h_counters[CT_LIST];
-    if (got >= n_s / 2) {
-      if (run_list(static_cast<uint32_t*>(c->sample.p), got, raw, nullptr, max_error)) return -1;
-      hipLaunchKernelGGL(k_ratio, dim3(cdiv(got, 256)), dim3(256), 0, st, static_cast<const uint32_t*>(c->sample.p), got,
-                         static_cast<const uint32_t*>(c->status.p), (const int32_t*)d_scores, ap.meta, static_cast<int32_t*>(c->ratio.p));
-      std::vector<int32_t> hr(got);
-      HIP_TRY(hipMemcpyAsync(hr.data(), c->ratio.p, (size_t)4 * got, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipStreamSynchronize(st));
-      std::sort(hr.begin(), hr.end());
-      const size_t valid = std::lower_bound(hr.begin(), hr.end(), INT_MAX) - hr.begin();
-      if (valid >= got / 2) {
-        const int q = hr[std::min(valid - 1, (size_t)(0.98 * valid))];      // score per 1024 bases
-        const int slack = pen.o + pen.e + pen.x + 2;
-        hipLaunchKernelGGL(k_budget, dim3(cdiv(n, 256)), dim3(256), 0, st, ap.meta, n, q, slack, static_cast<int32_t*>(c->budget.p));
-        budgets = static_cast<const int32_t*>(c->budget.p);
-        budget_cap = (int)std::min<long long>(max_error, ((long long)q * max_len * 102 / 100) / 1024 + slack);
-        c->stats.auto_budget = budget_cap;
+    uint32_t n_pending = (uint32_t)c->h_counters[CT_LIST];
+    if (raw) c->stats.pairs_raw += n_pending;
+    if (n_pending) {
+      max_len = bucket_hi;
+      ap.seq_words_cap = raw ? (int)((max_len + 3) / 4 + 1) : (int)((max_len + 15) / 16 + 1);
+      // ---- auto-tuned score budgets ---------------------------------------
+      // max_error is a ceiling the caller guesses (the CLI default is 10 % of the length times the largest
+      // penalty); the scores of a batch usually sit far below it.  A strided sample of the bucket is aligned
+      // with the caller's budget, the 98th percentile of score/length sets a per-pair budget for everyone
+      // else, and whoever exceeds it is re-run with the caller's budget.  Results are exact either way; a
+      // tight budget halves both the LDS ring and the number of wavefront cells (the wavefront becomes a
+      // diamond).
+      const int32_t* budgets = nullptr;
+      int budget_cap = max_error;
+      const bool try_budget = !raw && !want_band && n_pending >= 8192 && !getenv("WFAGPU_NO_AUTOBUDGET") &&
+                              window_width(max_error, pen.o, pen.e, max_len) > 128;
+      if (try_budget) {
+        const uint32_t n_s = std::min<uint32_t>(4096u, std::max<uint32_t>(512u, n_pending / 16u)), stride_s = n_pending / n_s;
+        if (c->sample.ensure((size_t)4 * n_s, st)) return -1;
+        if (c->ratio.ensure((size_t)4 * n_s, st)) return -1;
+        if (c->budget.ensure((size_t)4 * n, st)) return -1;
+        if (c->list_e.ensure((size_t)4 * n, st)) return -1;
+        hipLaunchKernelGGL(k_sample, dim3(cdiv(n_s, 256)), dim3(256), 0, st, (const uint32_t*)pending, n_s, stride_s, static_cast<uint32_t*>(c->sample.p));
+        if (run_list(static_cast<uint32_t*>(c->sample.p), n_s, raw, nullptr, max_error)) return -1;
+        hipLaunchKernelGGL(k_ratio, dim3(cdiv(n_s, 256)), dim3(256), 0, st, static_cast<const uint32_t*>(c->sample.p), n_s,
+                           static_cast<const uint32_t*>(c->status.p), (const int32_t*)d_scores, ap.meta, static_cast<int32_t*>(c->ratio.p));
+        std::vector<int32_t> hr(n_s);
+        HIP_TRY(hipMemcpyAsync(hr.data(), c->ratio.p, (size_t)4 * n_s, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        std::sort(hr.begin(), hr.end());
+        const size_t valid = std::lower_bound(hr.begin(), hr.end(), INT_MAX) - hr.begin();
+        if (valid >= n_s / 2) {
+          const int q = hr[std::min(valid - 1, (size_t)(0.98 * valid))];      // score per 1024 bases
+          const int slack = pen.o + pen.e + pen.x + 2;
+          hipLaunchKernelGGL(k_budget, dim3(cdiv(n, 256)), dim3(256), 0, st, ap.meta, n, q, slack, static_cast<int32_t*>(c->budget.p));
+          budgets = static_cast<const int32_t*>(c->budget.p);
+          budget_cap = (int)std::min<long long>(max_error, ((long long)q * max_len * 102 / 100) / 1024 + slack);
+          c->stats.auto_budget = budget_cap;
+        }
+        // the sampled pairs are done: drop them from the bucket's list
+        uint32_t* rest = static_cast<uint32_t*>(c->list_e.p);
+        if (zero_counter(c, CT_LIST)) return -1;
+        hipLaunchKernelGGL(k_compact, dim3(cdiv(n_pending, 256)), dim3(256), 0, st, (const uint32_t*)pending, n_pending,
+                           static_cast<const uint32_t*>(c->status.p), class_mask, rest, ct + CT_LIST);
+        if (read_counters(c)) return -1;
+        n_pending = (uint32_t)c->h_counters[CT_LIST];
+        HIP_TRY(hipMemcpyAsync(pending, rest, (size_t)4 * n_pending, hipMemcpyDeviceToDevice, st));
       }
+      if (n_pending && run_list(pending, n_pending, raw, budgets, budget_cap)) return -1;
     }
+    if (bucket_hi >= batch_max_len) break;
+    bucket_lo = bucket_hi + 1u;
   }
-  if (zero_counter(c, CT_LIST)) return -1;
-  uint32_t* pending = static_cast<uint32_t*>(c->list_c.p);
-  hipLaunchKernelGGL(k_compact, dim3(cdiv(n, 256)), dim3(256), 0, st, (const uint32_t*)nullptr, n,
-                     static_cast<const uint32_t*>(c->status.p), class_mask, pending, ct + CT_LIST);
-  if (read_counters(c)) return -1;
-  const uint32_t n_pending = (uint32_t)c->h_counters[CT_LIST];
-  if (raw) c->stats.pairs_raw = n_pending;
-  if (run_list(pending, n_pending, raw, budgets, budget_cap)) return -1;
   }  // class loop
   HIP_TRY(hipEventRecord(c->ev_end, st));
   HIP_TRY(hipStreamSynchronize(st));

@@ -114,7 +114,7 @@ __device__ __forceinline__ ColdParams cold_params() {
 }
 
 template <int NW, bool BT, typename OffT, bool GLOBAL_RING, bool RAW, bool BANDED>
-__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 1 ? 8 : 1, NW == 1 ? 8 : 8)))
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu((NW == 1 && !BANDED) ? 8 : 1, 8)))   // (the banded one-wave kernels would spill at 8)
 wfa_align_kernel(const WfaAlignParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NT = NW * 64;

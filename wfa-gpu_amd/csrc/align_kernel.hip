@@ -335,7 +335,8 @@ wfa_align_kernel(const WfaAlignParams p) {
         bool mx_null = false, mo_null = false, ie_null = false, de_null = false;   // (read by the banded cells)
         bool all_null = false, have_i = true, have_d = true;
         int ielo, iehi, delo, dehi;
-        if (!BANDED && regular >= dm - 1) {
+        const bool fast = !BANDED && regular >= dm - 1;
+        if (fast) {
           // I and D of s-e span the M limits of s-e: min(lo+1, lo-1), max(hi+1, hi-1)
           const int a_e = book.get_a(bk_e);
           ielo = delo = range_lo(a_e); iehi = dehi = range_hi(a_e);
@@ -575,6 +576,15 @@ wfa_align_kernel(const WfaAlignParams p) {
         // Limits recorded for the row: the computed ones.  Cells that are not valid hold NULL or a
         // negative value, which is all a reader needs; only values past a sequence end need the
         // exact per-component trimming (wavefront_compute.c:570-603): first/last in-range cell.
+        if (fast && !any_over) {
+          // regular regime goes on: the three components exist and span the computed limits
+          const int lim = pack_range(lo, hi);
+          ++regular;
+          book.set(bk_s, lim, lim, lim);
+          if constexpr (NW == 1) block_sync<NW>();
+          if (done) break;
+          continue;
+        }
         int lim_i = have_i ? pack_range(lo, hi) : ROW_NONE_A, lim_d = have_d ? pack_range(lo, hi) : ROW_NONE_A;
         if (any_over) {
           const int wave = (NW == 1) ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6);

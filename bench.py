@@ -119,9 +119,21 @@ def cpu_baseline(buf, meta, compute_cigar, budget_pairs):
         dt = time.perf_counter() - t0
         if dt >= 2.0 or reps >= 200:
             break
-    return {"value": n * reps / dt, "unit": "alignments/s", "cores": cores, "kind": kind,
-            "sample": f"{n} pairs of the same workload x{reps}, {'score+CIGAR' if compute_cigar else 'score-only'}, "
-                      f"one aligner per thread, {dt:.2f} s wall"}, out
+    res = {"value": n * reps / dt, "unit": "alignments/s", "cores": cores, "kind": kind,
+           "sample": f"{n} pairs of the same workload x{reps}, {'score+CIGAR' if compute_cigar else 'score-only'}, "
+                     f"one aligner per thread, {dt:.2f} s wall"}
+    # the same code on ONE core (SURVEY.md section 8d asks for both), on a sample sized for ~1-2 s
+    n1 = max(1, min(n, int(n * 1.5 / max(dt / reps, 1e-6) / max(cores, 1))))
+    m1 = meta[:n1]
+    if kind == "reference":
+        run1 = lambda: oracle_lib.ref_batch(sub, m1, PEN, cigar=compute_cigar, memory_mode=1, nthreads=1)
+    else:
+        run1 = lambda: oracle_lib.oracle_batch(sub, m1, PEN, cigar=compute_cigar, nthreads=1)
+    t1 = time.perf_counter()
+    run1()
+    d1 = time.perf_counter() - t1
+    res["single_core"] = {"value": n1 / d1, "unit": "alignments/s", "sample": f"{n1} pairs, {d1:.2f} s wall"}
+    return res, out
 
 
 def main():

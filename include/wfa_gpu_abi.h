@@ -37,7 +37,10 @@ typedef struct {
     size_t pattern_offset_packed;
     unsigned int text_len;
     unsigned int pattern_len;
-    bool has_N;                    /* set by the packing kernel: a byte outside ACGT */
+    bool has_N;                    /* input: ignored.  The reference's packing kernel sets it in its DEVICE copy
+                                    * only (sequence_packing_kernel.cu:57,74; no D2H of the records); this build
+                                    * keeps the same information in a device-side flag array, so the caller's
+                                    * copy is left as it was in both implementations. */
 } sequence_pair_t;
 
 /* lib/affine_penalties.h:25-30 -- match cost is 0 by construction */
@@ -142,8 +145,9 @@ bool destroy_wfa_results(wfa_alignment_result_t* results,
 /* --------------------------------------------------- the C-ABI seam (L3) */
 
 /* lib/align.cuh:35-47.  Blocking; results in input order; mutates
- * sequences_metadata[*].{text,pattern}_offset_packed and has_N exactly as
- * the reference does.  With check_correctness the -c self-check of
+ * sequences_metadata[*].{text,pattern}_offset_packed like the reference does
+ * (lib/align.cu:103-115; the values are batch-relative offsets of THIS build's
+ * packed layout) and nothing else of the caller's records.  With check_correctness the -c self-check of
  * lib/align.cu:258-326 / :688-739 runs and prints
  * "correct=%d Incorrect=%d" lines on stderr. */
 void launch_alignments(char* sequences_buffer,

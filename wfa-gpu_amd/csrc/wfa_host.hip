@@ -37,6 +37,13 @@ static_assert(sizeof(sequence_pair_t) == sizeof(WfaSeqPair), "ABI mirror");
     }                                                                                   \
   } while (0)
 
+// helper-kernel launch + launch-error check (the align/trace launchers are checked at their call sites)
+#define LAUNCH_K(kern, grid, block, lds, stream, ...)                 \
+  do {                                                                 \
+    hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);   \
+    HIP_TRY(hipGetLastError());                                        \
+  } while (0)
+
 namespace {
 
 struct DevBuf {
@@ -55,8 +62,17 @@ struct DevBuf {
         return -1;
       }
     }
-    if (p && preserve) hipMemcpyAsync(np, p, preserve, hipMemcpyDeviceToDevice, stream);
-    if (p) { hipStreamSynchronize(stream); hipFree(p); }
+    if (p) {
+      // (what the old buffer holds -- CIGAR text of earlier passes -- must survive the move: a failed copy is an error)
+      hipError_t e = preserve ? hipMemcpyAsync(np, p, preserve, hipMemcpyDeviceToDevice, stream) : hipSuccess;
+      if (e == hipSuccess) e = hipStreamSynchronize(stream);
+      if (e != hipSuccess) {
+        fprintf(stderr, "[!] ERROR: moving a device buffer of %zu bytes failed: %s\n", preserve, hipGetErrorString(e));
+        hipFree(np);
+        return -1;
+      }
+      hipFree(p);
+    }
     p = np; cap = ncap;
     return 0;
   }
@@ -170,6 +186,14 @@ __global__ void k_budget(const WfaSeqPair* __restrict__ meta, uint32_t n, int q,
   out[gid] = (int32_t)min(0x3FFFFFFFll, ((long long)q * len * 102 / 100) / 1024 + slack);
 }
 
+// pairs that are not DONE at the end of a call (must be none: every list is run to completion)
+__global__ void k_count_unfinished(uint32_t n, const uint32_t* __restrict__ status, unsigned long long* __restrict__ count) {
+  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool bad = gid < n && status[gid] != WFA_ST_DONE;
+  const unsigned long long bal = __ballot(bad);
+  if (bal && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(bal)) atomicAdd(count, (unsigned long long)__builtin_popcountll(bal));
+}
+
 __global__ void k_set_pending(const uint32_t* __restrict__ work, uint32_t n, uint32_t* __restrict__ status) {
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
   if (gid < n) status[work ? work[gid] : gid] = WFA_ST_PENDING;
@@ -206,26 +230,31 @@ int wfagpu_amd_create(wfagpu_amd_ctx_t** out, const wfagpu_amd_config_t* cfg) {
   HIP_TRY(hipSetDevice(dev));
   wfagpu_amd_ctx* c = new wfagpu_amd_ctx();
   c->device = dev;
-  if (cfg && cfg->stream) {
-    c->stream = static_cast<hipStream_t>(cfg->stream);
-  } else {
-    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    c->own_stream = true;
-  }
-  hipDeviceProp_t prop;
-  HIP_TRY(hipGetDeviceProperties(&prop, dev));
-  c->num_cus = prop.multiProcessorCount;
-  c->lds_per_block_max = prop.sharedMemPerBlock;   // 160 KiB on gfx950 (checked, not assumed)
-  c->arena_cfg = cfg ? cfg->arena_bytes : 0;
-  c->text_cfg = cfg ? cfg->text_bytes : 0;
-  c->arena_limit = cfg ? cfg->arena_limit_bytes : 0;
-  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_counters), CT_N * sizeof(unsigned long long), hipHostMallocDefault));
-  HIP_TRY(hipEventCreate(&c->ev_start)); HIP_TRY(hipEventCreate(&c->ev_pack));
-  HIP_TRY(hipEventCreate(&c->ev_a0)); HIP_TRY(hipEventCreate(&c->ev_a1));
-  HIP_TRY(hipEventCreate(&c->ev_t0)); HIP_TRY(hipEventCreate(&c->ev_t1));
-  HIP_TRY(hipEventCreate(&c->ev_end));
-  if (c->counters.ensure(CT_N * sizeof(unsigned long long), c->stream)) return -1;
-  if (c->work_ctr.ensure(8 * 64, c->stream)) return -1;
+  // (a context that fails half-way is torn down again: wfagpu_amd_destroy copes with whatever exists so far)
+  auto init = [&]() -> int {
+    if (cfg && cfg->stream) {
+      c->stream = static_cast<hipStream_t>(cfg->stream);
+    } else {
+      HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+      c->own_stream = true;
+    }
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    c->num_cus = prop.multiProcessorCount;
+    c->lds_per_block_max = prop.sharedMemPerBlock;   // 160 KiB on gfx950 (checked, not assumed)
+    c->arena_cfg = cfg ? cfg->arena_bytes : 0;
+    c->text_cfg = cfg ? cfg->text_bytes : 0;
+    c->arena_limit = cfg ? cfg->arena_limit_bytes : 0;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_counters), CT_N * sizeof(unsigned long long), hipHostMallocDefault));
+    HIP_TRY(hipEventCreate(&c->ev_start)); HIP_TRY(hipEventCreate(&c->ev_pack));
+    HIP_TRY(hipEventCreate(&c->ev_a0)); HIP_TRY(hipEventCreate(&c->ev_a1));
+    HIP_TRY(hipEventCreate(&c->ev_t0)); HIP_TRY(hipEventCreate(&c->ev_t1));
+    HIP_TRY(hipEventCreate(&c->ev_end));
+    if (c->counters.ensure(CT_N * sizeof(unsigned long long), c->stream)) return -1;
+    if (c->work_ctr.ensure(8 * 64, c->stream)) return -1;
+    return 0;
+  };
+  if (init()) { wfagpu_amd_destroy(c); return -1; }
   *out = c;
   return 0;
 }
@@ -233,14 +262,14 @@ int wfagpu_amd_create(wfagpu_amd_ctx_t** out, const wfagpu_amd_config_t* cfg) {
 void wfagpu_amd_destroy(wfagpu_amd_ctx_t* c) {
   if (!c) return;
   hipSetDevice(c->device);
-  hipStreamSynchronize(c->stream);
+  if (c->stream) hipStreamSynchronize(c->stream);
   for (DevBuf* b : {&c->packed, &c->flags, &c->status, &c->cells, &c->bt_final, &c->list_a, &c->list_b, &c->list_c, &c->list_d, &c->list_e, &c->work_ctr, &c->sample, &c->ratio, &c->budget,
                     &c->counters, &c->arena, &c->ops, &c->text, &c->cig_off, &c->cig_len, &c->gring})
     b->release();
   if (c->h_counters) hipHostFree(c->h_counters);
   for (hipEvent_t ev : {c->ev_start, c->ev_pack, c->ev_a0, c->ev_a1, c->ev_t0, c->ev_t1, c->ev_end})
     if (ev) hipEventDestroy(ev);
-  if (c->own_stream) hipStreamDestroy(c->stream);
+  if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
   delete c;
 }
 
@@ -418,7 +447,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   HIP_TRY(hipMemsetAsync(c->counters.p, 0, CT_N * sizeof(unsigned long long), st));
   HIP_TRY(hipEventRecord(c->ev_start, st));
   wfa_launch_pack(b->d_sequences, ap.meta, n, static_cast<uint32_t*>(c->packed.p), static_cast<uint8_t*>(c->flags.p), st);
-  hipLaunchKernelGGL(k_flag_alphabet, dim3(cdiv(n, 256)), dim3(256), 0, st, static_cast<const uint8_t*>(c->flags.p), n,
+  LAUNCH_K(k_flag_alphabet, dim3(cdiv(n, 256)), dim3(256), 0, st, static_cast<const uint8_t*>(c->flags.p), n,
                      static_cast<uint32_t*>(c->status.p));
   HIP_TRY(hipEventRecord(c->ev_pack, st));
 
@@ -429,7 +458,11 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
 
   // Runs one list of pairs to completion: passes bounded by the arena, tier escalation inside a pass,
   // backtrace + CIGAR text for what finished.  `budgets` (optional, per pair) is tried first.
-  auto run_list = [&](uint32_t* pending, uint32_t n_pending, const bool raw, const int32_t* budgets, const int budget_cap) -> int {
+  // `alt0`/`alt1`: the two lists the passes ping-pong between for what is left over (NOMEM pairs + pairs not launched
+  // yet).  The caller picks them so that neither is a list it still needs (the sampled run of the auto-budget step
+  // must not touch the bucket's own list).
+  auto run_list = [&](uint32_t* pending, uint32_t n_pending, const bool raw, const int32_t* budgets, const int budget_cap,
+                      uint32_t* alt0, uint32_t* alt1) -> int {
   grid_cap = UINT32_MAX;
   if (budgets) {
     // tight budgets make the wavefront a diamond: at most half the budget square of origin bytes
@@ -486,7 +519,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipEventRecord(c->ev_a1, st));
       uint32_t* nxt = spare[flip]; flip ^= 1;
-      hipLaunchKernelGGL(k_compact, dim3(cdiv(n_cur, 256)), dim3(256), 0, st, (const uint32_t*)cur, n_cur,
+      LAUNCH_K(k_compact, dim3(cdiv(n_cur, 256)), dim3(256), 0, st, (const uint32_t*)cur, n_cur,
                          static_cast<const uint32_t*>(c->status.p), MASK(WFA_ST_BAND) | MASK(WFA_ST_SCORE), nxt, ct + CT_LIST);
       if (read_counters(c)) return -1;
       float ms = 0.f;
@@ -512,7 +545,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
     // ---- backtrace + CIGAR for everything that finished in this pass ---------
     if (zero_counter(c, CT_SUM_OPS, 2)) return -1;
     if (zero_counter(c, CT_OPS)) return -1;
-    hipLaunchKernelGGL(k_trace_bounds, dim3(std::min<uint32_t>(cdiv(n_pass, 256), 1024u)), dim3(256), 0, st, (const uint32_t*)pending, n_pass,
+    LAUNCH_K(k_trace_bounds, dim3(std::min<uint32_t>(cdiv(n_pass, 256), 1024u)), dim3(256), 0, st, (const uint32_t*)pending, n_pass,
                        static_cast<const uint32_t*>(c->status.p), (const int32_t*)d_scores,
                        static_cast<const uint32_t*>(c->cells.p), std::min(pen.x, pen.e), ct);
     if (read_counters(c)) return -1;
@@ -545,9 +578,8 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
     }
     // ---- pairs that ran out of arena go into the next pass --------------------
     if (zero_counter(c, CT_LIST)) return -1;
-    uint32_t* nxt_pending = (pending == static_cast<uint32_t*>(c->list_c.p)) ? static_cast<uint32_t*>(c->list_d.p)
-                                                                             : static_cast<uint32_t*>(c->list_c.p);
-    hipLaunchKernelGGL(k_compact, dim3(cdiv(n_pass, 256)), dim3(256), 0, st, (const uint32_t*)pending, n_pass,
+    uint32_t* nxt_pending = (pending == alt0) ? alt1 : alt0;
+    LAUNCH_K(k_compact, dim3(cdiv(n_pass, 256)), dim3(256), 0, st, (const uint32_t*)pending, n_pass,
                        static_cast<const uint32_t*>(c->status.p), MASK(WFA_ST_NOMEM), nxt_pending, ct + CT_LIST);
     if (read_counters(c)) return -1;
     if (compute_cigar) {
@@ -580,7 +612,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       }
     }
     if (n_nomem) {
-      hipLaunchKernelGGL(k_set_pending, dim3(cdiv(n_nomem, 256)), dim3(256), 0, st, (const uint32_t*)nxt_pending, n_nomem,
+      LAUNCH_K(k_set_pending, dim3(cdiv(n_nomem, 256)), dim3(256), 0, st, (const uint32_t*)nxt_pending, n_nomem,
                          static_cast<uint32_t*>(c->status.p));
     }
     c->stats.arena_units = std::max<unsigned long long>(c->stats.arena_units, c->h_counters[CT_ARENA]);
@@ -611,7 +643,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
     if (bucket_hi >= batch_max_len / 2u || bucket_hi > (1u << 30)) bucket_hi = batch_max_len;   // last bucket takes the rest
     uint32_t* pending = static_cast<uint32_t*>(c->list_c.p);
     if (zero_counter(c, CT_LIST)) return -1;
-    hipLaunchKernelGGL(k_compact_len, dim3(cdiv(n, 256)), dim3(256), 0, st, n, static_cast<const uint32_t*>(c->status.p), class_mask,
+    LAUNCH_K(k_compact_len, dim3(cdiv(n, 256)), dim3(256), 0, st, n, static_cast<const uint32_t*>(c->status.p), class_mask,
                        ap.meta, bucket_lo, bucket_hi, pending, ct + CT_LIST);
     if (read_counters(c)) return -1;
     uint32_t n_pending = (uint32_t)c->h_counters[CT_LIST];
@@ -636,9 +668,11 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         if (c->ratio.ensure((size_t)4 * n_s, st)) return -1;
         if (c->budget.ensure((size_t)4 * n, st)) return -1;
         if (c->list_e.ensure((size_t)4 * n, st)) return -1;
-        hipLaunchKernelGGL(k_sample, dim3(cdiv(n_s, 256)), dim3(256), 0, st, (const uint32_t*)pending, n_s, stride_s, static_cast<uint32_t*>(c->sample.p));
-        if (run_list(static_cast<uint32_t*>(c->sample.p), n_s, raw, nullptr, max_error)) return -1;
-        hipLaunchKernelGGL(k_ratio, dim3(cdiv(n_s, 256)), dim3(256), 0, st, static_cast<const uint32_t*>(c->sample.p), n_s,
+        LAUNCH_K(k_sample, dim3(cdiv(n_s, 256)), dim3(256), 0, st, (const uint32_t*)pending, n_s, stride_s, static_cast<uint32_t*>(c->sample.p));
+        // (leftovers of the sampled run ping-pong between list_d and list_e; list_c keeps the bucket)
+        if (run_list(static_cast<uint32_t*>(c->sample.p), n_s, raw, nullptr, max_error, static_cast<uint32_t*>(c->list_d.p),
+                     static_cast<uint32_t*>(c->list_e.p))) return -1;
+        LAUNCH_K(k_ratio, dim3(cdiv(n_s, 256)), dim3(256), 0, st, static_cast<const uint32_t*>(c->sample.p), n_s,
                            static_cast<const uint32_t*>(c->status.p), (const int32_t*)d_scores, ap.meta, static_cast<int32_t*>(c->ratio.p));
         std::vector<int32_t> hr(n_s);
         HIP_TRY(hipMemcpyAsync(hr.data(), c->ratio.p, (size_t)4 * n_s, hipMemcpyDeviceToHost, st));
@@ -648,7 +682,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         if (valid >= n_s / 2) {
           const int q = hr[std::min(valid - 1, (size_t)(0.98 * valid))];      // score per 1024 bases
           const int slack = pen.o + pen.e + pen.x + 2;
-          hipLaunchKernelGGL(k_budget, dim3(cdiv(n, 256)), dim3(256), 0, st, ap.meta, n, q, slack, static_cast<int32_t*>(c->budget.p));
+          LAUNCH_K(k_budget, dim3(cdiv(n, 256)), dim3(256), 0, st, ap.meta, n, q, slack, static_cast<int32_t*>(c->budget.p));
           budgets = static_cast<const int32_t*>(c->budget.p);
           budget_cap = (int)std::min<long long>(max_error, ((long long)q * max_len * 102 / 100) / 1024 + slack);
           c->stats.auto_budget = budget_cap;
@@ -656,20 +690,28 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         // the sampled pairs are done: drop them from the bucket's list
         uint32_t* rest = static_cast<uint32_t*>(c->list_e.p);
         if (zero_counter(c, CT_LIST)) return -1;
-        hipLaunchKernelGGL(k_compact, dim3(cdiv(n_pending, 256)), dim3(256), 0, st, (const uint32_t*)pending, n_pending,
+        LAUNCH_K(k_compact, dim3(cdiv(n_pending, 256)), dim3(256), 0, st, (const uint32_t*)pending, n_pending,
                            static_cast<const uint32_t*>(c->status.p), class_mask, rest, ct + CT_LIST);
         if (read_counters(c)) return -1;
         n_pending = (uint32_t)c->h_counters[CT_LIST];
         HIP_TRY(hipMemcpyAsync(pending, rest, (size_t)4 * n_pending, hipMemcpyDeviceToDevice, st));
       }
-      if (n_pending && run_list(pending, n_pending, raw, budgets, budget_cap)) return -1;
+      if (n_pending && run_list(pending, n_pending, raw, budgets, budget_cap, static_cast<uint32_t*>(c->list_d.p), pending)) return -1;
     }
     if (bucket_hi >= batch_max_len) break;
     bucket_lo = bucket_hi + 1u;
   }
   }  // class loop
+  // every pair must have been finished by one of the lists above; anything else is a driver bug and must not
+  // be returned as a result
+  if (zero_counter(c, CT_LIST)) return -1;
+  LAUNCH_K(k_count_unfinished, dim3(cdiv(n, 256)), dim3(256), 0, st, n, static_cast<const uint32_t*>(c->status.p), ct + CT_LIST);
   HIP_TRY(hipEventRecord(c->ev_end, st));
-  HIP_TRY(hipStreamSynchronize(st));
+  if (read_counters(c)) return -1;
+  if (c->h_counters[CT_LIST]) {
+    fprintf(stderr, "[!] ERROR: %llu of %u alignments were left unfinished\n", c->h_counters[CT_LIST], n);
+    return -1;
+  }
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, c->ev_start, c->ev_pack)); c->stats.pack_ms = ms;
   HIP_TRY(hipEventElapsedTime(&ms, c->ev_start, c->ev_end)); c->stats.total_ms = ms;

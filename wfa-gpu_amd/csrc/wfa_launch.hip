@@ -207,7 +207,8 @@ int run_shard(const CallArgs& a, Shard& sh) {
     cv.wait(l, [&] { return counter >= at_least || rc.load() != 0; });
     return rc.load() == 0;
   };
-  auto fail = [&](int code) { rc.store(code); cv.notify_all(); };
+  // (the flag changes under the mutex the waiters test it under: no wake-up can fall between their test and their block)
+  auto fail = [&](int code) { { std::lock_guard<std::mutex> l(mu); rc.store(code); } cv.notify_all(); };
 
   std::thread uploader([&] {
     if (hipSetDevice(sh.device) != hipSuccess) { fail(-1); return; }

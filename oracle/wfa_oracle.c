@@ -200,7 +200,41 @@ static void compute_step(oracle_aligner_t* al, int s, oracle_stats_t* st) {
   if (have_i) row_alloc(al, oi, s, 1, lo, hi); else *oi = OWF_NULL;
   if (have_d) row_alloc(al, od, s, 2, lo, hi); else *od = OWF_NULL;
   const uint32_t plen = (uint32_t)al->plen, tlen = (uint32_t)al->tlen;
+  /* Interior diagonals, where all five reads fall inside their rows, run without the range tests of rd()
+   * (same arithmetic; lets the compiler vectorise the loop that dominates long alignments). */
+  int in_lo = hi + 1, in_hi = hi;
+  if (!MX.null && !MOE.null && !IE.null && !DE.null && have_i && have_d) {
+    in_lo = MX.lo; in_hi = MX.hi;
+    if (in_lo < MOE.lo + 1) in_lo = MOE.lo + 1;
+    if (in_hi > MOE.hi - 1) in_hi = MOE.hi - 1;
+    if (in_lo < IE.lo + 1) in_lo = IE.lo + 1;
+    if (in_hi > IE.hi + 1) in_hi = IE.hi + 1;
+    if (in_lo < DE.lo - 1) in_lo = DE.lo - 1;
+    if (in_hi > DE.hi - 1) in_hi = DE.hi - 1;
+    if (in_lo < lo) in_lo = lo;
+    if (in_hi > hi) in_hi = hi;
+    if (in_lo > in_hi) { in_lo = hi + 1; in_hi = hi; }
+  }
   for (int k = lo; k <= hi; ++k) {
+    if (k == in_lo) {
+      const int32_t* restrict pmo = MOE.off - MOE.base;
+      const int32_t* restrict pie = IE.off - IE.base;
+      const int32_t* restrict pde = DE.off - DE.base;
+      const int32_t* restrict pmx = MX.off - MX.base;
+      int32_t* restrict qi = oi->off - lo; int32_t* restrict qd = od->off - lo; int32_t* restrict qm = om->off - lo;
+      for (int kk = in_lo; kk <= in_hi; ++kk) {
+        const int32_t ins = OMAX(pmo[kk - 1], pie[kk - 1]) + 1;
+        const int32_t del = OMAX(pmo[kk + 1], pde[kk + 1]);
+        const int32_t mis = pmx[kk] + 1;
+        int32_t mx3 = OMAX(del, OMAX(mis, ins));
+        const uint32_t h = (uint32_t)mx3, v = (uint32_t)(mx3 - kk);
+        if (h > tlen) mx3 = ONULL;
+        if (v > plen) mx3 = ONULL;
+        qi[kk] = ins; qd[kk] = del; qm[kk] = mx3;
+      }
+      k = in_hi;
+      continue;
+    }
     const int32_t ins = OMAX(rd(&MOE, k - 1), rd(&IE, k - 1)) + 1;
     const int32_t del = OMAX(rd(&MOE, k + 1), rd(&DE, k + 1));
     const int32_t mis = rd(&MX, k) + 1;

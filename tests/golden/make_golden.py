@@ -14,6 +14,7 @@ on seeded synthetic pairs.  No reference source text is stored.
   seq10k.seq / seq10k.*.scores     first 30 pairs and golden scores of tests/data/sequences_10K.h
   hifi.seq / hifi.g231.alg         first 12 pairs of tests/data/test_hifi.seq + _ref output
   synth.cfg{2,3}.alg               _ref output on seeded synthetic pairs (generator parameters inside)
+  synth.cfg{4,5}.alg               the same for the first 8 / 4 pairs of the long-read sets (10 kbp @ 3 %, 30 kbp @ 10 %)
 """
 import os
 import re
@@ -86,6 +87,14 @@ def main():
         s, c = oracle_lib.ref_batch(buf, meta, (2, 3, 1), cigar=True, nthreads=8)
         with open(f"{HERE}/synth.{tag}.alg", "w") as f:
             f.write(f"# generate_pairs(n={n}, length={length}, error={err}, seed={seed}) penalties=2,3,1\n")
+            for sc, cg in zip(s, c):
+                f.write(f"{-int(sc)}\t{cg}\n")
+    # long reads (BASELINE.json configs[3]/[4] shapes): the first `keep` pairs of the set the GPU test regenerates
+    for tag, n, keep, length, err, seed in (("cfg4", 64, 8, 10000, 0.03, 44), ("cfg5", 16, 4, 30000, 0.10, 55)):
+        buf, meta = wfagpu.generate_pairs(n, length, err, seed)
+        s, c = oracle_lib.ref_batch(buf, meta[:keep], (2, 3, 1), cigar=True, nthreads=4)
+        with open(f"{HERE}/synth.{tag}.alg", "w") as f:
+            f.write(f"# first {keep} pairs of generate_pairs(n={n}, length={length}, error={err}, seed={seed}) penalties=2,3,1\n")
             for sc, cg in zip(s, c):
                 f.write(f"{-int(sc)}\t{cg}\n")
     print("golden fixtures written to", HERE)

@@ -387,3 +387,108 @@ def test_length_buckets_mixed_batch(aligner):
         s2, _ = _run(aligner, buf, meta, (2, 3, 1), max_error=max_error, cigar=False)
         assert np.array_equal(s2, so)
     assert aligner.stats().sub_batches >= 3
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Round 2: the host orchestration the headline number runs through, and the long-read configurations.
+
+def _truth(buf, meta, pen, nthreads=8):
+    """Ground truth for long reads (score + CIGAR): the reference's own WFA2 compiled in place (oracle/_ref, travels as
+    a prebuilt .so) when it is there -- it is ~5x faster than the restatement at 30 kbp -- else the oracle."""
+    if oracle_lib.have_ref():
+        return oracle_lib.ref_batch(buf, meta, pen, cigar=True, memory_mode=0, nthreads=nthreads)
+    s, c, _ = oracle_lib.oracle_batch(buf, meta, pen, cigar=True, nthreads=min(nthreads, 4))
+    return s, c
+
+
+def _concat_layouts(parts):
+    """[(buf, meta)] -> one batch (records rebased), order preserved."""
+    bufs, metas, base = [], [], 0
+    for buf, meta in parts:
+        m = meta.copy()
+        m["pattern_offset"] += base
+        m["text_offset"] += base
+        pad = (-len(buf)) % 4
+        bufs.append(buf)
+        if pad:
+            bufs.append(np.zeros(pad, dtype=np.uint8))
+        base += len(buf) + pad
+        metas.append(m)
+    return np.concatenate(bufs + [np.zeros(16, dtype=np.uint8)]), np.concatenate(metas)
+
+
+def test_auto_budget_path_on_a_heterogeneous_batch(aligner):
+    """The sampled auto-budget driver (csrc/wfa_host.hip: k_sample -> sampled run -> k_ratio -> percentile -> k_budget
+    -> budget round -> misses re-run with the caller's budget) only engages at >= 8192 pairs with a window > 128
+    diagonals -- the regime bench.py's cfg3 runs in.  A 1.5 % sub-population with four times the error rate sits above
+    the sampled 98th percentile, so its pairs MUST miss their budget and be re-run; lengths vary 3x inside the bucket.
+    Scores and CIGARs byte-identical to the oracle on every pair."""
+    parts = [wfagpu.generate_pairs(9000, 1000, 0.03, seed=101), wfagpu.generate_pairs(7000, 600, 0.04, seed=102),
+             wfagpu.generate_pairs(240, 1000, 0.13, seed=103), wfagpu.generate_pairs(300, 350, 0.02, seed=104)]
+    buf, meta = _concat_layouts(parts)
+    perm = np.random.RandomState(5).permutation(len(meta))
+    meta = np.ascontiguousarray(meta[perm])
+    so, co, _ = oracle_lib.oracle_batch(buf, meta, (2, 3, 1), cigar=True, nthreads=16)
+    batch = aligner.upload(buf, meta)
+    s, c = aligner.align(batch, (2, 3, 1), max_error=400, compute_cigar=True)
+    st = aligner.stats()
+    assert st.auto_budget > 0, "the auto-budget path did not engage"
+    assert st.pairs_budget_missed >= 200, st.pairs_budget_missed
+    assert st.auto_budget < 400
+    assert np.array_equal(s, so)
+    assert c == co
+    s2, _ = aligner.align(batch, (2, 3, 1), max_error=400, compute_cigar=False)
+    assert aligner.stats().auto_budget > 0
+    assert np.array_equal(s2, so)
+
+
+def test_auto_budget_sample_with_a_tiny_arena():
+    """with an arena too small for the SAMPLE of the auto-budget step (several passes, NOMEM re-queues)
+    the sampled run used to write its leftovers over the bucket's own pending list; pairs were then never aligned and
+    the call still returned 0.  >= 8192 pairs, CIGARs, 2 MiB arena, compared against the oracle pair by pair."""
+    al = wfagpu.DeviceAligner(0, arena_bytes=2 << 20)
+    try:
+        buf, meta = wfagpu.generate_pairs(10240, 400, 0.05, seed=77)
+        so, co, _ = oracle_lib.oracle_batch(buf, meta, (2, 3, 1), cigar=True, nthreads=16)
+        batch = al.upload(buf, meta)
+        s, c = al.align(batch, (2, 3, 1), max_error=300, compute_cigar=True)
+        st = al.stats()
+        assert st.auto_budget > 0 and st.sub_batches > 4, (st.auto_budget, st.sub_batches)
+        assert np.array_equal(s, so)
+        assert c == co
+    finally:
+        al.close()
+
+
+def test_cfg5_ont_30kbp_exact_with_cigars(aligner, golden_dir):
+    """BASELINE configs[4] shape: ONT-like 30 kbp pairs at 10 % error, exact (unbanded) + CIGAR, -e 9000
+    (lib/wfa_types.h:59-64 and lib/sequence_alignment.cu:31-57 size the reference's backtrace for this case).  The first
+    four pairs are pinned by a committed golden made with the reference's WFA2 (tests/golden/make_golden.py); all 16
+    are compared with the checker available on the box."""
+    buf, meta = wfagpu.generate_pairs(16, 30000, 0.10, seed=55)
+    gs, gc = oracle_lib.read_alg_skip_comments(os.path.join(golden_dir, "synth.cfg5.alg"))
+    s, c = _run(aligner, buf, meta, (2, 3, 1), max_error=9000)
+    st = aligner.stats()
+    assert np.array_equal(s[:len(gs)], gs)
+    assert c[:len(gc)] == gc
+    so, co = _truth(buf, meta, (2, 3, 1))
+    assert np.array_equal(s, so)
+    assert c == co
+    assert st.cells > 16 * 30_000_000          # the exact search, not a band
+    s2, _ = _run(aligner, buf, meta, (2, 3, 1), max_error=9000, cigar=False)
+    assert np.array_equal(s2, so)
+    # -e too small by 20x: escalation on the device, same answers
+    s3, c3 = _run(aligner, buf[:int(meta[3]["text_offset"]) + 30016], meta[:4], (2, 3, 1), max_error=450)
+    assert np.array_equal(s3, so[:4]) and c3 == co[:4]
+
+
+def test_cfg4_hifi_10kbp_exact_with_cigars(aligner, golden_dir):
+    """BASELINE configs[3] shape without the band: 10 kbp pairs at 3 % error, exact + CIGAR, -e 3000."""
+    buf, meta = wfagpu.generate_pairs(64, 10000, 0.03, seed=44)
+    gs, gc = oracle_lib.read_alg_skip_comments(os.path.join(golden_dir, "synth.cfg4.alg"))
+    s, c = _run(aligner, buf, meta, (2, 3, 1), max_error=3000)
+    assert np.array_equal(s[:len(gs)], gs)
+    assert c[:len(gc)] == gc
+    so, co = _truth(buf, meta, (2, 3, 1))
+    assert np.array_equal(s, so)
+    assert c == co

@@ -62,6 +62,19 @@ def test_oracle_matches_ref_on_hifi_and_synthetic(golden_dir):
         assert c == gc, fname
 
 
+def test_oracle_matches_ref_on_long_read_goldens(golden_dir):
+    """BASELINE configs[3]/[4] shapes (10 kbp @ 3 %, 30 kbp @ 10 %): goldens made with the reference's WFA2."""
+    for fname, n, length, err, seed in (("synth.cfg4.alg", 64, 10000, 0.03, 44), ("synth.cfg5.alg", 16, 30000, 0.10, 55)):
+        gs, gc = oracle_lib.read_alg_skip_comments(os.path.join(golden_dir, fname))
+        buf, meta = wfagpu.generate_pairs(n, length, err, seed)
+        s, c, _ = oracle_lib.oracle_batch(buf, meta[:len(gs)], (2, 3, 1), cigar=True, nthreads=4)
+        assert np.array_equal(s, gs), fname
+        assert c == gc, fname
+        for (p, t), cg, sc in zip(wfagpu.pairs_from_layout(buf, meta[:len(gs)]), c, s):
+            ok, cost = oracle_lib.check_cigar(p, t, cg, (2, 3, 1))
+            assert ok and cost == sc
+
+
 def _rand_pairs(rng, n, maxlen, alphabet=b"ACGT", err=0.1):
     out = []
     for _ in range(n):

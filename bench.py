@@ -1,20 +1,31 @@
 #!/usr/bin/env python3
 """Headline benchmark of the MI355X gap-affine WFA path (BASELINE.json metric: alignments/s + GCUPS).
 
-One "step" = one pass of the whole hot path (2-bit pack -> wavefront kernels -> backtrace -> CIGAR text)
-over one batch that is already resident in HBM.  Default workload = BASELINE.json configs[2], the
-configuration the north-star target is quoted on: 1M synthetic 1 kbp pairs at 5 % error, penalties
-(2,3,1), score + CIGAR.  Prints ONE JSON line on rank 0.
+One "step" = one pass of the whole hot path (2-bit pack -> wavefront kernels -> backtrace -> CIGAR text) over one
+batch that is already resident in HBM.  Default workload = BASELINE.json configs[2], the configuration the north-star
+target is quoted on: 1M synthetic 1 kbp pairs at 5 % error, penalties (2,3,1), score + CIGAR.  ONE JSON line on rank 0.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3] [--pairs P] [--max-error E]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg4|cfg4x|cfg5] [--pairs P] [--max-error E]
+                  [--mode ranks|library] [--no-cpu-baseline] [--no-host-to-host]
 
-Multi-GPU (launched by torch.distributed.run, one rank per GPU): the batch is sharded -- every rank
-aligns its own P pairs (weak scaling), no data-path collective; RCCL only carries the barrier and the
-max-over-ranks of the timing.
+Multi-GPU.  --mode ranks (default): one rank per GPU under torch.distributed (RCCL carries the barrier and the
+max-over-ranks of the clock only; no data-path collective), every rank aligns its own P pairs: weak scaling.  When
+--gpus N > 1 is given WITHOUT a torchrun environment, this script starts the N ranks itself (a `python -m
+torch.distributed.run` child, before anything here touches the GPU) and relays the child's output and exit code.
+--mode library: ONE process times launch_alignments() -- the reference's host-buffer call (tools/aligner.c:450-474) --
+with N*P pairs sharded inside the library over N devices (what a user of the reference API gets).
+
+Besides the contract fields the line carries
+  roofline      the dominant kernel's main launch against the HBM roofline (SURVEY.md 8d algorithmic bytes) and, from the
+                committed PMC pass of the same command, against the instruction-issue limit that really binds it
+  cpu_baseline  the reference's WFA2 (oracle/_ref) on this box's host cores, bounded sample, N=1 only
+  host_to_host  the reference's own metric: wall of launch_alignments from a pageable host buffer to host CIGAR buffers
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -25,61 +36,57 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
 WORKLOADS = {
-    # name: (pairs, length, error, compute_cigar, default max_error, description)
-    "cfg2": (100_000, 150, 0.02, False, 45, "100k synthetic 150 bp pairs, 2% error, x=2,o=3,e=1, score-only"),
-    "cfg3": (1_000_000, 1000, 0.05, True, 300, "1M synthetic 1 kbp pairs, 5% error, x=2,o=3,e=1, score+CIGAR"),
+    # name: pairs, length, error, compute_cigar, max_error, band (lambda, beta) or None, default steps, description
+    "cfg2": dict(pairs=100_000, length=150, error=0.02, cigar=False, max_error=45, band=None, steps=2000,
+                 desc="100k synthetic 150 bp pairs, 2% error, x=2,o=3,e=1, score-only"),
+    "cfg3": dict(pairs=1_000_000, length=1000, error=0.05, cigar=True, max_error=300, band=None, steps=100,
+                 desc="1M synthetic 1 kbp pairs, 5% error, x=2,o=3,e=1, score+CIGAR"),
+    "cfg4": dict(pairs=16_384, length=10_000, error=0.03, cigar=True, max_error=3000, band=(25, 512), steps=200,
+                 desc="16k HiFi-shaped 10 kbp pairs, 3% error, -B auto (re-centre every 25 scores) -t 512 banded, score+CIGAR"),
+    "cfg4x": dict(pairs=16_384, length=10_000, error=0.03, cigar=True, max_error=3000, band=None, steps=100,
+                  desc="16k HiFi-shaped 10 kbp pairs, 3% error, exact (unbanded), score+CIGAR"),
+    "cfg5": dict(pairs=1024, length=30_000, error=0.10, cigar=True, max_error=9000, band=None, steps=25,
+                 desc="1024 ONT-shaped 30 kbp pairs, 10% error, exact (unbanded), -e 9000, score+CIGAR"),
 }
 PEN = (2, 3, 1)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def algorithmic_bytes(meta, cells, cigar_bytes, compute_cigar):
-    """in + out + bt per pair, summed over the batch.
-       in  = pad4(P+1)+pad4(T+1) ASCII read + 2*4*(ceil(P/16)+ceil(T/16)) packed write+read + 48 B record
-       out = 20 B result (+ CIGAR text), bt = 6 B per wavefront cell in CIGAR mode."""
-    P = meta["pattern_len"].astype(np.int64)
-    T = meta["text_len"].astype(np.int64)
-    pad4 = lambda v: v + (4 - v % 4)
-    ascii_b = int((pad4(P + 1) + pad4(T + 1)).sum())
-    packed_b = int((4 * ((P + 15) // 16 + (T + 15) // 16)).sum())
-    n = len(meta)
-    total = ascii_b + 2 * packed_b + 48 * n + 20 * n
-    # share of the dominant (wavefront) kernel: packed read + record + result (+ backtrace stream)
-    kernel = packed_b + 48 * n + 20 * n
-    if compute_cigar:
-        total += 6 * cells + cigar_bytes
-        kernel += 6 * cells
-    return total, kernel
+def kernel_source_hash():
+    """Identifies the kernels a PMC summary was taken with (profiles/*/..._pmc_counters.csv carry it in a '#' line)."""
+    h = hashlib.sha1()
+    for f in ("align_kernel.hip", "trace_kernel.hip", "pack_kernel.hip", "wfa_device.h"):
+        h.update(open(os.path.join(ROOT, "wfa-gpu_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 
 
-def _pmc_per_launch(workload, counters):
-    """Per-launch averages of `counters` for wfa_align_kernel from the newest committed rocprofv3 PMC summary of this
-    same command (profiles/rNN/<workload>_pmc_counters.csv; separate --pmc passes over one step).  A step launches
-    the kernel several times (sample, main, retries): values are summed over the launches of the pass and divided
-    by their number, the same averaging as `kernel_ms_avg`."""
+def algorithmic_bytes(seq_bytes, pairs, cells, compute_cigar):
+    """SURVEY.md section 8(d), share of the wavefront kernel: packed sequences read + 48 B record + 20 B result per pair,
+    + 6 B per wavefront cell (three 16-bit offsets) in CIGAR mode."""
+    return int(seq_bytes + 68 * pairs + (6 * cells if compute_cigar else 0))
+
+
+def _pmc_main_launch(workload, counters):
+    """Counters of the MAIN launch (largest WRITE_SIZE+FETCH_SIZE) of wfa_align_kernel from the newest committed rocprofv3
+    PMC summary of this same command (profiles/rNN/<workload>_pmc_counters.csv; separate --pmc passes over one step).
+    Returns (values, source, stale) -- stale when the summary was taken with other kernel sources than the ones here."""
     import csv
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"{workload}_pmc_counters.csv")))
     if not files:
-        return None, None
-    tot = {c: 0.0 for c in counters}
-    cnt = {c: 0 for c in counters}
-    for r in csv.DictReader(open(files[-1])):
-        if "wfa_align_kernel" in r["kernel"] and r["counter"] in tot:
-            tot[r["counter"]] += float(r["value"])
-            cnt[r["counter"]] += 1
-    if any(cnt[c] == 0 for c in counters):
-        return None, None
-    return {c: tot[c] / cnt[c] for c in counters}, os.path.relpath(files[-1], ROOT)
-
-
-def pmc_traffic_bytes(workload):
-    """HBM bytes per launch of the dominant kernel: (FETCH_SIZE*2 + WRITE_SIZE) KB -- FETCH_SIZE counts half of a
-    wide coalesced read on gfx950 (MI355X_MICROARCH.md, HBM section).  None if no summary is committed."""
-    v, src = _pmc_per_launch(workload, ["FETCH_SIZE", "WRITE_SIZE"])
-    if v is None:
-        return None, None
-    return int((2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024), src
+        return None, None, None
+    src = files[-1]
+    lines = open(src).read().splitlines()
+    tag = [ln for ln in lines if ln.startswith("#") and "kernel_sha1=" in ln]
+    stale = (not tag) or (tag[0].split("kernel_sha1=")[1].split()[0] != kernel_source_hash())
+    rows = [r for r in csv.DictReader(ln for ln in lines if not ln.startswith("#")) if "wfa_align_kernel" in r["kernel"]]
+    out = {}
+    for c in counters:
+        vals = [float(r["value"]) for r in rows if r["counter"] == c]
+        if not vals:
+            return None, None, None
+        out[c] = max(vals)          # the main launch dominates every counter used here
+    return out, os.path.relpath(src, ROOT), stale
 
 
 def usable_cores():
@@ -98,23 +105,22 @@ def cpu_baseline(buf, meta, compute_cigar, budget_pairs):
     """Times the CPU ground truth on the host cores on a bounded sample of the same workload:
     the reference's own WFA2 (oracle/_ref, kind 'reference') when it is there, else the C port."""
     import oracle_lib
-    import wfagpu
     n = min(len(meta), budget_pairs)
     pairs_meta = meta[:n]
     end = int(max(pairs_meta["text_offset"].max() + pairs_meta["text_len"].max(),
                   pairs_meta["pattern_offset"].max() + pairs_meta["pattern_len"].max())) + 8
     sub = np.ascontiguousarray(buf[:end])
-    cores = usable_cores()
+    cores = min(usable_cores(), 64)
     if oracle_lib.have_ref():
         kind = "reference"
-        run = lambda: oracle_lib.ref_batch(sub, pairs_meta, PEN, cigar=compute_cigar, memory_mode=1, nthreads=cores)
+        run = lambda m, nt: oracle_lib.ref_batch(sub, m, PEN, cigar=compute_cigar, memory_mode=1, nthreads=nt)
     else:
         kind = "port"
-        run = lambda: oracle_lib.oracle_batch(sub, pairs_meta, PEN, cigar=compute_cigar, nthreads=cores)
+        run = lambda m, nt: oracle_lib.oracle_batch(sub, m, PEN, cigar=compute_cigar, nthreads=nt)
     reps = 0
     t0 = time.perf_counter()
     while True:
-        out = run()
+        run(pairs_meta, cores)
         reps += 1
         dt = time.perf_counter() - t0
         if dt >= 2.0 or reps >= 200:
@@ -124,152 +130,314 @@ def cpu_baseline(buf, meta, compute_cigar, budget_pairs):
                      f"one aligner per thread, {dt:.2f} s wall"}
     # the same code on ONE core (SURVEY.md section 8d asks for both), on a sample sized for ~1-2 s
     n1 = max(1, min(n, int(n * 1.5 / max(dt / reps, 1e-6) / max(cores, 1))))
-    m1 = meta[:n1]
-    if kind == "reference":
-        run1 = lambda: oracle_lib.ref_batch(sub, m1, PEN, cigar=compute_cigar, memory_mode=1, nthreads=1)
-    else:
-        run1 = lambda: oracle_lib.oracle_batch(sub, m1, PEN, cigar=compute_cigar, nthreads=1)
     t1 = time.perf_counter()
-    run1()
+    run(meta[:n1], 1)
     d1 = time.perf_counter() - t1
     res["single_core"] = {"value": n1 / d1, "unit": "alignments/s", "sample": f"{n1} pairs, {d1:.2f} s wall"}
-    return res, out
+    return res
+
+
+def host_to_host(buf, meta, wl, max_error, n_devices=1, reps=3, registered=True):
+    """The metric as SURVEY.md section 8(d) defines it: N / wall of launch_alignments*() -- pageable host buffers in,
+    host results (CIGAR strings scattered into the caller's wfa_alignment_result_t records) out, PCIe both ways.
+    First call = cold (context, allocations), later calls = warm (per-device state cached by the library)."""
+    import ctypes as C
+    import wfagpu
+    lib = wfagpu.load()
+    lib.wfagpu_amd_release_cache.restype = None
+    n = len(meta)
+    res = C.POINTER(wfagpu.AlignmentResult)()
+    assert lib.initialize_wfa_results(C.byref(res), n, 256 if wl["cigar"] else 1)
+    band = wl["band"]
+    opt = wfagpu.Options(max_error=max_error, threads_per_block=band[1] if band else 64, num_workers=0,
+                         band=band[0] if band else -1, batch_size=n, num_alignments=n,
+                         penalties=wfagpu.Penalties(*PEN), compute_cigar=wl["cigar"])
+    fn = lib.launch_alignments if wl["cigar"] else lib.launch_alignments_distance
+    lib.wfagpu_amd_set_num_devices(n_devices)
+    meta = meta.copy()
+
+    def timed(k):
+        out = []
+        for _ in range(k):
+            t0 = time.perf_counter()
+            fn(buf.ctypes.data, buf.nbytes, meta.ctypes.data, res, opt, False)
+            out.append((time.perf_counter() - t0) * 1e3)
+        return out
+
+    lib.wfagpu_amd_release_cache()
+    ms = timed(1 + reps)
+    out = {"unit": "alignments/s", "pairs": n, "devices": n_devices,
+           "what": "wall of launch_alignments%s(): pageable host buffer -> device -> host results%s" %
+                   ("" if wl["cigar"] else "_distance", " with CIGAR strings" if wl["cigar"] else ""),
+           "pageable": {"cold_ms": round(ms[0], 2), "warm_ms": round(min(ms[1:]), 2),
+                        "cold": round(n / ms[0] * 1e3, 1), "warm": round(n / min(ms[1:]) * 1e3, 1)}}
+    if registered:
+        hip = wfagpu._hiprt()
+        hip.hipHostRegister.argtypes = [C.c_void_p, C.c_size_t, C.c_uint]
+        hip.hipHostUnregister.argtypes = [C.c_void_p]
+        t0 = time.perf_counter()
+        rc = hip.hipHostRegister(buf.ctypes.data, buf.nbytes, 0)
+        reg_ms = (time.perf_counter() - t0) * 1e3
+        if rc == 0:
+            ms = timed(reps)
+            hip.hipHostUnregister(buf.ctypes.data)
+            out["registered"] = {"register_ms": round(reg_ms, 2), "warm_ms": round(min(ms), 2),
+                                 "warm": round(n / min(ms) * 1e3, 1)}
+    out["first_result"] = int(res[0].error)
+    lib.destroy_wfa_results(res, n)
+    return out
+
+
+def self_spawn(args):
+    """--gpus N without a torchrun environment: start the N ranks as a CHILD of this process -- nothing here has touched
+    the GPU yet (no HIP call, no torch.cuda.*), and the parent never execs: it relays output and exit code."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, env=env)
+    sys.exit(r.returncode)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=0, help="default: enough steps of the workload for a >= 5 s timed region")
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU per step (default: the workload's)")
     ap.add_argument("--max-error", type=int, default=0)
+    ap.add_argument("--mode", default="ranks", choices=["ranks", "library"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-to-host", action="store_true")
+    ap.add_argument("--cpu-harness", action="store_true",
+                    help="CPU-only check of the rank/timing harness (gloo; the step is the ORACLE, nothing is measured)")
     args = ap.parse_args()
 
-    import torch
-    import wfagpu
+    in_torchrun = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if args.mode == "ranks" and args.gpus > 1 and not in_torchrun:
+        self_spawn(args)
+
+    wl = dict(WORKLOADS[args.workload])
+    n_pairs = args.pairs or wl["pairs"]
+    max_error = args.max_error or wl["max_error"]
+    steps = args.steps or wl["steps"]
 
     import shardlib
     rank, local_rank, world = shardlib.env_rank_world()
-    dist = None
-    torch.cuda.set_device(local_rank) if torch.cuda.is_available() else None
+    if args.mode == "ranks" and in_torchrun and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
+
+    if args.cpu_harness:
+        return cpu_harness(args, rank, world, n_pairs, steps)
+
+    import torch
+    import wfagpu
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+
+    if args.mode == "library":
+        return library_mode(args, wl, n_pairs, max_error, steps)
+
+    dist = None
+    torch.cuda.set_device(local_rank)
     if world > 1:
         dist = shardlib.init_distributed("nccl", device=torch.device("cuda", local_rank))   # "nccl" is RCCL on ROCm
 
-    n_pairs, length, err, cigar, max_error, desc = WORKLOADS[args.workload]
-    if args.pairs:
-        n_pairs = args.pairs
-    if args.max_error:
-        max_error = args.max_error
-
     # synthetic data (seeded; every rank its own shard), resident in HBM before the clock starts
-    buf, meta = wfagpu.generate_pairs(n_pairs, length, err, seed=shardlib.shard_seed(1000, rank),
+    buf, meta = wfagpu.generate_pairs(n_pairs, wl["length"], wl["error"], seed=shardlib.shard_seed(1000, rank),
                                       nthreads=min(16, usable_cores()))
     al = wfagpu.DeviceAligner(local_rank)
     batch = al.upload(buf, meta)
     dptt = int((meta["pattern_len"].astype(np.int64) * meta["text_len"].astype(np.int64)).sum())
-    acc = {"align_ms": 0.0, "pack_ms": 0.0, "trace_ms": 0.0, "launches": 0, "steps": 0}
+    acc = {"align_ms": 0.0, "pack_ms": 0.0, "trace_ms": 0.0, "launches": 0, "main_ms": 0.0}
     last = {}
+    band = wl["band"]
 
     def step():
-        last["out"] = al.align(batch, PEN, max_error=max_error, compute_cigar=cigar, fetch=False)
+        last["out"] = al.align(batch, PEN, max_error=max_error, compute_cigar=wl["cigar"], band=band[0] if band else -1,
+                               band_width=band[1] if band else 0, fetch=False)
         st = al.stats()
         acc["align_ms"] += st.align_ms
         acc["pack_ms"] += st.pack_ms
         acc["trace_ms"] += st.trace_ms
         acc["launches"] += st.align_launches
-        acc["steps"] += 1
-
-    def reset_acc():
-        for k in acc:
-            acc[k] = 0
+        acc["main_ms"] += st.main_launch_ms
 
     for _ in range(args.warmup):
         step()
-    reset_acc()
-    elapsed = shardlib.timed_steps(step, args.steps, 0, dist=dist, sync=torch.cuda.synchronize, device="cuda")
+    for k in acc:
+        acc[k] = 0
+    elapsed = shardlib.timed_steps(step, steps, 0, dist=dist, sync=torch.cuda.synchronize, device="cuda")
     d_scores, ptrs = last["out"]
 
     st = al.stats()
-    total_pairs = n_pairs * args.steps * world
+    total_pairs = n_pairs * steps * world
     value = total_pairs / elapsed
-    gcups = dptt * args.steps * world / elapsed / 1e9
+    gcups = dptt * steps * world / elapsed / 1e9
 
     out = None
     if rank == 0:
-        total_b, kernel_b = algorithmic_bytes(meta, int(st.cells), int(st.text_bytes), cigar)
-        k_ms = acc["align_ms"] / max(1, acc["launches"])            # average wavefront-kernel launch
-        launches_per_step = acc["launches"] / max(1, args.steps)
-        achieved = (kernel_b / max(launches_per_step, 1e-9)) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        traffic, traffic_src = pmc_traffic_bytes(args.workload) if not args.pairs and not args.max_error else (None, None)
-        roofline = {"bound": "hbm", "kernel": "wfa_align_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "traffic_source": traffic_src,
-                    "algorithmic_bytes_per_launch": int(kernel_b / max(launches_per_step, 1e-9)),
-                    "kernel_ms_avg": round(k_ms, 4), "launches_per_step": launches_per_step,
-                    "cells_per_step": int(st.cells), "cells_per_s": round(st.cells / (acc["align_ms"] / args.steps * 1e-3), 1)
-                    if acc["align_ms"] > 0 else None,
-                    "note": "LDS-resident integer kernel: HBM fraction is low by construction, see DESIGN.md"}
-        issue, _ = _pmc_per_launch(args.workload, ["SQ_INSTS_VALU", "SQ_INSTS_SALU"]) \
-            if not args.pairs and not args.max_error else (None, None)
-        if issue and k_ms > 0:
-            # What this kernel really saturates: instruction issue.  A SIMD issues at most one vector and one
-            # scalar instruction per 4 cycles (scratch/valu_rate.hip measures 4.04-4.17 cycles per integer
-            # wave64 op; the CU's scalar unit serves its 4 SIMDs in turn): 1024 SIMDs at 2.4 GHz.
+        # Dominant kernel = wfa_align_kernel; its MAIN launch (a step also has the short launches of the auto-budget
+        # sample and of re-runs).  Duration: HIP events on the stream the kernel is launched on (csrc/wfa_host.hip),
+        # averaged over the timed steps.
+        main_ms = acc["main_ms"] / steps
+        alg = algorithmic_bytes(int(st.main_launch_seq_bytes), int(st.main_launch_pairs), int(st.main_launch_cells), wl["cigar"])
+        achieved = alg / (main_ms * 1e-3) / 1e9 if main_ms > 0 else 0.0
+        default_cmd = not args.pairs and not args.max_error
+        pmc, pmc_src, pmc_stale = _pmc_main_launch(args.workload, ["FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_INSTS_SALU"]) \
+            if default_cmd else (None, None, None)
+        # HBM bytes of the main launch: (FETCH_SIZE*2 + WRITE_SIZE) KB -- FETCH_SIZE counts half of a wide coalesced
+        # read on gfx950 (MI355X_MICROARCH.md, HBM section)
+        traffic = int((2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024) if pmc else None
+        roofline = {"bound": "valu-issue", "kernel": "wfa_align_kernel (main launch of a step)",
+                    "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": pmc_src,
+                    "pmc_stale": pmc_stale,
+                    "algorithmic_bytes_per_launch": alg, "kernel_ms": round(main_ms, 4),
+                    "launch": {"tier": int(st.main_launch_tier), "pairs": int(st.main_launch_pairs),
+                               "cells": int(st.main_launch_cells)},
+                    "launches_per_step": acc["launches"] / steps,
+                    "all_launches_ms_per_step": round(acc["align_ms"] / steps, 4),
+                    "cells_per_step": int(st.cells),
+                    "cells_per_s": round(st.main_launch_cells / (main_ms * 1e-3), 1) if main_ms > 0 else None,
+                    "note": "achieved/peak/frac: SURVEY 8(d) algorithmic bytes of the main launch / its HIP-event duration "
+                            "vs HBM peak.  The kernel keeps its wavefronts in LDS and stores 1 B per cell, so HBM is not "
+                            "what binds it: see `issue` (instruction issue, from the committed PMC pass) and DESIGN.md"}
+        if pmc and main_ms > 0:
+            # What this kernel really saturates: instruction issue.  A SIMD issues at most one vector and one scalar
+            # instruction per 4 cycles (profiles/r02/valu_rate.txt: 4.0-4.2 cycles per integer wave64 op); 1024 SIMDs, 2.4 GHz.
             peak = 1024 * 0.25 * 2.4e9 / 1e9
-            roofline["issue"] = {"unit": "G wave-instr/s", "peak_per_pipe": round(peak, 1),
-                                 "source": "SQ_INSTS_VALU / SQ_INSTS_SALU from the committed PMC pass of this command"}
+            roofline["issue"] = {"unit": "G wave-instr/s", "peak_per_pipe": round(peak, 1), "source": pmc_src, "stale": pmc_stale}
             for pipe, key in (("valu", "SQ_INSTS_VALU"), ("salu", "SQ_INSTS_SALU")):
-                ach = issue[key] / (k_ms * 1e-3) / 1e9
-                roofline["issue"][pipe] = {"achieved": round(ach, 1), "frac": round(ach / peak, 3),
-                                           "insts_per_launch": int(issue[key])}
-        # LDS side of SURVEY.md section 8(d): 16 B of wavefront offsets per cell against 256 CU x 128 B/clk
-        if acc["align_ms"] > 0:
-            lds_ach = 16.0 * st.cells / (acc["align_ms"] / args.steps * 1e-3) / 1e9
-            roofline["lds"] = {"achieved": round(lds_ach, 1), "peak": round(256 * 128 * 2.4, 1), "unit": "GB/s",
-                               "frac": round(lds_ach / (256 * 128 * 2.4), 4), "bytes_per_cell": 16}
+                ach = pmc[key] / (main_ms * 1e-3) / 1e9
+                roofline["issue"][pipe] = {"achieved": round(ach, 1), "frac": round(ach / peak, 3), "insts": int(pmc[key])}
         out = {
             "metric": "alignments_per_sec", "value": round(value, 1), "unit": "alignments/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "n_gpus": world, "steps": steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {desc}", "pairs_per_gpu_per_step": n_pairs, "length": length,
-                       "error": err, "penalties": "x=2,o=3,e=1", "max_error": max_error,
-                       "compute_cigar": cigar, "sharding": f"batch-sharded x{world}, no collective"},
+            "config": {"workload": f"{args.workload}: {wl['desc']}", "pairs_per_gpu_per_step": n_pairs, "length": wl["length"],
+                       "error": wl["error"], "penalties": "x=2,o=3,e=1", "max_error": max_error,
+                       "compute_cigar": wl["cigar"], "band": {"period": band[0], "width": band[1]} if band else None,
+                       "sharding": f"batch-sharded x{world}, no collective", "mode": "ranks"},
             "gcups": round(gcups, 2),
-            "stage_ms_per_step": {"pack": round(acc["pack_ms"] / args.steps, 3),
-                                  "align": round(acc["align_ms"] / args.steps, 3),
-                                  "trace": round(acc["trace_ms"] / args.steps, 3)},
-            "tier0": {"lds_bytes": int(st.lds_bytes_tier0), "blocks_per_cu": int(st.blocks_per_cu_tier0),
-                      "pairs_retried": int(st.pairs_retried), "sub_batches": int(st.sub_batches)},
+            "stage_ms_per_step": {"pack": round(acc["pack_ms"] / steps, 3), "align": round(acc["align_ms"] / steps, 3),
+                                  "trace": round(acc["trace_ms"] / steps, 3)},
+            "tiers": {"lds_bytes_first": int(st.lds_bytes_tier0), "blocks_per_cu_first": int(st.blocks_per_cu_tier0),
+                      "pairs_per_tier": [int(v) for v in st.pairs_tier], "pairs_retried": int(st.pairs_retried),
+                      "pairs_banded": int(st.pairs_banded), "auto_budget": int(st.auto_budget),
+                      "pairs_budget_missed": int(st.pairs_budget_missed), "passes": int(st.sub_batches),
+                      "arena_gb": round(st.arena_units * 16 / 1e9, 2)},
             "roofline": roofline,
         }
-        # parity spot check outside the timed region: a sample against the oracle
+        # parity spot check outside the timed region: a sample against the checker
         try:
             import oracle_lib
-            k = min(2000, n_pairs)
+            k = min(2000 if wl["length"] <= 1000 else (64 if wl["length"] <= 10000 else 8), n_pairs)
             scores = d_scores[:k].cpu().numpy()
-            so, co, _ = oracle_lib.oracle_batch(buf, meta[:k], PEN, cigar=cigar, nthreads=usable_cores())
-            ok = bool(np.array_equal(scores, so))
-            if cigar:
-                cg = wfagpu.fetch_cigars(ptrs[0], ptrs[1], ptrs[2], n_pairs, st.text_bytes)[:k]
-                ok = ok and cg == co
-            out["parity_sample"] = {"pairs": k, "bit_exact_vs_oracle": ok}
+            if oracle_lib.have_ref():
+                so, co = oracle_lib.ref_batch(buf, meta[:k], PEN, cigar=wl["cigar"], memory_mode=0, nthreads=min(16, usable_cores()))
+            else:
+                so, co, _ = oracle_lib.oracle_batch(buf, meta[:k], PEN, cigar=wl["cigar"], nthreads=min(8, usable_cores()))
+            cg = wfagpu.fetch_cigars(ptrs[0], ptrs[1], ptrs[2], n_pairs, st.text_bytes)[:k] if wl["cigar"] else None
+            if band:
+                # the adaptive band is a heuristic: valid alignments, cost == score >= optimum; recall reported
+                pairs = wfagpu.pairs_from_layout(buf, meta[:k])
+                chk = [oracle_lib.check_cigar(p, t, c, PEN) for (p, t), c in zip(pairs, cg)]
+                ok = all(o and cost == s for (o, cost), s in zip(chk, scores)) and bool((scores >= so).all())
+                out["parity_sample"] = {"pairs": k, "valid_and_cost_equals_score": ok, "recall": float((scores == so).mean())}
+            else:
+                ok = bool(np.array_equal(scores, so)) and (not wl["cigar"] or cg == co)
+                out["parity_sample"] = {"pairs": k, "bit_exact_vs_oracle": ok}
         except Exception as ex:  # the checker is optional for the measurement itself
             out["parity_sample"] = {"error": str(ex)}
-        if world == 1 and not args.no_cpu_baseline:
-            # ~10-30 s of CPU work: bounded sample of the same workload
-            per_pair_us = 2.0 if length <= 200 else 95.0 * (length / 1000.0) ** 2
-            budget = int(max(2000, min(n_pairs, 20e6 / per_pair_us)))
-            out["cpu_baseline"], _ = cpu_baseline(buf, meta, cigar, budget)
     al.close()
+    del batch
+    torch.cuda.empty_cache()
+    if rank == 0 and world == 1:
+        if not args.no_host_to_host:
+            try:
+                out["host_to_host"] = host_to_host(buf, meta, wl, max_error)
+            except Exception as ex:
+                out["host_to_host"] = {"error": str(ex)}
+        if not args.no_cpu_baseline:
+            # ~10-30 s of CPU work: bounded sample of the same workload
+            per_pair_us = 2.0 if wl["length"] <= 200 else 95.0 * (wl["length"] / 1000.0) ** 2
+            budget = int(max(16, min(n_pairs, 20e6 / per_pair_us)))
+            out["cpu_baseline"] = cpu_baseline(buf, meta, wl["cigar"], budget)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+
+
+def library_mode(args, wl, n_pairs, max_error, steps):
+    """ONE process, N devices inside the library: a step = one launch_alignments() call on N*P pairs in a pageable host
+    buffer (H2D, kernels, D2H and the scatter into the caller's result records all inside the clock)."""
+    import ctypes as C
+    import wfagpu
+    n = n_pairs * args.gpus
+    buf, meta = wfagpu.generate_pairs(n, wl["length"], wl["error"], seed=1000, nthreads=min(16, usable_cores()))
+    lib = wfagpu.load()
+    res = C.POINTER(wfagpu.AlignmentResult)()
+    assert lib.initialize_wfa_results(C.byref(res), n, 256 if wl["cigar"] else 1)
+    band = wl["band"]
+    opt = wfagpu.Options(max_error=max_error, threads_per_block=band[1] if band else 64, num_workers=0,
+                         band=band[0] if band else -1, batch_size=n, num_alignments=n,
+                         penalties=wfagpu.Penalties(*PEN), compute_cigar=wl["cigar"])
+    fn = lib.launch_alignments if wl["cigar"] else lib.launch_alignments_distance
+    lib.wfagpu_amd_set_num_devices(args.gpus)
+    nd = C.c_int(0)
+    lib.get_num_cuda_devices(C.byref(nd))
+    if nd.value < args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but only {nd.value} devices are visible")
+    steps = args.steps or max(5, steps // 5)
+    for _ in range(max(1, args.warmup)):
+        fn(buf.ctypes.data, buf.nbytes, meta.ctypes.data, res, opt, False)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn(buf.ctypes.data, buf.nbytes, meta.ctypes.data, res, opt, False)
+    elapsed = time.perf_counter() - t0
+    dptt = int((meta["pattern_len"].astype(np.int64) * meta["text_len"].astype(np.int64)).sum())
+    out = {"metric": "alignments_per_sec", "value": round(n * steps / elapsed, 1), "unit": "alignments/s",
+           "n_gpus": args.gpus, "steps": steps, "warmup": max(1, args.warmup), "ms_per_step": round(elapsed / steps * 1e3, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+           "config": {"workload": f"{args.workload}: {wl['desc']}", "pairs_per_gpu_per_step": n_pairs, "length": wl["length"],
+                      "error": wl["error"], "penalties": "x=2,o=3,e=1", "max_error": max_error, "compute_cigar": wl["cigar"],
+                      "sharding": f"one launch_alignments() call sharded in-library over {args.gpus} devices, no collective",
+                      "mode": "library (host buffer -> host results, PCIe inclusive)"},
+           "gcups": round(dptt * steps / elapsed / 1e9, 2), "first_result": int(res[0].error)}
+    lib.destroy_wfa_results(res, n)
+    print(json.dumps(out))
+
+
+def cpu_harness(args, rank, world, n_pairs, steps):
+    """No GPU: the same rank discovery, barrier + max-over-ranks timing and rank-0 aggregation with gloo, the ORACLE as
+    the step.  Exists so that the N>1 launch path (including the self-spawn) is covered by CPU tests; it measures nothing."""
+    import oracle_lib
+    import shardlib
+    import wfagpu
+    dist = shardlib.init_distributed("gloo") if world > 1 else None
+    n = min(n_pairs, 64)
+    buf, meta = wfagpu.generate_pairs(n, 120, 0.05, seed=shardlib.shard_seed(1000, rank))
+    state = {}
+
+    def step():
+        state["s"], _, _ = oracle_lib.oracle_batch(buf, meta, PEN, cigar=False)
+
+    elapsed = shardlib.timed_steps(step, steps, args.warmup, dist=dist)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "alignments_per_sec", "harness_only": True, "n_gpus": world, "steps": steps,
+                          "warmup": args.warmup, "value": n * steps * world / elapsed, "unit": "alignments/s",
+                          "ms_per_step": elapsed / steps * 1e3, "scaling": "weak"}))
 
 
 if __name__ == "__main__":

@@ -60,6 +60,13 @@ typedef struct {
     unsigned int sub_batches;          /* arena-bounded passes                            */
     size_t lds_bytes_tier0;
     int blocks_per_cu_tier0;
+    /* the longest wavefront-kernel launch of the call (the "main launch": a call also has short
+     * launches for the auto-budget sample and for re-runs) */
+    float main_launch_ms;
+    int main_launch_tier;
+    unsigned int main_launch_pairs;
+    unsigned long long main_launch_cells;
+    unsigned long long main_launch_seq_bytes;   /* packed sequence bytes its pairs read */
 } wfagpu_amd_stats_t;
 
 /* 0 on success, negative on error (message on stderr). */

@@ -190,3 +190,90 @@ def test_call_sharded_over_several_device_slots(golden_dir, monkeypatch, shards,
         if cigar:
             assert c == co
     lib.wfagpu_amd_release_cache()
+
+
+# ---- reader / writer fidelity (tools/aligner.c:148-165,476-513, utils/sequence_reader.c:118-392)
+
+def _fasta_files(tmp_path, pairs, n_q=None, n_t=None, eol="\n", width=(70, 61)):
+    q, t = tmp_path / "q.fasta", tmp_path / "t.fasta"
+    with open(q, "w", newline="") as fq, open(t, "w", newline="") as ft:
+        for i, (p, x) in enumerate(pairs):
+            if n_q is None or i < n_q:
+                fq.write(f">q{i} some description{eol}")
+                for j in range(0, len(p), width[0]):
+                    fq.write(p[j:j + width[0]].decode() + eol)
+            if n_t is None or i < n_t:
+                ft.write(f">t{i}{eol}")
+                for j in range(0, len(x), width[1]):
+                    ft.write(x[j:j + width[1]].decode() + eol)
+    return str(q), str(t)
+
+
+def test_cli_num_alignments_truncates_seq_and_fasta(golden_dir, tmp_path):
+    """-n (tools/aligner.c:148-165): only the first n pairs are read, in .seq and in paired FASTA input; the output has n
+    lines equal to the first n golden lines; n larger than the file reads everything."""
+    pairs = wfagpu.read_seq_file(os.path.join(golden_dir, "hifi.seq"))
+    gold = open(os.path.join(golden_dir, "hifi.g231.alg")).read().splitlines()
+    out = tmp_path / "n.out"
+    r = _run_cli(["-i", os.path.join(golden_dir, "hifi.seq"), "-n", "5", "-x", "-o", str(out)])
+    assert open(out).read().splitlines() == gold[:5]
+    assert "(5 pairs)" in r.stdout + r.stderr
+    q, t = _fasta_files(tmp_path, pairs)
+    _run_cli(["-Q", q, "-T", t, "-n", "3", "-x", "-o", str(out)])
+    assert open(out).read().splitlines() == gold[:3]
+    _run_cli(["-i", os.path.join(golden_dir, "hifi.seq"), "-n", "1000", "-x", "-o", str(out)])
+    assert open(out).read().splitlines() == gold
+
+
+def test_cli_verbose_output_and_print_to_stderr(golden_dir, tmp_path):
+    """-O adds the pattern and text columns (tools/aligner.c:505-508: "%d\\t%s\\t%s\\t%s"), for .seq AND for FASTA
+    input (the reference prints from the unused .seq reader there, SURVEY.md Appendix C -- fixed here); -p writes the
+    same lines to stderr instead of a file; score-only mode leaves the CIGAR column empty."""
+    pairs = wfagpu.read_seq_file(os.path.join(golden_dir, "hifi.seq"))[:4]
+    gold = open(os.path.join(golden_dir, "hifi.g231.alg")).read().splitlines()[:4]
+    want = [f"{g}\t{p.decode()}\t{t.decode()}" for g, (p, t) in zip(gold, pairs)]
+    out = tmp_path / "v.out"
+    _run_cli(["-i", os.path.join(golden_dir, "hifi.seq"), "-n", "4", "-x", "-O", "-o", str(out)])
+    assert open(out).read().splitlines() == want
+    q, t = _fasta_files(tmp_path, pairs)
+    _run_cli(["-Q", q, "-T", t, "-x", "-O", "-o", str(out)])
+    assert open(out).read().splitlines() == want
+    r = _run_cli(["-i", os.path.join(golden_dir, "hifi.seq"), "-n", "4", "-x", "-p"])
+    printed = [ln for ln in r.stderr.splitlines() if ln[:1] == "-" or ln[:1].isdigit()]
+    assert printed == gold
+    r = _run_cli(["-i", os.path.join(golden_dir, "hifi.seq"), "-n", "4", "-O", "-p"])
+    printed = [ln for ln in r.stderr.splitlines() if ln[:1] == "-" or ln[:1].isdigit()]
+    assert printed == [f"{g.split(chr(9))[0]}\t\t{p.decode()}\t{t.decode()}" for g, (p, t) in zip(gold, pairs)]
+
+
+def test_cli_unequal_fasta_record_counts_and_crlf(golden_dir, tmp_path):
+    """Paired FASTA files with a different number of records align the common prefix (with a warning); CRLF line ends
+    (.seq and FASTA) do not leak '\\r' into the sequences."""
+    pairs = wfagpu.read_seq_file(os.path.join(golden_dir, "hifi.seq"))[:6]
+    gold = open(os.path.join(golden_dir, "hifi.g231.alg")).read().splitlines()[:6]
+    out = tmp_path / "u.out"
+    q, t = _fasta_files(tmp_path, pairs, n_q=6, n_t=4)
+    r = _run_cli(["-Q", q, "-T", t, "-x", "-o", str(out)])
+    assert open(out).read().splitlines() == gold[:4]
+    assert "different number of records" in r.stdout + r.stderr
+    q, t = _fasta_files(tmp_path, pairs, eol="\r\n")
+    _run_cli(["-Q", q, "-T", t, "-x", "-c", "-o", str(out)])
+    assert open(out).read().splitlines() == gold
+    crlf = tmp_path / "crlf.seq"
+    with open(crlf, "wb") as f:
+        for p, x in pairs:
+            f.write(b">" + p + b"\r\n<" + x + b"\r\n")
+    _run_cli(["-i", str(crlf), "-x", "-o", str(out)])
+    assert open(out).read().splitlines() == gold
+
+
+def test_cli_rejects_bad_input(tmp_path):
+    """Malformed .seq input and missing files end with a non-zero exit code and a message, not a crash."""
+    bad = tmp_path / "bad.seq"
+    bad.write_text("<ACGT\n>ACGT\n")
+    r = subprocess.run([CLI, "-i", str(bad)], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "Malformed" in r.stdout + r.stderr
+    r = subprocess.run([CLI, "-i", str(tmp_path / "nope.seq")], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0
+    r = subprocess.run([CLI], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "No input file" in r.stdout + r.stderr

@@ -62,3 +62,42 @@ def test_two_rank_gloo_harness():
     assert e0 == e1 >= 0.1               # max over ranks, identical on both
     assert s0 != s1                      # different shards (different seeds)
     assert n0 + n1 == 128                # whole-job units = sum over ranks
+
+
+def _bench_json(args, env_extra=None):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout      # ONE JSON line, from rank 0 only
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_flag_starts_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT a torchrun environment must start 2 ranks itself (a torch.distributed.run child,
+    spawned before the parent touches any GPU) and report n_gpus = the ranks that really ran.  --cpu-harness swaps the
+    GPU step for the oracle and RCCL for gloo so that this launch path is covered here."""
+    out = _bench_json(["--gpus", "2", "--cpu-harness", "--steps", "2", "--warmup", "1"])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["harness_only"] is True
+    one = _bench_json(["--cpu-harness", "--steps", "2", "--warmup", "1"])
+    assert one["n_gpus"] == 1
+
+
+def test_bench_refuses_a_rank_count_that_differs_from_gpus():
+    """Launched by torchrun with 2 ranks but --gpus 4: the line would misreport n_gpus, so the run must fail."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "4", "--cpu-harness", "--steps", "1"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "started 2 ranks" in r.stderr + r.stdout

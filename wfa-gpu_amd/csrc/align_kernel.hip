@@ -143,6 +143,7 @@ wfa_align_kernel(const WfaAlignParams p) {
   else { book.A = reinterpret_cast<int*>(bslot + 2); book.I = book.A + (bkm + 1); book.D = book.I + (bkm + 1); }
 
   uint32_t chunk_cur = 0, chunk_left = 0;   // arena units owned by this block
+  unsigned long long blk_cells = 0;         // cells computed by this workgroup (reported once, at the end)
 
   // Work distribution: the list is cut into contiguous shards, each with its own counter on its
   // own cache line; a block starts on shard blockIdx % 8 and moves on when a shard is empty.  One
@@ -638,7 +639,12 @@ wfa_align_kernel(const WfaAlignParams p) {
       cp->status[pair] = status;
       if (cp->cells) cp->cells[pair] = ncells;
     }
+    blk_cells += ncells;
     block_sync<NW>();
+  }
+  if (tid == 0 && blk_cells) {
+    unsigned long long* lc = cold_params()->launch_cells;
+    if (lc) atomicAdd(lc, blk_cells);
   }
 }
 

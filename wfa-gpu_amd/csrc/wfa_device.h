@@ -67,6 +67,7 @@ struct WfaAlignParams {
   int32_t* score;                // [pair] out
   uint32_t* status;              // [pair] out
   uint32_t* cells;               // [pair] out, optional: number of wavefront cells computed
+  unsigned long long* launch_cells;  // optional: += cells computed by this launch (one atomic per workgroup)
   // backtrace (CIGAR mode)
   uint8_t* arena;                // base of the arena
   unsigned long long arena_units;        // capacity in 16-byte units

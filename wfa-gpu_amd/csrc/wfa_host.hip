@@ -80,7 +80,7 @@ struct DevBuf {
 };
 
 // device counters (u64 slots)
-enum { CT_ARENA = 0, CT_OPS = 1, CT_TEXT = 2, CT_WORK = 3, CT_LIST = 4, CT_SUM_OPS = 5, CT_SUM_TEXT = 6, CT_CELLS = 7, CT_N = 8 };
+enum { CT_ARENA = 0, CT_OPS = 1, CT_TEXT = 2, CT_LCELLS = 3, CT_LIST = 4, CT_SUM_OPS = 5, CT_SUM_TEXT = 6, CT_CELLS = 7, CT_N = 8 };
 
 constexpr uint32_t MASK(uint32_t st) { return 1u << st; }
 
@@ -417,6 +417,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   ap.cells = static_cast<uint32_t*>(c->cells.p);
   ap.work_counter = static_cast<unsigned int*>(c->work_ctr.p);
   ap.arena_top = ct + CT_ARENA;
+  ap.launch_cells = ct + CT_LCELLS;
   ap.chunk_units = 256;   // 4 KiB refills
   // tuning knob for experiments (not part of the interface)
   const char* env_chunk = getenv("WFAGPU_CHUNK_UNITS");
@@ -512,7 +513,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       // was the whole kernel time
       if (compute_cigar) ap.chunk_units = (uint32_t)std::min<unsigned long long>(env_chunk ? (unsigned)atoi(env_chunk) : 4096u, std::max<unsigned long long>(256, ap.arena_units / (4ull * (unsigned)grid)));
       { const char* es = getenv("WFAGPU_SHARDS"); ap.work_shards = es ? (uint32_t)atoi(es) : 8u; }
-      if (zero_counter(c, CT_LIST)) return -1;
+      if (zero_counter(c, CT_LCELLS, 2)) return -1;   // CT_LCELLS and CT_LIST
       HIP_TRY(hipMemsetAsync(c->work_ctr.p, 0, 8 * 64, st));
       HIP_TRY(hipEventRecord(c->ev_a0, st));
       wfa_launch_align(ap, tp.tier, compute_cigar, raw, grid, st);
@@ -526,6 +527,11 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       HIP_TRY(hipEventElapsedTime(&ms, c->ev_a0, c->ev_a1));
       align_ms += ms;
       c->stats.align_launches++;
+      if (ms > c->stats.main_launch_ms) {
+        c->stats.main_launch_ms = ms; c->stats.main_launch_tier = tp.tier; c->stats.main_launch_pairs = n_cur;
+        c->stats.main_launch_cells = c->h_counters[CT_LCELLS];
+        c->stats.main_launch_seq_bytes = (unsigned long long)((double)b->packed_bytes * n_cur / n);   // (share of the batch)
+      }
       const uint32_t n_next = (uint32_t)c->h_counters[CT_LIST];
       c->stats.pairs_tier[tp.tier] += n_cur - n_next;
       if (round == 0) c->stats.pairs_retried += n_next;

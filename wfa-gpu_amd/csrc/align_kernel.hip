@@ -35,6 +35,8 @@
 //     bump-allocated arena; a per-alignment row table (8 bytes per score) locates the rows.  No
 //     O(max_error^2) per-alignment reservation and nothing to memset between alignments.
 //   * A last-resort instantiation keeps a 32-bit ring in HBM/L2 for wavefronts too wide for LDS.
+#include <type_traits>
+
 #include "wfa_device.h"
 
 namespace {
@@ -101,6 +103,9 @@ template <int NW> struct RowBook {
     }
   }
 };
+
+// What the banded cells need to know about the rows they read (each lives at its own window base).
+struct BandCtx { bool mx_null, mo_null, ie_null, de_null; int mxlo, mxhi, molo, mohi, ielo, iehi, delo, dehi; };
 
 // Kernel arguments that are only needed between alignments (work list, result arrays, arena
 // bookkeeping) are re-read from the kernarg segment where they are used instead of being held in
@@ -210,11 +215,12 @@ wfa_align_kernel(const WfaAlignParams p) {
         whi = min(whi, tlen); wlo = max(wlo, -plen);
       }
     }
-    const int kidx0 = 1 - wlo;              // exact mode: row index of diagonal 0 (one guard cell each side)
+    const int kidx0 = dm - wlo;             // exact mode: row index of diagonal 0 (dm guard cells each side: the lean path
+                                            // re-NULLs up to dm cells beyond a row's ends without looking anything up)
 
     if (!feasible) {
       status = WFA_ST_SCORE;
-    } else if ((!BANDED && whi - wlo + 3 > rs) || pwords > p.seq_words_cap || twords > p.seq_words_cap) {
+    } else if ((!BANDED && whi - wlo + 1 + 2 * dm > rs) || pwords > p.seq_words_cap || twords > p.seq_words_cap) {
       status = WFA_ST_BAND;
     } else {
       // ---- stage the sequences, reset the ring ---------------------------------------------
@@ -262,10 +268,7 @@ wfa_align_kernel(const WfaAlignParams p) {
         if (status == WFA_ST_DONE) {
           tab_base = chunk_cur; row_s = chunk_cur + tab_units; chunk_cur += tab_units + 1; chunk_left -= tab_units + 1;
           tab = reinterpret_cast<uint2*>(p.arena + (size_t)tab_base * 16);
-          if (tid == 0) {
-            tab[0] = make_uint2(row_s, 0u);
-            p.arena[(size_t)row_s * 16] = 0;
-          }
+          if (tid == 0) p.arena[(size_t)row_s * 16] = 0;     // (its row-table entry: tab_set(0, ...) below)
         }
       }
       uint32_t d0 = 0;
@@ -280,10 +283,12 @@ wfa_align_kernel(const WfaAlignParams p) {
           if (n < PER) break;
         }
         Mr[BANDED ? 0 : kidx0] = (OffT)h0;
-        d0 = (kend == 0 && h0 >= tlen) ? 1u : 0u;
+        d0 = ((kend == 0 && h0 >= tlen) ? 1u : 0u) | (h0 >= min(plen, tlen) ? 2u : 0u);
       }
       book.set(0, pack_range(0, 0), ROW_NONE_A, ROW_NONE_A);
-      done = block_bcast<NW>(d0, bslot) != 0;
+      d0 = block_bcast<NW>(d0, bslot);
+      done = (d0 & 1u) != 0;
+      const bool touched_at_0 = (d0 & 2u) != 0;
       block_sync<NW>();
 
       // Ring state of score s, as row pointers that advance by one row per score (no multiply, no modulo
@@ -309,8 +314,255 @@ wfa_align_kernel(const WfaAlignParams p) {
       // untrimmed limits.  Once that covers every row the recurrences read, the limits follow from the M
       // limits alone and none of the "no wavefront" cases of wavefront_compute.c:41-71 can occur.
       int regular = 0;
+      // Backtrace row of `width` origin bytes for the current score: bump allocation from the block's
+      // arena chunk, refilled with one atomic when it runs dry.  false: arena exhausted.
+      auto alloc_row = [&](int width) -> bool {
+        const uint32_t need = ((uint32_t)width + 15u) >> 4;
+        if (need > chunk_left) {
+          ColdParams cp = cold_params();
+          const uint32_t grab = max(need, cp->chunk_units);
+          uint32_t base = WFA_ROW_NONE;
+          if (tid == 0) {
+            const unsigned long long b = atomicAdd(cp->arena_top, (unsigned long long)grab);
+            if (b + grab <= cp->arena_units) base = (uint32_t)b;
+          }
+          base = block_bcast<NW>(base, bslot);
+          if (base == WFA_ROW_NONE) { chunk_left = 0; return false; }
+          chunk_cur = base; chunk_left = grab;
+        }
+        row_s = chunk_cur; chunk_cur += need; chunk_left -= need;
+        return true;
+      };
+      // Row-table entry of score s.  One wavefront: entries collect in two VGPRs (lane = score & 63) and go out
+      // as one coalesced 512-byte store every 64 scores (and at the end of the alignment) instead of one
+      // single-lane store + address arithmetic per score.
+      int tabv_row = 0, tabv_lo = 0, tab_group = 0;     // the buffered entries belong to scores [64 * tab_group, 64 * tab_group + 63]
+      auto tab_set = [&](int score, uint32_t row, int lo_) {
+        if constexpr (NW == 1) {
+          if ((score >> 6) != tab_group) {
+            // (scores without a wavefront leave their lanes stale: such entries are never read)
+            tab[(tab_group << 6) + lane] = make_uint2((uint32_t)tabv_row, (uint32_t)tabv_lo);
+            tab_group = score >> 6;
+          }
+          const bool mine = lane == (score & 63);
+          tabv_row = mine ? (int)row : tabv_row; tabv_lo = mine ? lo_ : tabv_lo;
+        } else {
+          if (tid == 0) tab[score] = make_uint2(row, (uint32_t)lo_);
+        }
+      };
+      auto tab_flush = [&](int score) {       // the last group, up to the final score
+        if constexpr (NW == 1) {
+          if (lane <= (score & 63)) tab[(score & ~63) + lane] = make_uint2((uint32_t)tabv_row, (uint32_t)tabv_lo);
+        }
+      };
+      if constexpr (BT) { if (status == WFA_ST_DONE) tab_set(0, row_s, 0); }
+      // ---- the cells of one score.  Lanes past the end recompute cell `hi` (same values, same
+      // addresses), so no store needs an exec mask.  The vector ALU is the unit this kernel saturates (one
+      // integer wave64 instruction holds its SIMD for 4 cycles), so everything uniform is folded into scalar
+      // row bases: each LDS address is one v_lshl_add of the diagonal.
+      //   rb_mx[k] = M[s-x][k]   rb_mo[k] = M[s-o-e][k-1], rb_mo[k+2] = M[s-o-e][k+1]
+      //   rb_ie[k] = I[s-e][k-1] rb_de[k] = D[s-e][k+1]     wb_*[k]: the rows written now
+      // LEAN (regular regime, no cell has touched a sequence end yet): no value can run past an end, so the
+      // overrun test and the saturation of I are dropped.  my_touch: an M cell reached min(plen + k, tlen).
+      auto cells_of_score = [&](auto lean_tag, const int lo, const int hi, uint8_t* codes, const OffT* rb_mx, const OffT* rb_mo,
+                                const OffT* rb_ie, const OffT* rb_de, OffT* wb_m, OffT* wb_i, OffT* wb_d, const BandCtx& bc,
+                                bool& my_over, bool& my_touch) {
+        constexpr bool LEAN = decltype(lean_tag)::value;
+        for (int k0 = lo; k0 <= hi; k0 += NT) {
+          const int k = min(k0 + tid, hi);
+          // recurrences (wavefront_compute_affine.c:66-84)
+          int m_x, m_ol, m_or, i_e, d_e;
+          if constexpr (BANDED) {
+            // rows live at their own window base: form the index only for diagonals inside the row
+            const bool in_x = !bc.mx_null && (unsigned)(k - bc.mxlo) <= (unsigned)(bc.mxhi - bc.mxlo);
+            const bool in_ol = !bc.mo_null && (unsigned)(k - 1 - bc.molo) <= (unsigned)(bc.mohi - bc.molo);
+            const bool in_or = !bc.mo_null && (unsigned)(k + 1 - bc.molo) <= (unsigned)(bc.mohi - bc.molo);
+            const bool in_ie = !bc.ie_null && (unsigned)(k - 1 - bc.ielo) <= (unsigned)(bc.iehi - bc.ielo);
+            const bool in_de = !bc.de_null && (unsigned)(k + 1 - bc.delo) <= (unsigned)(bc.dehi - bc.delo);
+            m_x = in_x ? (int)rb_mx[k] : OFF_NULL;
+            m_ol = in_ol ? (int)rb_mo[k] : OFF_NULL;
+            m_or = in_or ? (int)rb_mo[k + 2] : OFF_NULL;
+            i_e = in_ie ? (int)rb_ie[k] : OFF_NULL;
+            d_e = in_de ? (int)rb_de[k] : OFF_NULL;
+          } else {
+            m_x = (int)rb_mx[k];
+            m_ol = (int)rb_mo[k];
+            m_or = (int)rb_mo[k + 2];
+            i_e = (int)rb_ie[k];
+            d_e = (int)rb_de[k];
+          }
+          const int ins = max(m_ol, i_e) + 1;
+          const int del = max(m_or, d_e);
+          const int mis = m_x + 1;
+          const int mv0 = max(del, max(mis, ins));
+          // !(h > tlen || v > plen), unsigned so that negatives fail too
+          const bool ok = ((unsigned)mv0 <= (unsigned)tlen) && ((unsigned)(mv0 - k) <= (unsigned)plen);
+          uint32_t code = 0;
+          if constexpr (BT) {
+            // tie-breaks: gap extension wins over gap open on equal offsets
+            // (wavefront_compute_affine.c:135-143,153-161); for M: mismatch, then deletion, then
+            // insertion (wavefront_backtrace.c:48-59)
+            // (the M origin of a cell that is not valid is never read: the backtrace only visits valid cells)
+            code = (i_e >= m_ol ? BT_I_EXT : 0u) | (d_e >= m_or ? BT_D_EXT : 0u);
+            code |= (mis == mv0) ? BT_M_X : ((del == mv0) ? BT_M_D : BT_M_I);
+          }
+          // An I (D) value can only be out of range by running past the text (pattern) end; such
+          // values are rare (last scores only) and send the row through the exact trimming pass
+          // below.  Everywhere else "invalid" means negative, which already reads as NULL, so the
+          // computed limits can stand in for the trimmed ones.
+          if constexpr (!LEAN) my_over |= (ins > tlen) || (del - k > plen);
+          // extend = longest common prefix from (v,h) (wavefront_extend.c:174-199), PER symbols per step, under
+          // the exec mask of the valid cells.  The first step is straight-line code (most cells stop inside their
+          // first word); only when some lane matched a whole word with more to go does the wave enter the loop,
+          // in which lanes that are done carry left == 0 and idle along.
+          int h = mv0;
+          if (ok) {
+            constexpr int SH = RAW ? 2 : 4, PER = 1 << SH, BITS = RAW ? 3 : 1;
+            const int v = mv0 - k;
+            // the run cannot pass either sequence end: h <= tlen and v = h - k <= plen
+            const int hmax = min(plen + k, tlen);
+            const int rem = hmax - h;
+            // word pointers and bit offsets are fixed for the whole run: a lane that goes on has
+            // consumed exactly PER symbols = one word
+            const char* pp = reinterpret_cast<const char*>(Pw + (v >> SH));
+            const char* tp = reinterpret_cast<const char*>(Tw + (h >> SH));
+            const uint32_t sa = (uint32_t)v << BITS, sb = (uint32_t)h << BITS;
+            uint32_t fb;
+            {
+              const uint32_t* pw = reinterpret_cast<const uint32_t*>(pp);
+              const uint32_t* tw = reinterpret_cast<const uint32_t*>(tp);
+              const uint32_t d = __builtin_amdgcn_alignbit(pw[1], pw[0], sa) ^ __builtin_amdgcn_alignbit(tw[1], tw[0], sb);
+              // v_ffbl_b32 returns 0xFFFFFFFF for 0, so "all equal" is a huge positive count
+              asm("v_ffbl_b32 %0, %1" : "=v"(fb) : "v"(d));
+            }
+            const int n = (int)(fb >> BITS);
+            h += min(min(n, PER), rem);
+            // goes on iff the whole word matched and more than a word remains
+            bool more = min(n, rem - 1) >= PER;
+            if (__builtin_amdgcn_ballot_w64(more) != 0ull) {
+              int left = more ? rem - PER : 0;
+              do {
+                pp += 4; tp += 4;
+                const uint32_t* pw = reinterpret_cast<const uint32_t*>(pp);
+                const uint32_t* tw = reinterpret_cast<const uint32_t*>(tp);
+                const uint32_t d = __builtin_amdgcn_alignbit(pw[1], pw[0], sa) ^ __builtin_amdgcn_alignbit(tw[1], tw[0], sb);
+                asm("v_ffbl_b32 %0, %1" : "=v"(fb) : "v"(d));
+                const int nn = min(min((int)(fb >> BITS), PER), left);
+                h += nn;
+                left = (nn == PER) ? left - PER : 0;
+              } while (__builtin_amdgcn_ballot_w64(left > 0) != 0ull);
+            }
+            my_touch |= h == hmax;
+          }
+          const int mv = ok ? h : OFF_NULL;
+          // M and D offsets never exceed the text length, so they fit 16 bits as they are; only an I
+          // chain running past the text end keeps growing and is saturated by off_store
+          wb_m[k] = (OffT)mv;
+          if constexpr (LEAN) wb_i[k] = (OffT)ins; else wb_i[k] = off_store<OffT>(ins);
+          wb_d[k] = (OffT)del;
+          if constexpr (BT) codes[(uint32_t)(k - lo)] = (uint8_t)code;
+        }
+      };
+      // Limits of the last score (the lean path derives the next ones from them alone).
+      int last_lo = 0, last_hi = 0;
+      // Has any M cell reached the end of a sequence (offset == min(plen + k, tlen)) so far?  Only after that can an
+      // I or D value run past a sequence end (every such value has a predecessor chain that starts at an M cell sitting
+      // on the border), and only such a cell can be the final one.  Until then the lean path needs neither the
+      // per-cell overrun tests nor the per-score termination read.
+      bool touched_ever = touched_at_0 || cold_params()->no_lean != 0;    // (WFAGPU_NO_LEAN: the lean path is never entered)
       // ---- score loop ----------------------------------------------------------------------------
       if (!done && status == WFA_ST_DONE) for (;;) {
+        // ---- lean path: gap extension 1, every row the recurrences read is regular (all three components over the
+        // computed limits) and no cell has touched a sequence end.  Then nothing can be trimmed, no "no wavefront"
+        // case can occur, and with e == 1 the limits of wavefront_compute.c:41-71 collapse to [lo - 1, hi + 1] of the
+        // last score (the I and D rows of s-1 span its M limits), clipped by the window and the budget's reach.
+        // An inner loop with its own small state: the instruction-issue pipes are what this kernel saturates, and
+        // the scalar registers are what the compiler runs out of (every spilled one comes back through the vector unit).
+        if constexpr (!BANDED) {
+          if (e == 1 && regular >= dm && !touched_ever) {
+            int lo = last_lo, hi = last_hi;
+            // (e == 1: the reach interval is [kend - (budget - s), kend + (budget - s)]; `reach` is budget - s)
+            int reach = bounded ? budget - s : INT_MAX / 2;
+            const int s_in = s;
+            // the I/D ring has two rows: "advance with wrap" is a swap
+            OffT* i_cur = p_ic; OffT* i_prev = p_ip;
+            bool nomem = false;
+            for (;;) {
+              int nlo = max(lo - 1, wlo), nhi = min(hi + 1, whi);
+              if constexpr (NW == 1) asm volatile("" : "+s"(nlo), "+s"(nhi));   // (keeps the chains off v_max3/v_min3)
+              nlo = max(nlo, kend - (reach - 1)); nhi = min(nhi, kend + (reach - 1));
+              if (nlo > nhi) break;
+              lo = nlo; hi = nhi;
+              ++s; --reach;
+              if constexpr (NW > 1) {
+                if (tid < 8) red[8 * ((s + 1) % 3) + tid] = (tid == 6) ? 0 : ((tid & 1) ? INT_MIN : INT_MAX);
+              }
+              p_m += rs;  if (p_m == m_end) p_m = m_first;
+              p_x += rs;  if (p_x == m_end) p_x = m_first;
+              p_oe += rs; if (p_oe == m_end) p_oe = m_first;
+              { OffT* t = i_cur; i_cur = i_prev; i_prev = t; }
+              const int width = hi - lo + 1;
+              ncells += (uint32_t)width;
+              uint8_t* codes = nullptr;
+              if constexpr (BT) {
+                if (!alloc_row(width)) { nomem = true; break; }
+                if constexpr (NW == 1) {
+                  // row table, buffered by lane: a new group of 64 scores starts at every multiple of 64
+                  if ((s & 63) == 0) tab[s - 64 + lane] = make_uint2((uint32_t)tabv_row, (uint32_t)tabv_lo);
+                  const bool mine = lane == (s & 63);
+                  tabv_row = mine ? (int)row_s : tabv_row; tabv_lo = mine ? lo : tabv_lo;
+                } else {
+                  if (tid == 0) tab[s] = make_uint2(row_s, (uint32_t)lo);
+                }
+                codes = p.arena + (size_t)row_s * 16;
+              }
+              OffT* out_m = p_m; OffT* out_i = i_cur; OffT* out_d = i_cur + d_off;
+              // Ring invariant: the slots written now last held scores s-dm (M) and s-2 (I, D), whose limits differ from
+              // [lo, hi] by at most dm diagonals per side (the limits move by at most one diagonal per score here):
+              // NULL the dm cells beyond each end, wherever they stand (rows carry dm guard cells per side).
+              for (int j = tid; j < 2 * dm; j += NT) {
+                const int q = (j < dm) ? lo - 1 - j : hi + 1 + (j - dm);
+                out_m[q] = (OffT)OFF_NULL; out_i[q] = (OffT)OFF_NULL; out_d[q] = (OffT)OFF_NULL;
+              }
+              bool my_over = false, my_touch = false;
+              cells_of_score(std::true_type{}, lo, hi, codes, p_x, p_oe - 1, i_prev - 1, i_prev + d_off + 1, out_m, out_i, out_d, BandCtx{},
+                             my_over, my_touch);
+              const bool wave_touch = __builtin_amdgcn_ballot_w64(my_touch) != 0ull;
+              bool any_touch;
+              if constexpr (NW == 1) {
+                block_sync<NW>();
+                any_touch = wave_touch;
+              } else {
+                int* acc = red + 8 * (s % 3);
+                if (lane == 0 && wave_touch) atomicOr(&acc[6], 4);
+                __syncthreads();
+                any_touch = (acc[6] & 4) != 0;
+              }
+              const int lim = pack_range(lo, hi);
+              book.set(s & bkm, lim, lim, lim);
+              if constexpr (NW == 1) block_sync<NW>();
+              if (any_touch) {
+                // a cell sits on a sequence end: it may be the last one (wavefront_extend.c:47-67), and from the next
+                // score on values may run past the ends -- the careful path takes over
+                touched_ever = true;
+                done = ((unsigned)(kend - lo) <= (unsigned)(hi - lo)) && __builtin_amdgcn_readfirstlane((int)out_m[kend]) >= tlen;
+                break;
+              }
+            }
+            // back to the general state
+            const int n_lean = s - s_in;
+            regular += n_lean;
+            last_lo = lo; last_hi = hi;
+            p_ic = i_cur; p_ip = i_prev;
+            if (bounded) { rlo += n_lean; rhi -= n_lean; }
+            tab_group = s >> 6;
+            if (nomem) { status = WFA_ST_NOMEM; break; }
+            if (done) break;
+            if (n_lean > 0 && !touched_ever) {
+              // left because the reach interval is empty: the careful path reports it (no wavefront at s + 1, budget exhausted)
+            }
+          }
+        }
         ++s;
         // (exact mode: past the budget the reach interval is empty, so the test sits on the "no wavefront" path)
         if constexpr (BANDED) { if (s > budget) { status = WFA_ST_SCORE; break; } }
@@ -425,21 +677,8 @@ wfa_align_kernel(const WfaAlignParams p) {
 
         uint8_t* codes = nullptr;
         if constexpr (BT) {
-          const uint32_t need = ((uint32_t)width + 15u) >> 4;
-          if (need > chunk_left) {
-            ColdParams cp = cold_params();
-            const uint32_t grab = max(need, cp->chunk_units);
-            uint32_t base = WFA_ROW_NONE;
-            if (tid == 0) {
-              const unsigned long long b = atomicAdd(cp->arena_top, (unsigned long long)grab);
-              if (b + grab <= cp->arena_units) base = (uint32_t)b;
-            }
-            base = block_bcast<NW>(base, bslot);
-            if (base == WFA_ROW_NONE) { status = WFA_ST_NOMEM; chunk_left = 0; break; }
-            chunk_cur = base; chunk_left = grab;
-          }
-          row_s = chunk_cur; chunk_cur += need; chunk_left -= need;
-          if (tid == 0) tab[s] = make_uint2(row_s, (uint32_t)lo);
+          if (!alloc_row(width)) { status = WFA_ST_NOMEM; break; }
+          tab_set(s, row_s, lo);
           codes = p.arena + (size_t)row_s * 16;
         }
 
@@ -475,101 +714,26 @@ wfa_align_kernel(const WfaAlignParams p) {
         OffT* wb_m = out_m + wbase;
         OffT* wb_i = out_i + wbase;
         OffT* wb_d = out_d + wbase;
-        bool my_over = false;
-        for (int k0 = lo; k0 <= hi; k0 += NT) {
-          const int k = min(k0 + tid, hi);
-          // recurrences (wavefront_compute_affine.c:66-84)
-          int m_x, m_ol, m_or, i_e, d_e;
-          if constexpr (BANDED) {
-            // rows live at their own window base: form the index only for diagonals inside the row
-            const bool in_x = !mx_null && (unsigned)(k - mxlo) <= (unsigned)(mxhi - mxlo);
-            const bool in_ol = !mo_null && (unsigned)(k - 1 - molo) <= (unsigned)(mohi - molo);
-            const bool in_or = !mo_null && (unsigned)(k + 1 - molo) <= (unsigned)(mohi - molo);
-            const bool in_ie = !ie_null && (unsigned)(k - 1 - ielo) <= (unsigned)(iehi - ielo);
-            const bool in_de = !de_null && (unsigned)(k + 1 - delo) <= (unsigned)(dehi - delo);
-            m_x = in_x ? (int)rb_mx[k] : OFF_NULL;
-            m_ol = in_ol ? (int)rb_mo[k] : OFF_NULL;
-            m_or = in_or ? (int)rb_mo[k + 2] : OFF_NULL;
-            i_e = in_ie ? (int)rb_ie[k] : OFF_NULL;
-            d_e = in_de ? (int)rb_de[k] : OFF_NULL;
-          } else {
-            m_x = (int)rb_mx[k];
-            m_ol = (int)rb_mo[k];
-            m_or = (int)rb_mo[k + 2];
-            i_e = (int)rb_ie[k];
-            d_e = (int)rb_de[k];
-          }
-          const int ins = max(m_ol, i_e) + 1;
-          const int del = max(m_or, d_e);
-          const int mis = m_x + 1;
-          const int mv0 = max(del, max(mis, ins));
-          // !(h > tlen || v > plen), unsigned so that negatives fail too
-          const bool ok = ((unsigned)mv0 <= (unsigned)tlen) && ((unsigned)(mv0 - k) <= (unsigned)plen);
-          uint32_t code = 0;
-          if constexpr (BT) {
-            // tie-breaks: gap extension wins over gap open on equal offsets
-            // (wavefront_compute_affine.c:135-143,153-161); for M: mismatch, then deletion, then
-            // insertion (wavefront_backtrace.c:48-59)
-            // (the M origin of a cell that is not valid is never read: the backtrace only visits valid cells)
-            code = (i_e >= m_ol ? BT_I_EXT : 0u) | (d_e >= m_or ? BT_D_EXT : 0u);
-            code |= (mis == mv0) ? BT_M_X : ((del == mv0) ? BT_M_D : BT_M_I);
-          }
-          // An I (D) value can only be out of range by running past the text (pattern) end; such
-          // values are rare (last scores only) and send the row through the exact trimming pass
-          // below.  Everywhere else "invalid" means negative, which already reads as NULL, so the
-          // computed limits can stand in for the trimmed ones.
-          my_over |= (ins > tlen) || (del - k > plen);
-          // extend = longest common prefix from (v,h) (wavefront_extend.c:174-199), PER symbols per
-          // iteration, under the exec mask of the valid cells (scalar-unit work is cheap here); lanes
-          // that are done carry rem == 0 and idle along
-          int h = mv0;
-          if (ok) {
-            constexpr int SH = RAW ? 2 : 4, PER = 1 << SH, BITS = RAW ? 3 : 1;
-            const int v = mv0 - k;
-            int rem = min(plen - v, tlen - h);
-            // word pointers and bit offsets are fixed for the whole run: a lane that goes on has
-            // consumed exactly PER symbols = one word
-            const char* pp = reinterpret_cast<const char*>(Pw + (v >> SH));
-            const char* tp = reinterpret_cast<const char*>(Tw + (h >> SH));
-            const uint32_t sa = (uint32_t)v << BITS, sb = (uint32_t)h << BITS;
-            bool more;
-            do {
-              const uint32_t* pw = reinterpret_cast<const uint32_t*>(pp);
-              const uint32_t* tw = reinterpret_cast<const uint32_t*>(tp);
-              const uint32_t a = __builtin_amdgcn_alignbit(pw[1], pw[0], sa);
-              const uint32_t b = __builtin_amdgcn_alignbit(tw[1], tw[0], sb);
-              const uint32_t d = a ^ b;
-              // v_ffbl_b32 returns 0xFFFFFFFF for 0, so "all equal" falls out of the cap at PER
-              uint32_t fb;
-              asm("v_ffbl_b32 %0, %1" : "=v"(fb) : "v"(d));
-              const int n = (int)min(min(fb >> BITS, (uint32_t)PER), (uint32_t)rem);
-              h += n;
-              const bool full = n == PER;
-              rem = full ? rem - PER : 0;
-              const int adv = full ? 4 : 0;
-              pp += adv; tp += adv;
-              more = rem > 0;
-            } while (__builtin_amdgcn_ballot_w64(more) != 0ull);
-          }
-          const int mv = ok ? h : OFF_NULL;
-          // M and D offsets never exceed the text length, so they fit 16 bits as they are; only an I
-          // chain running past the text end keeps growing and is saturated by off_store
-          wb_m[k] = (OffT)mv;
-          wb_i[k] = off_store<OffT>(ins);
-          wb_d[k] = (OffT)del;
-          if constexpr (BT) codes[(uint32_t)(k - lo)] = (uint8_t)code;
+        bool my_over = false, my_touch = false;
+        {
+          BandCtx bc;
+          if constexpr (BANDED) bc = BandCtx{mx_null, mo_null, ie_null, de_null, mxlo, mxhi, molo, mohi, ielo, iehi, delo, dehi};
+          cells_of_score(std::false_type{}, lo, hi, codes, rb_mx, rb_mo, rb_ie, rb_de, wb_m, wb_i, wb_d, bc, my_over, my_touch);
         }
         bool any_over = false;
         {
           const bool wave_over = __builtin_amdgcn_ballot_w64(my_over) != 0ull;
+          const bool wave_touch = __builtin_amdgcn_ballot_w64(my_touch) != 0ull;
           if constexpr (NW == 1) {
             block_sync<NW>();
             any_over = wave_over;
+            touched_ever |= wave_touch;
           } else {
             int* acc = red + 8 * (s % 3);
-            if (lane == 0 && wave_over) atomicOr(&acc[6], 2);
+            if (lane == 0 && (wave_over || wave_touch)) atomicOr(&acc[6], (wave_over ? 2 : 0) | (wave_touch ? 4 : 0));
             __syncthreads();
             any_over = (acc[6] & 2) != 0;
+            touched_ever |= (acc[6] & 4) != 0;
           }
           // termination (wavefront_extend.c:47-67): every lane reads the same cell
           done = ((unsigned)(kend - lo) <= (unsigned)(hi - lo)) && __builtin_amdgcn_readfirstlane((int)wb_m[kend]) >= tlen;
@@ -582,6 +746,7 @@ wfa_align_kernel(const WfaAlignParams p) {
           const int lim = pack_range(lo, hi);
           ++regular;
           book.set(bk_s, lim, lim, lim);
+          last_lo = lo; last_hi = hi;
           if constexpr (NW == 1) block_sync<NW>();
           if (done) break;
           continue;
@@ -626,11 +791,15 @@ wfa_align_kernel(const WfaAlignParams p) {
         }
         regular = (have_i && have_d && !any_over) ? regular + 1 : 0;
         book.set(bk_s, pack_range(lo, hi), lim_i, lim_d);
+        last_lo = lo; last_hi = hi;
         if constexpr (NW == 1) block_sync<NW>();
         if (done) break;
       }
-      if (tid == 0 && status == WFA_ST_DONE) {
-        if constexpr (BT) cold_params()->bt_final_row[pair] = tab_base;
+      if constexpr (BT) {
+        if (status == WFA_ST_DONE) {
+          tab_flush(s);
+          if (tid == 0) cold_params()->bt_final_row[pair] = tab_base;
+        }
       }
     }
     if (tid == 0) {

@@ -64,6 +64,7 @@ struct WfaAlignParams {
   int band_width;                // > 0: adaptive band, diagonals kept per wavefront (banded kernels)
   int band_period;               //      re-centre the band every this many scores
   int seq_words_cap;             // LDS words reserved per packed sequence
+  int no_lean;                   // diagnostics (WFAGPU_NO_LEAN): keep every score on the careful path
   int32_t* score;                // [pair] out
   uint32_t* status;              // [pair] out
   uint32_t* cells;               // [pair] out, optional: number of wavefront cells computed

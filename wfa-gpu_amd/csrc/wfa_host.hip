@@ -328,7 +328,7 @@ bool plan_tier(const wfagpu_amd_ctx* c, WfaAlignParams& p, int max_score, unsign
     return true;
   }
   const int width = window_width(max_score, p.oe - p.e, p.e, max_seq_len);
-  p.rs = (width + 3 + 1) & ~1;
+  p.rs = (width + 1 + 2 * p.dm + 1) & ~1;     // dm guard cells on each side of a row (see the kernel's lean path)
   const bool i16_ok = max_seq_len <= 32766u && max_score <= 30000;
   const size_t budget[3] = {40u << 10, 80u << 10, c->lds_per_block_max};
   // WFAGPU_MIN_TIER (tests): skip the smaller tiers so that the rarely needed ones get exercised
@@ -418,6 +418,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   ap.work_counter = static_cast<unsigned int*>(c->work_ctr.p);
   ap.arena_top = ct + CT_ARENA;
   ap.launch_cells = ct + CT_LCELLS;
+  ap.no_lean = getenv("WFAGPU_NO_LEAN") ? 1 : 0;
   ap.chunk_units = 256;   // 4 KiB refills
   // tuning knob for experiments (not part of the interface)
   const char* env_chunk = getenv("WFAGPU_CHUNK_UNITS");

@@ -51,6 +51,11 @@ template <> __device__ __forceinline__ int16_t off_store<int16_t>(int v) {
 }
 template <> __device__ __forceinline__ int32_t off_store<int32_t>(int v) { return v; }
 
+// LDS byte address of a pointer into the dynamic shared array (for hand-written DS instructions)
+template <typename T> __device__ __forceinline__ uint32_t lds_addr(const T* p) {
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+
 template <int NW> __device__ __forceinline__ void block_sync() {
   if constexpr (NW == 1) {
     // single wavefront: DS/VMEM operations issue in program order, only the compiler has to be
@@ -371,77 +376,104 @@ wfa_align_kernel(const WfaAlignParams p) {
         for (int k0 = lo; k0 <= hi; k0 += NT) {
           const int k = min(k0 + tid, hi);
           // recurrences (wavefront_compute_affine.c:66-84)
-          int m_x, m_ol, m_or, i_e, d_e;
-          if constexpr (BANDED) {
-            // rows live at their own window base: form the index only for diagonals inside the row
-            const bool in_x = !bc.mx_null && (unsigned)(k - bc.mxlo) <= (unsigned)(bc.mxhi - bc.mxlo);
-            const bool in_ol = !bc.mo_null && (unsigned)(k - 1 - bc.molo) <= (unsigned)(bc.mohi - bc.molo);
-            const bool in_or = !bc.mo_null && (unsigned)(k + 1 - bc.molo) <= (unsigned)(bc.mohi - bc.molo);
-            const bool in_ie = !bc.ie_null && (unsigned)(k - 1 - bc.ielo) <= (unsigned)(bc.iehi - bc.ielo);
-            const bool in_de = !bc.de_null && (unsigned)(k + 1 - bc.delo) <= (unsigned)(bc.dehi - bc.delo);
-            m_x = in_x ? (int)rb_mx[k] : OFF_NULL;
-            m_ol = in_ol ? (int)rb_mo[k] : OFF_NULL;
-            m_or = in_or ? (int)rb_mo[k + 2] : OFF_NULL;
-            i_e = in_ie ? (int)rb_ie[k] : OFF_NULL;
-            d_e = in_de ? (int)rb_de[k] : OFF_NULL;
-          } else {
-            m_x = (int)rb_mx[k];
-            m_ol = (int)rb_mo[k];
-            m_or = (int)rb_mo[k + 2];
-            i_e = (int)rb_ie[k];
-            d_e = (int)rb_de[k];
-          }
-          const int ins = max(m_ol, i_e) + 1;
-          const int del = max(m_or, d_e);
-          const int mis = m_x + 1;
-          const int mv0 = max(del, max(mis, ins));
-          // !(h > tlen || v > plen), unsigned so that negatives fail too
-          const bool ok = ((unsigned)mv0 <= (unsigned)tlen) && ((unsigned)(mv0 - k) <= (unsigned)plen);
+          constexpr bool TAGGED = LEAN && !GLOBAL_RING && !BANDED && sizeof(OffT) == 2;
+          int ins, del, mv0;
           uint32_t code = 0;
-          if constexpr (BT) {
-            // tie-breaks: gap extension wins over gap open on equal offsets
-            // (wavefront_compute_affine.c:135-143,153-161); for M: mismatch, then deletion, then
-            // insertion (wavefront_backtrace.c:48-59)
-            // (the M origin of a cell that is not valid is never read: the backtrace only visits valid cells)
-            code = (i_e >= m_ol ? BT_I_EXT : 0u) | (d_e >= m_or ? BT_D_EXT : 0u);
-            code |= (mis == mv0) ? BT_M_X : ((del == mv0) ? BT_M_D : BT_M_I);
+          int ins_hi = 0, del_hi = 0;           // TAGGED: values whose high halves are stored
+          if constexpr (TAGGED) {
+            // Offsets go to the high halves, the role of each value (its origin bits, see wfa_device.h) to the low
+            // halves -- one v_lshl_add/v_lshl_or per value, which also carries the "+1" of the insertion and
+            // mismatch candidates.  A signed max then picks the larger offset and, on equal offsets, the source WFA2
+            // prefers (extension over open; mismatch, then deletion, then insertion), and the origin byte is two
+            // bit-field inserts of the winners' low bits.  (The MI355X runs with SRAM ECC on, where d16_hi loads zero
+            // the other half of their destination: the role bits cannot simply be left standing in the registers.)
+            const uint32_t u_ol = (uint16_t)rb_mo[k], u_or = (uint16_t)rb_mo[k + 2], u_ie = (uint16_t)rb_ie[k],
+                           u_de = (uint16_t)rb_de[k], u_x = (uint16_t)rb_mx[k];
+            const int ins_c = max((int)((u_ol << 16) + (0x10000u | BT_M_I)), (int)((u_ie << 16) + (0x10000u | BT_M_I | BT_I_EXT)));
+            const int del_t = max((int)((u_or << 16) | BT_M_D), (int)((u_de << 16) | (BT_M_D | BT_D_EXT)));
+            const int mis_c = (int)((u_x << 16) + (0x10000u | BT_M_X));
+            const int mv_t = max(del_t, max(mis_c, ins_c));
+            if constexpr (BT) {
+              uint32_t c1;
+              asm("v_bfi_b32 %0, 2, %1, %2" : "=v"(c1) : "v"(del_t), "v"(mv_t));      // bit 1 from the deletion winner
+              asm("v_bfi_b32 %0, 1, %1, %2" : "=v"(code) : "v"(ins_c), "v"(c1));      // bit 0 from the insertion winner
+            }
+            mv0 = mv_t >> 16;
+            ins_hi = ins_c; del_hi = del_t;
+            ins = 0; del = 0;
+          } else {
+            int m_x, m_ol, m_or, i_e, d_e;
+            if constexpr (BANDED) {
+              // rows live at their own window base: form the index only for diagonals inside the row
+              const bool in_x = !bc.mx_null && (unsigned)(k - bc.mxlo) <= (unsigned)(bc.mxhi - bc.mxlo);
+              const bool in_ol = !bc.mo_null && (unsigned)(k - 1 - bc.molo) <= (unsigned)(bc.mohi - bc.molo);
+              const bool in_or = !bc.mo_null && (unsigned)(k + 1 - bc.molo) <= (unsigned)(bc.mohi - bc.molo);
+              const bool in_ie = !bc.ie_null && (unsigned)(k - 1 - bc.ielo) <= (unsigned)(bc.iehi - bc.ielo);
+              const bool in_de = !bc.de_null && (unsigned)(k + 1 - bc.delo) <= (unsigned)(bc.dehi - bc.delo);
+              m_x = in_x ? (int)rb_mx[k] : OFF_NULL;
+              m_ol = in_ol ? (int)rb_mo[k] : OFF_NULL;
+              m_or = in_or ? (int)rb_mo[k + 2] : OFF_NULL;
+              i_e = in_ie ? (int)rb_ie[k] : OFF_NULL;
+              d_e = in_de ? (int)rb_de[k] : OFF_NULL;
+            } else {
+              m_x = (int)rb_mx[k];
+              m_ol = (int)rb_mo[k];
+              m_or = (int)rb_mo[k + 2];
+              i_e = (int)rb_ie[k];
+              d_e = (int)rb_de[k];
+            }
+            ins = max(m_ol, i_e) + 1;
+            del = max(m_or, d_e);
+            const int mis = m_x + 1;
+            mv0 = max(del, max(mis, ins));
+            if constexpr (BT) {
+              // tie-breaks: gap extension wins over gap open on equal offsets
+              // (wavefront_compute_affine.c:135-143,153-161); for M: mismatch, then deletion, then
+              // insertion (wavefront_backtrace.c:48-59)
+              // (the M origin of a cell that is not valid is never read: the backtrace only visits valid cells)
+              code = (i_e >= m_ol ? BT_I_EXT : 0u) | (d_e >= m_or ? BT_D_EXT : 0u);
+              code |= (mis == mv0) ? BT_M_X : ((del == mv0) ? BT_M_D : BT_M_I);
+            }
           }
+          // !(h > tlen || v > plen), unsigned so that negatives fail too
+          const bool ok = ((unsigned)mv0 <= (unsigned)tlen) & ((unsigned)(mv0 - k) <= (unsigned)plen);
           // An I (D) value can only be out of range by running past the text (pattern) end; such
           // values are rare (last scores only) and send the row through the exact trimming pass
           // below.  Everywhere else "invalid" means negative, which already reads as NULL, so the
           // computed limits can stand in for the trimmed ones.
           if constexpr (!LEAN) my_over |= (ins > tlen) || (del - k > plen);
-          // extend = longest common prefix from (v,h) (wavefront_extend.c:174-199), PER symbols per step, under
-          // the exec mask of the valid cells.  The first step is straight-line code (most cells stop inside their
-          // first word); only when some lane matched a whole word with more to go does the wave enter the loop,
-          // in which lanes that are done carry left == 0 and idle along.
+          // extend = longest common prefix from (v,h) (wavefront_extend.c:174-199), PER symbols per step.  No exec
+          // mask for the cells that are not valid: a wave instruction costs the same with any lane active, mask
+          // bookkeeping costs scalar instructions, and LDS reads at their meaningless addresses are harmless (an
+          // address beyond the workgroup's allocation reads as 0); their result is dropped below.  The first step is
+          // straight-line code (most cells stop inside their first word); only when some lane matched a whole word
+          // with more to go does the wave enter the loop, in which lanes that are done carry left == 0 and idle along.
           int h = mv0;
-          if (ok) {
-            constexpr int SH = RAW ? 2 : 4, PER = 1 << SH, BITS = RAW ? 3 : 1;
+          constexpr int SH = RAW ? 2 : 4, PER = 1 << SH, BITS = RAW ? 3 : 1;
+          // the run cannot pass either sequence end: h <= tlen and v = h - k <= plen
+          const int hmax = min(plen + k, tlen);
+          {
             const int v = mv0 - k;
-            // the run cannot pass either sequence end: h <= tlen and v = h - k <= plen
-            const int hmax = min(plen + k, tlen);
             const int rem = hmax - h;
             // word pointers and bit offsets are fixed for the whole run: a lane that goes on has
             // consumed exactly PER symbols = one word
             const char* pp = reinterpret_cast<const char*>(Pw + (v >> SH));
             const char* tp = reinterpret_cast<const char*>(Tw + (h >> SH));
             const uint32_t sa = (uint32_t)v << BITS, sb = (uint32_t)h << BITS;
-            uint32_t fb;
+            uint32_t fb, d0w;
             {
               const uint32_t* pw = reinterpret_cast<const uint32_t*>(pp);
               const uint32_t* tw = reinterpret_cast<const uint32_t*>(tp);
-              const uint32_t d = __builtin_amdgcn_alignbit(pw[1], pw[0], sa) ^ __builtin_amdgcn_alignbit(tw[1], tw[0], sb);
+              d0w = __builtin_amdgcn_alignbit(pw[1], pw[0], sa) ^ __builtin_amdgcn_alignbit(tw[1], tw[0], sb);
               // v_ffbl_b32 returns 0xFFFFFFFF for 0, so "all equal" is a huge positive count
-              asm("v_ffbl_b32 %0, %1" : "=v"(fb) : "v"(d));
+              asm("v_ffbl_b32 %0, %1" : "=v"(fb) : "v"(d0w));
             }
-            const int n = (int)(fb >> BITS);
-            h += min(min(n, PER), rem);
-            // goes on iff the whole word matched and more than a word remains
-            bool more = min(n, rem - 1) >= PER;
+            h += min(min((int)(fb >> BITS), PER), rem);
+            // the whole word matched: the run may go on (if anything remains)
+            const bool more = ok & (d0w == 0u);
             if (__builtin_amdgcn_ballot_w64(more) != 0ull) {
-              int left = more ? rem - PER : 0;
-              do {
+              int left = more ? max(rem - PER, 0) : 0;
+              while (__builtin_amdgcn_ballot_w64(left > 0) != 0ull) {
                 pp += 4; tp += 4;
                 const uint32_t* pw = reinterpret_cast<const uint32_t*>(pp);
                 const uint32_t* tw = reinterpret_cast<const uint32_t*>(tp);
@@ -450,16 +482,21 @@ wfa_align_kernel(const WfaAlignParams p) {
                 const int nn = min(min((int)(fb >> BITS), PER), left);
                 h += nn;
                 left = (nn == PER) ? left - PER : 0;
-              } while (__builtin_amdgcn_ballot_w64(left > 0) != 0ull);
+              }
             }
-            my_touch |= h == hmax;
           }
           const int mv = ok ? h : OFF_NULL;
+          my_touch |= mv == hmax;             // (NULL never equals it)
           // M and D offsets never exceed the text length, so they fit 16 bits as they are; only an I
           // chain running past the text end keeps growing and is saturated by off_store
           wb_m[k] = (OffT)mv;
-          if constexpr (LEAN) wb_i[k] = (OffT)ins; else wb_i[k] = off_store<OffT>(ins);
-          wb_d[k] = (OffT)del;
+          if constexpr (TAGGED) {
+            wb_i[k] = (OffT)(ins_hi >> 16);     // (high halves: ds_write_b16_d16_hi, no unpacking)
+            wb_d[k] = (OffT)(del_hi >> 16);
+          } else {
+            if constexpr (LEAN) wb_i[k] = (OffT)ins; else wb_i[k] = off_store<OffT>(ins);
+            wb_d[k] = (OffT)del;
+          }
           if constexpr (BT) codes[(uint32_t)(k - lo)] = (uint8_t)code;
         }
       };

@@ -156,7 +156,7 @@ __global__ void __launch_bounds__(TRACE_THREADS) wfa_walk_kernel(const WfaTraceP
       const uint2 row = tab[s];
       const uint32_t code = p.arena[(size_t)row.x * 16 + (uint32_t)(k - (int)row.y)];
       if (state == 0) {
-        const uint32_t org = code & 3u;
+        const uint32_t org = code & BT_M_MASK;
         if (org == BT_M_X) { *--q = OP_X | OP_EXT_AFTER; s -= p.x; }
         else if (org == BT_M_I) {
           *--q = OP_I | OP_EXT_AFTER; --k;

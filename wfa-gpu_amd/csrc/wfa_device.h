@@ -38,10 +38,12 @@ enum : uint32_t {
 };
 
 // Origin byte per wavefront cell (what the backtrace needs, 4 bits used):
-//   bits 1:0  source of M : 0 none (cell not valid), 1 mismatch, 2 insertion, 3 deletion
-//   bit  2    I came from I (gap extension) rather than from M (gap open)
-//   bit  3    D came from D (gap extension) rather than from M (gap open)
-enum : uint32_t { BT_M_NONE = 0, BT_M_X = 1, BT_M_I = 2, BT_M_D = 3, BT_I_EXT = 4, BT_D_EXT = 8 };
+//   bits 3:2  source of M : 0 none (cell not valid), 3 mismatch, 2 deletion, 1 insertion  (WFA2's priority on equal
+//             offsets, wavefront_backtrace.c:48-59: the lean kernel path gets it from ONE signed max over
+//             offset << 16 | these bits)
+//   bit  1    D came from D (gap extension) rather than from M (gap open)
+//   bit  0    I came from I (gap extension) rather than from M (gap open)
+enum : uint32_t { BT_M_NONE = 0, BT_M_X = 12, BT_M_D = 8, BT_M_I = 4, BT_M_MASK = 12, BT_D_EXT = 2, BT_I_EXT = 1 };
 
 #define WFA_ROW_NONE 0xFFFFFFFFu
 

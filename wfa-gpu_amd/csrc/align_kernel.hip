@@ -98,6 +98,16 @@ template <int NW> struct RowBook {
   __device__ __forceinline__ int get_i(int slot) const { if constexpr (NW == 1) return __builtin_amdgcn_readlane(i, slot); else return I[slot]; }
   __device__ __forceinline__ int get_d(int slot) const { if constexpr (NW == 1) return __builtin_amdgcn_readlane(d, slot); else return D[slot]; }
   __device__ __forceinline__ void reset() { a = i = d = ROW_NONE_A; }
+  // Lean path: every score it records has I and D limits equal to the A limits, and so have the dm scores before it
+  // (they were regular); older entries are never read again.  So only A is recorded per score and I, D are set from A
+  // wholesale when the path is left.
+  __device__ __forceinline__ void set_a(int slot, int va) {
+    if constexpr (NW == 1) { a = ((int)(threadIdx.x & 63) == slot) ? va : a; } else { A[slot] = va; }
+  }
+  __device__ __forceinline__ void copy_a_to_id(int tid, int nt, int mask) {
+    if constexpr (NW == 1) { i = a; d = a; }
+    else { __syncthreads(); for (int j = tid; j <= mask; j += nt) { I[j] = A[j]; D[j] = A[j]; } __syncthreads(); }
+  }
   // every thread calls set with the same values (NW > 1: same-value stores, each thread reads back its own)
   __device__ __forceinline__ void set(int slot, int va, int vi, int vd) {
     if constexpr (NW == 1) {
@@ -368,10 +378,10 @@ wfa_align_kernel(const WfaAlignParams p) {
       //   rb_mx[k] = M[s-x][k]   rb_mo[k] = M[s-o-e][k-1], rb_mo[k+2] = M[s-o-e][k+1]
       //   rb_ie[k] = I[s-e][k-1] rb_de[k] = D[s-e][k+1]     wb_*[k]: the rows written now
       // LEAN (regular regime, no cell has touched a sequence end yet): no value can run past an end, so the
-      // overrun test and the saturation of I are dropped.  my_touch: an M cell reached min(plen + k, tlen).
+      // overrun test and the saturation of I are dropped.  wave_touch: lanes whose M cell reached min(plen + k, tlen).
       auto cells_of_score = [&](auto lean_tag, const int lo, const int hi, uint8_t* codes, const OffT* rb_mx, const OffT* rb_mo,
                                 const OffT* rb_ie, const OffT* rb_de, OffT* wb_m, OffT* wb_i, OffT* wb_d, const BandCtx& bc,
-                                bool& my_over, bool& my_touch) {
+                                bool& my_over, unsigned long long& wave_touch) {
         constexpr bool LEAN = decltype(lean_tag)::value;
         for (int k0 = lo; k0 <= hi; k0 += NT) {
           const int k = min(k0 + tid, hi);
@@ -486,7 +496,7 @@ wfa_align_kernel(const WfaAlignParams p) {
             }
           }
           const int mv = ok ? h : OFF_NULL;
-          my_touch |= mv == hmax;             // (NULL never equals it)
+          wave_touch |= __builtin_amdgcn_ballot_w64(mv == hmax);      // (NULL never equals it)
           // M and D offsets never exceed the text length, so they fit 16 bits as they are; only an I
           // chain running past the text end keeps growing and is saturated by off_store
           wb_m[k] = (OffT)mv;
@@ -516,7 +526,7 @@ wfa_align_kernel(const WfaAlignParams p) {
         // An inner loop with its own small state: the instruction-issue pipes are what this kernel saturates, and
         // the scalar registers are what the compiler runs out of (every spilled one comes back through the vector unit).
         if constexpr (!BANDED) {
-          if (e == 1 && regular >= dm && !touched_ever) {
+          if (e == 1 && regular >= dm - 1 && !touched_ever) {
             int lo = last_lo, hi = last_hi;
             // (e == 1: the reach interval is [kend - (budget - s), kend + (budget - s)]; `reach` is budget - s)
             int reach = bounded ? budget - s : INT_MAX / 2;
@@ -554,17 +564,22 @@ wfa_align_kernel(const WfaAlignParams p) {
                 codes = p.arena + (size_t)row_s * 16;
               }
               OffT* out_m = p_m; OffT* out_i = i_cur; OffT* out_d = i_cur + d_off;
-              // Ring invariant: the slots written now last held scores s-dm (M) and s-2 (I, D), whose limits differ from
-              // [lo, hi] by at most dm diagonals per side (the limits move by at most one diagonal per score here):
-              // NULL the dm cells beyond each end, wherever they stand (rows carry dm guard cells per side).
-              for (int j = tid; j < 2 * dm; j += NT) {
-                const int q = (j < dm) ? lo - 1 - j : hi + 1 + (j - dm);
+              // Ring invariant: the slots written now last held scores s-dm (M) and s-2 (I, D).  Until a cell touches a
+              // sequence end the limits move by at most one diagonal per score (wavefronts that exist: [lo - 1, hi + 1]
+              // clipped by the window and by the reach interval, which itself moves one diagonal per score; scores
+              // without a wavefront leave their slots all NULL), so whatever those rows hold beyond [lo, hi] lies within
+              // dm diagonals of it: NULL the dm cells beyond each end (rows carry dm guard cells per side).
+              // (lanes beyond 2 dm repeat the last of those cells: same value, same address, no exec mask)
+              for (int j0 = 0; j0 < 2 * dm; j0 += NT) {
+                const int j = min(j0 + tid, 2 * dm - 1);
+                const int q = (j < dm) ? lo - 1 - j : hi + 1 - dm + j;
                 out_m[q] = (OffT)OFF_NULL; out_i[q] = (OffT)OFF_NULL; out_d[q] = (OffT)OFF_NULL;
               }
-              bool my_over = false, my_touch = false;
+              bool my_over = false;
+              unsigned long long touch_mask = 0;
               cells_of_score(std::true_type{}, lo, hi, codes, p_x, p_oe - 1, i_prev - 1, i_prev + d_off + 1, out_m, out_i, out_d, BandCtx{},
-                             my_over, my_touch);
-              const bool wave_touch = __builtin_amdgcn_ballot_w64(my_touch) != 0ull;
+                             my_over, touch_mask);
+              const bool wave_touch = touch_mask != 0ull;
               bool any_touch;
               if constexpr (NW == 1) {
                 block_sync<NW>();
@@ -575,8 +590,7 @@ wfa_align_kernel(const WfaAlignParams p) {
                 __syncthreads();
                 any_touch = (acc[6] & 4) != 0;
               }
-              const int lim = pack_range(lo, hi);
-              book.set(s & bkm, lim, lim, lim);
+              book.set_a(s & bkm, pack_range(lo, hi));    // (the I and D limits equal it: written back when the loop is left)
               if constexpr (NW == 1) block_sync<NW>();
               if (any_touch) {
                 // a cell sits on a sequence end: it may be the last one (wavefront_extend.c:47-67), and from the next
@@ -588,6 +602,7 @@ wfa_align_kernel(const WfaAlignParams p) {
             }
             // back to the general state
             const int n_lean = s - s_in;
+            if (n_lean > 0) book.copy_a_to_id(tid, NT, bkm);
             regular += n_lean;
             last_lo = lo; last_hi = hi;
             p_ic = i_cur; p_ip = i_prev;
@@ -751,16 +766,17 @@ wfa_align_kernel(const WfaAlignParams p) {
         OffT* wb_m = out_m + wbase;
         OffT* wb_i = out_i + wbase;
         OffT* wb_d = out_d + wbase;
-        bool my_over = false, my_touch = false;
+        bool my_over = false;
+        unsigned long long touch_mask = 0;
         {
           BandCtx bc;
           if constexpr (BANDED) bc = BandCtx{mx_null, mo_null, ie_null, de_null, mxlo, mxhi, molo, mohi, ielo, iehi, delo, dehi};
-          cells_of_score(std::false_type{}, lo, hi, codes, rb_mx, rb_mo, rb_ie, rb_de, wb_m, wb_i, wb_d, bc, my_over, my_touch);
+          cells_of_score(std::false_type{}, lo, hi, codes, rb_mx, rb_mo, rb_ie, rb_de, wb_m, wb_i, wb_d, bc, my_over, touch_mask);
         }
         bool any_over = false;
         {
           const bool wave_over = __builtin_amdgcn_ballot_w64(my_over) != 0ull;
-          const bool wave_touch = __builtin_amdgcn_ballot_w64(my_touch) != 0ull;
+          const bool wave_touch = touch_mask != 0ull;
           if constexpr (NW == 1) {
             block_sync<NW>();
             any_over = wave_over;

@@ -105,6 +105,11 @@ void wfagpu_amd_last_stats(const wfagpu_amd_ctx_t* ctx, wfagpu_amd_stats_t* out)
  * visible).  Results stay in input order. */
 void wfagpu_amd_set_num_devices(int n);
 
+/* Pairs that failed the check_correctness (-c) verification in the last launch_alignments* call (the "Incorrect=" counts
+ * of its batch lines, summed).  The reference only prints them (lib/align.cu:318-326); the CLI turns a non-zero value
+ * into a non-zero exit code. */
+long wfagpu_amd_check_failures(void);
+
 /* launch_alignments* keep their per-device state (context, backtrace arena,
  * input buffers, pinned result staging) for the next call of the process:
  * allocating it is most of the cost of a cold call.  This frees it. */

@@ -277,3 +277,49 @@ def test_cli_rejects_bad_input(tmp_path):
     assert r.returncode != 0
     r = subprocess.run([CLI], capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "No input file" in r.stdout + r.stderr
+
+
+def test_cli_full_size_cfg3_with_check(tmp_path):
+    """BASELINE configs[2] as the reference states it: 1M synthetic 1 kbp pairs at 5 % error, -x (CIGAR) + -c (check), through
+    the CLI.  Every batch line must report Incorrect=0 (CIGAR replays onto the pair, its gap-affine cost equals the score,
+    the score equals the independent CPU scorer of utils/verification.c -- lib/align.cu:258-326 of the reference), all
+    pairs must be covered, and the exit code is 0 (it is 2 when any pair fails the check)."""
+    import re
+    seq = tmp_path / "cfg3.seq"
+    n = 1_000_000
+    subprocess.run([os.path.join(PKG, "bin", "generate_dataset"), "-n", str(n), "-l", "1000", "-e", "0.05", "-s", "9", "-t", "32",
+                    "-o", str(seq)], check=True, timeout=600)
+    out = tmp_path / "cfg3.out"
+    r = subprocess.run([CLI, "-i", str(seq), "-x", "-c", "-e", "300", "-b", "250000", "-o", str(out)], capture_output=True, text=True,
+                       timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = re.findall(r"\(Batch (\d+)\) correct=(\d+) Incorrect=(\d+)", r.stderr)
+    assert lines and sum(int(c) for _, c, _ in lines) == n
+    assert all(int(bad) == 0 for _, _, bad in lines), lines
+    m = re.search(r"Wall time: ([0-9.]+)s", r.stdout)
+    assert m
+    # output file: n lines "score<TAB>CIGAR", spot-check a few against the oracle
+    with open(out) as f:
+        first = [next(f) for _ in range(50)]
+    pairs = wfagpu.read_seq_file(str(seq), limit=50)
+    buf, meta = wfagpu.layout_pairs(pairs)
+    so, co, _ = oracle_lib.oracle_batch(buf, meta, (2, 3, 1), cigar=True, nthreads=8)
+    assert [ln.rstrip("\n") for ln in first] == [f"{-int(s)}\t{c}" for s, c in zip(so, co)]
+    os.remove(seq)
+    os.remove(out)
+
+
+def test_ragged_call_is_cut_by_work_not_by_count(monkeypatch):
+    """launch_alignments* cut a call into per-device slices of equal P x T work: a batch whose long pairs all sit at the end
+    must still come back complete and in input order from 3 slices (WFAGPU_VIRTUAL_DEVICES), CIGARs included."""
+    import random
+    lib = wfagpu.load()
+    monkeypatch.setenv("WFAGPU_VIRTUAL_DEVICES", "3")
+    rng = random.Random(77)
+    from test_oracle import _rand_pairs
+    pairs = _rand_pairs(rng, 600, 100, err=0.05) + _rand_pairs(rng, 40, 3000, err=0.05)
+    buf, meta = wfagpu.layout_pairs(pairs)
+    so, co, _ = oracle_lib.oracle_batch(buf, meta, (2, 3, 1), cigar=True, nthreads=8)
+    s, c = _api_align(pairs, (2, 3, 1), cigar=True, max_error=400)
+    assert np.array_equal(s, np.asarray(so)) and c == co
+    lib.wfagpu_amd_release_cache()

@@ -73,6 +73,7 @@ ABI_SYMBOLS = [
     # include/wfa_gpu_device.h
     "wfagpu_amd_create", "wfagpu_amd_destroy", "wfagpu_amd_fill_packed_offsets", "wfagpu_amd_pack_device",
     "wfagpu_amd_align_device", "wfagpu_amd_last_stats", "wfagpu_amd_set_num_devices", "wfagpu_amd_release_cache",
+    "wfagpu_amd_check_failures",
 ]
 
 _lib = None
@@ -108,6 +109,10 @@ def load():
     lib.wfagpu_amd_last_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
     lib.wfagpu_amd_last_stats.restype = None
     lib.wfagpu_amd_set_num_devices.argtypes = [C.c_int]
+    lib.wfagpu_amd_check_failures.argtypes = []
+    lib.wfagpu_amd_check_failures.restype = C.c_long
+    lib.wfagpu_amd_release_cache.argtypes = []
+    lib.wfagpu_amd_release_cache.restype = None
     lib.launch_alignments.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, Options, C.c_bool]
     lib.launch_alignments.restype = None
     lib.launch_alignments_distance.argtypes = lib.launch_alignments.argtypes

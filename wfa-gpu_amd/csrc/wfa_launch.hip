@@ -21,6 +21,8 @@
 #include <thread>
 #include <vector>
 
+#include <sched.h>
+
 #include "../../include/wfa_gpu_device.h"
 #include "../utils/logger.h"
 #include "../utils/verification.h"
@@ -28,11 +30,21 @@
 namespace {
 
 std::atomic<int> g_num_devices{0};   // 0: all visible
+std::atomic<long> g_check_failures{0};   // pairs that failed the -c check in the last launch_alignments* call
+
+// Host cores this process may use (affinity mask), the budget the slices of a call share.
+unsigned usable_host_threads() {
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int n = CPU_COUNT(&set); if (n > 0) return (unsigned)n; }
+  return std::max(1u, std::thread::hardware_concurrency());
+}
 
 struct Shard {
   int device;        // physical device
   int slot;          // index of the cached per-device state (== device unless WFAGPU_VIRTUAL_DEVICES is set)
   size_t from, to;   // [from, to)
+  unsigned host_threads = 1;   // this slice's share of the host cores (scatter and -c workers): SURVEY.md section 8(e)
   int rc = 0;
 };
 
@@ -55,7 +67,7 @@ struct CallArgs {
     }                                                                                        \
   } while (0)
 
-int check_batch(const CallArgs& a, size_t from, size_t to, int batch_idx) {
+int check_batch(const CallArgs& a, size_t from, size_t to, int batch_idx, unsigned max_threads) {
   // lib/align.cu:258-326 (CIGAR mode) / :688-739 (distance mode)
   std::atomic<long> correct{0}, incorrect{0};
   std::atomic<long long> sum{0};
@@ -87,7 +99,9 @@ int check_batch(const CallArgs& a, size_t from, size_t to, int batch_idx) {
       }
     }
   };
-  unsigned nt = std::max(1u, std::thread::hardware_concurrency());
+  // (each slice has its share of the host cores: with 8 devices x 2 slices a pool of hardware_concurrency() threads per
+  // batch and slice would oversubscribe the host 16-fold and starve the upload and scatter threads)
+  unsigned nt = std::max(1u, max_threads);
   nt = (unsigned)std::min<size_t>(nt, (to - from + 15) / 16);
   std::vector<std::thread> pool;
   for (unsigned t = 1; t < nt; ++t) pool.emplace_back(worker);
@@ -95,6 +109,7 @@ int check_batch(const CallArgs& a, size_t from, size_t to, int batch_idx) {
   for (auto& t : pool) t.join();
   fprintf(stderr, "(Batch %d) correct=%ld Incorrect=%ld Average score=%f\n", batch_idx, correct.load(), incorrect.load(),
           (to > from) ? (double)sum.load() / (double)(to - from) : 0.0);
+  g_check_failures += incorrect.load();
   return incorrect.load() ? 1 : 0;
 }
 
@@ -144,9 +159,14 @@ int acquire_dev(int slot, int device, DevState** out) {
   HIP_OK(hipSetDevice(device));
   wfagpu_amd_config_t cfg{};
   cfg.device = device;
-  // device allocation costs ~33 ms per GiB, so keep the backtrace arena small and let big batches run in
-  // several passes
-  cfg.arena_limit_bytes = (size_t)4 << 30;
+  // The backtrace arena is kept between calls.  Cap: a quarter of the device memory that is free now, at most 32 GiB
+  // (1M x 1 kbp pairs need 18 GB, 1024 x 30 kbp 43 GB: under the round-1 cap of 4 GiB such calls ran in many passes);
+  // a batch that needs more than the cap runs in several passes.
+  {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)16 << 30;
+    cfg.arena_limit_bytes = std::min<size_t>((size_t)32 << 30, free_b / 4);
+  }
   if (const char* e = getenv("WFAGPU_ARENA_LIMIT_MB")) cfg.arena_limit_bytes = (size_t)atol(e) << 20;
   if (wfagpu_amd_create(&d.ctx, &cfg)) return -1;
   d.device = device;
@@ -281,7 +301,7 @@ int run_shard(const CallArgs& a, Shard& sh) {
           cg.last_free_position = o.len[j];
         }
       };
-      const unsigned nt = a.cigar ? (unsigned)std::min<size_t>(std::max(1u, std::min(8u, std::thread::hardware_concurrency())), (n + 8191) / 8192) : 1u;
+      const unsigned nt = a.cigar ? (unsigned)std::min<size_t>(std::max(1u, std::min(8u, sh.host_threads)), (n + 8191) / 8192) : 1u;
       if (nt <= 1) work(0, n);
       else {
         std::vector<std::thread> pool;
@@ -290,7 +310,7 @@ int run_shard(const CallArgs& a, Shard& sh) {
         for (auto& t : pool) t.join();
       }
       if (bad.load()) { fail(-1); return; }
-      if (a.check) check_batch(a, b.from, b.to, i);
+      if (a.check) check_batch(a, b.from, b.to, i, sh.host_threads);
       t_scatter += now() - t0;
       advance(scattered);
     }
@@ -378,12 +398,29 @@ void launch_impl(char* seq, size_t seq_bytes, sequence_pair_t* meta, wfa_alignme
   if (const char* e = getenv("WFAGPU_VIRTUAL_DEVICES")) ndev = std::max(1, std::min(MAX_DEV, atoi(e)));
   ndev = (int)std::min<size_t>((size_t)ndev, n);
   CallArgs a{seq, seq_bytes, meta, results, opt, check, cigar};
+  g_check_failures.store(0);
   std::vector<Shard> shards(ndev);
+  // Contiguous slices of equal WORK, not of equal count: the wavefront work of a pair grows with P x T (score^2 at a
+  // given error rate), so a ragged batch cut by count would leave devices idle.  One pass over the records.
+  std::vector<size_t> cut(ndev + 1, n);
+  cut[0] = 0;
+  if (ndev > 1) {
+    long double total = 0;
+    for (size_t i = 0; i < n; ++i) total += (long double)meta[i].pattern_len * meta[i].text_len + 1024.0L;   // (+ a per-pair constant)
+    long double acc = 0;
+    int d = 1;
+    for (size_t i = 0; i < n && d < ndev; ++i) {
+      acc += (long double)meta[i].pattern_len * meta[i].text_len + 1024.0L;
+      while (d < ndev && acc >= total * d / ndev) cut[d++] = i + 1;
+    }
+  }
+  const unsigned host_threads = usable_host_threads();
   for (int d = 0; d < ndev; ++d) {
     shards[d].device = d % physical;
     shards[d].slot = d;
-    shards[d].from = n * d / ndev;
-    shards[d].to = n * (d + 1) / ndev;
+    shards[d].from = cut[d];
+    shards[d].to = cut[d + 1];
+    shards[d].host_threads = std::max(1u, std::min(64u, host_threads / (unsigned)ndev));
   }
   if (ndev == 1) {
     shards[0].rc = run_shard(a, shards[0]);
@@ -401,6 +438,8 @@ void launch_impl(char* seq, size_t seq_bytes, sequence_pair_t* meta, wfa_alignme
 extern "C" {
 
 void wfagpu_amd_set_num_devices(int n) { g_num_devices.store(n < 0 ? 0 : n); }
+
+long wfagpu_amd_check_failures(void) { return g_check_failures.load(); }
 
 void wfagpu_amd_release_cache(void) {
   for (int i = 0; i < MAX_DEV; ++i) {

@@ -11,7 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "../../include/wfa_gpu_abi.h"
+#include "../../include/wfa_gpu_device.h"
 #include "../utils/logger.h"
 #include "../utils/sequence_reader.h"
 #include "../utils/wf_clock.h"
@@ -174,5 +174,9 @@ int main(int argc, char** argv) {
     }
     destroy_wfa_results(results, num_alignments);
     free_sequence_set(&set);
+    if (check && wfagpu_amd_check_failures() > 0) {
+        LOG_ERROR("%ld alignments failed the -c verification.", wfagpu_amd_check_failures())
+        return 2;
+    }
     return 0;
 }

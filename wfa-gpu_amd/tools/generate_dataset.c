@@ -100,19 +100,20 @@ size_t wfagen_generate(char* seqbuf, size_t cap, sequence_pair_t* meta, size_t n
 
 #ifdef GENERATE_DATASET_MAIN
 int main(int argc, char** argv) {
-    size_t n = 1000; int length = 1000; double error = 0.05; uint64_t seed = 1; const char* out = NULL;
+    size_t n = 1000; int length = 1000; double error = 0.05; uint64_t seed = 1; const char* out = NULL; int threads = 1;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "-n") && i + 1 < argc) n = strtoull(argv[++i], NULL, 10);
         else if (!strcmp(argv[i], "-l") && i + 1 < argc) length = atoi(argv[++i]);
         else if (!strcmp(argv[i], "-e") && i + 1 < argc) error = atof(argv[++i]);
         else if (!strcmp(argv[i], "-s") && i + 1 < argc) seed = strtoull(argv[++i], NULL, 10);
         else if (!strcmp(argv[i], "-o") && i + 1 < argc) out = argv[++i];
-        else { fprintf(stderr, "usage: %s -n pairs -l length -e error -s seed [-o file.seq]\n", argv[0]); return 1; }
+        else if (!strcmp(argv[i], "-t") && i + 1 < argc) threads = atoi(argv[++i]);
+        else { fprintf(stderr, "usage: %s -n pairs -l length -e error -s seed [-t threads] [-o file.seq]\n", argv[0]); return 1; }
     }
     const size_t cap = wfagen_pair_stride(length, error) * n + 64;
     char* buf = (char*)calloc(cap, 1);
     sequence_pair_t* meta = (sequence_pair_t*)calloc(n ? n : 1, sizeof(*meta));
-    if (!buf || !meta || !wfagen_generate(buf, cap, meta, n, length, error, seed, 1)) { fprintf(stderr, "generation failed\n"); return 1; }
+    if (!buf || !meta || !wfagen_generate(buf, cap, meta, n, length, error, seed, threads)) { fprintf(stderr, "generation failed\n"); return 1; }
     FILE* f = out ? fopen(out, "w") : stdout;
     if (!f) { perror(out); return 1; }
     for (size_t i = 0; i < n; ++i)

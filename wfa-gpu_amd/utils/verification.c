@@ -52,40 +52,57 @@ bool check_affine_distance(const char* text, const char* pattern, size_t tlen, s
     return cost == distance;
 }
 
-/* Furthest-reaching points per (score, diagonal), full-width rows indexed by
- * k + plen, three score-indexed tables kept whole.  Deliberately the plain
- * textbook formulation (no trimming, no ring) so that it shares nothing with
- * the kernels it checks. */
+/* Furthest-reaching points per (score, diagonal): the plain textbook formulation (the span grows by one diagonal per
+ * side and score, nothing is trimmed, three score-indexed tables) so that it shares nothing with the kernels it
+ * checks.  Storage is a ring of depth max(x, o+e)+1 rows per table over columns k + plen + 1, kept in a per-thread
+ * scratch that is grown, never freed per pair, and never bulk-filled: spans only grow, so a ring slot is always
+ * reused by a WIDER row, and the only cells a read can reach that the slot's current row has not written are columns
+ * that entered the span after the slot's previous (narrower) row was written -- those are set to NONE in every slot
+ * of the ring at the moment they enter (two columns per score). */
+static __thread int* vs_buf = NULL;
+static __thread size_t vs_cap = 0;
+
 int verification_cpu_score(const char* pattern, const char* text, size_t plen_, size_t tlen_,
                            int x, int o, int e) {
     const int plen = (int)plen_, tlen = (int)tlen_;
-    const int W = plen + tlen + 3, K0 = plen + 1;
+    const int W = plen + tlen + 5, K0 = plen + 2;
     const int NONE = -(1 << 28);
     const int oe = o + e;
     const int depth = (x > oe ? x : oe) + 1;
-    int* buf = (int*)malloc(sizeof(int) * (size_t)W * 3 * (size_t)depth);
-    if (!buf) return -1;
-    int* M = buf; int* I = M + (size_t)W * depth; int* D = I + (size_t)W * depth;
-    for (size_t i = 0; i < (size_t)W * 3 * depth; ++i) buf[i] = NONE;
-    int lo = 0, hi = 0;     /* diagonal span that can be non-empty at the current score */
+    const size_t need = (size_t)W * 3 * (size_t)depth;
+    if (need > vs_cap) {
+        free(vs_buf);
+        vs_cap = need + need / 4;
+        vs_buf = (int*)malloc(sizeof(int) * vs_cap);
+        if (!vs_buf) { vs_cap = 0; return -1; }
+    }
+    int* M = vs_buf; int* I = M + (size_t)W * depth; int* D = I + (size_t)W * depth;
     const int kend = tlen - plen;
-    int s = 0;
-    /* score 0 */
+    /* columns -1, 0, 1 of every slot: the span of score 0 and its guards */
+    for (int r = 0; r < depth; ++r)
+        for (int k = -1; k <= 1; ++k) { M[(size_t)r * W + K0 + k] = NONE; I[(size_t)r * W + K0 + k] = NONE; D[(size_t)r * W + K0 + k] = NONE; }
     {
         int h = 0;
         while (h < plen && h < tlen && pattern[h] == text[h]) ++h;
         M[K0] = h;
-        if (kend == 0 && h >= tlen) { free(buf); return 0; }
+        if (kend == 0 && h >= tlen) return 0;
     }
+    int lo = 0, hi = 0;     /* diagonal span that can be non-empty at the current score */
+    int s;
     for (s = 1;; ++s) {
         int* Ms = M + (size_t)(s % depth) * W; int* Is = I + (size_t)(s % depth) * W; int* Ds = D + (size_t)(s % depth) * W;
         const int* Mx = s >= x ? M + (size_t)((s - x) % depth) * W : NULL;
         const int* Mo = s >= oe ? M + (size_t)((s - oe) % depth) * W : NULL;
         const int* Ie = s >= e ? I + (size_t)((s - e) % depth) * W : NULL;
         const int* De = s >= e ? D + (size_t)((s - e) % depth) * W : NULL;
-        if (lo > -plen) --lo;
-        if (hi < tlen) ++hi;
-        for (int k = -plen - 1; k <= tlen + 1; ++k) { Ms[K0 + k] = NONE; Is[K0 + k] = NONE; Ds[K0 + k] = NONE; }
+        if (lo > -plen) {
+            --lo;
+            for (int r = 0; r < depth; ++r) { M[(size_t)r * W + K0 + lo - 1] = NONE; I[(size_t)r * W + K0 + lo - 1] = NONE; D[(size_t)r * W + K0 + lo - 1] = NONE; }
+        }
+        if (hi < tlen) {
+            ++hi;
+            for (int r = 0; r < depth; ++r) { M[(size_t)r * W + K0 + hi + 1] = NONE; I[(size_t)r * W + K0 + hi + 1] = NONE; D[(size_t)r * W + K0 + hi + 1] = NONE; }
+        }
         for (int k = lo; k <= hi; ++k) {
             int ins = NONE, del = NONE, mis = NONE;
             if (Mo && Mo[K0 + k - 1] > ins) ins = Mo[K0 + k - 1];
@@ -108,6 +125,5 @@ int verification_cpu_score(const char* pattern, const char* text, size_t plen_, 
         }
         if (kend >= lo && kend <= hi && Ms[K0 + kend] >= tlen) break;
     }
-    free(buf);
     return s;
 }

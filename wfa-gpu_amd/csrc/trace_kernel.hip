@@ -71,6 +71,7 @@ __device__ __forceinline__ int dec_digits(uint32_t n) {
 
 struct RleSink {
   char* out;      // nullptr: count only
+  uint32_t cap;   // bytes available at `out` (items that would not fit are only counted)
   uint32_t len;
   uint32_t run;
   char op;
@@ -79,14 +80,14 @@ struct RleSink {
   __device__ __forceinline__ void flush() {
     if (run == 0) return;
     const int nd = dec_digits(run);
-    if (out) {
+    if (out && len + (uint32_t)nd + 2u <= cap) {
       uint32_t r = run;
       for (int i = nd - 1; i >= 0; --i) { out[len + i] = (char)('0' + r % 10); r /= 10; }
       out[len + nd] = op;
-      // (utils/verification.c:91-146 of the reference: a new gap wherever the operation changes)
-      if (op == 'X') cost += x * (int)run;
-      else if (op != 'M') cost += o + e * (int)run;
     }
+    // (utils/verification.c:91-146 of the reference: a new gap wherever the operation changes)
+    if (op == 'X') cost += x * (int)run;
+    else if (op != 'M') cost += o + e * (int)run;
     len += (uint32_t)nd + 1;
     run = 0;
   }
@@ -100,8 +101,9 @@ struct RleSink {
 template <bool RAW>
 __device__ __forceinline__ uint32_t replay(const uint8_t* ops, uint32_t nops,
                                            const uint32_t* Pw, const uint32_t* Tw,
-                                           int plen, int tlen, char* out, int x, int o, int e, int* cost) {
-  RleSink sink{out, 0, 0, 0, x, o, e, 0};
+                                           int plen, int tlen, char* out, int x, int o, int e, int* cost,
+                                           uint32_t out_cap = 0xFFFFFFFFu) {
+  RleSink sink{out, out_cap, 0, 0, 0, x, o, e, 0};
   int v = 0, h = 0;
   int n = lcp_seq<RAW>(Pw, Tw, plen, tlen, v, h);
   sink.push('M', (uint32_t)n); v += n; h += n;
@@ -118,7 +120,8 @@ __device__ __forceinline__ uint32_t replay(const uint8_t* ops, uint32_t nops,
     }
   }
   sink.flush();
-  if (out) { out[sink.len] = '\0'; *cost = sink.cost; }
+  if (out && sink.len < out_cap) out[sink.len] = '\0';
+  if (cost) *cost = sink.cost;
   // a consistent trace ends exactly at the corner
   return (v == plen && h == tlen) ? sink.len : 0xFFFFFFFFu;
 }
@@ -257,10 +260,165 @@ __global__ void __launch_bounds__(TRACE_THREADS) wfa_emit_kernel(const WfaTraceP
   }
 }
 
+
+// ---- long alignments: one WAVEFRONT per alignment ----------------------------------------------------------------
+// With one lane per alignment a batch of long reads (1024 x 30 kbp: 3000 operations each) keeps 16 wavefronts busy on
+// a 1024-SIMD chip and every step of the walk and of the replay pays a full memory round trip (walk 4.3 ms + emit
+// 10.8 ms per 1024 pairs of BASELINE configs[4]).  Here the wavefront
+//   1. copies both packed sequences into LDS (coalesced), so the replay's LCPs never leave the CU;
+//   2. walks the origin bytes through TILES: lane r fetches 16 origin bytes of score s-r around the current diagonal
+//      (64 independent loads in flight instead of one), then the walk consumes the tile from LDS until the path leaves
+//      it (a tile lasts ~20 operations: mismatches stay on their diagonal, gaps move one diagonal per base);
+//   3. replays the operations (two passes: size, then text) -- sequential, but out of LDS.
+// All lanes follow the same control flow; lane 0 does the stores.
+template <bool RAW>
+__global__ void __launch_bounds__(TRACE_THREADS) wfa_trace_wave_kernel(const WfaTraceParams p) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t wlds[];
+  const int lane = threadIdx.x & 63;
+  uint32_t* Pw = wlds;
+  uint32_t* Tw = Pw + p.seq_words_cap;
+  uint8_t* tile = reinterpret_cast<uint8_t*>(Tw + p.seq_words_cap);     // [64 rows][16 bytes]
+  uint8_t* ops_lds = tile + 64 * 16;                                    // [ops_lds_bytes]
+  char* text_lds = reinterpret_cast<char*>(ops_lds + p.ops_lds_bytes);  // [text_lds_bytes]
+  constexpr int TILE_W = 16, TILE_H = 64;
+  for (uint32_t w = blockIdx.x; w < p.n_work; w += gridDim.x) {
+    const uint32_t pair = __builtin_amdgcn_readfirstlane(p.work ? p.work[w] : w);
+    if (p.status[pair] != WFA_ST_DONE) continue;
+    const WfaSeqPair mp = p.meta[pair];
+    const int plen = __builtin_amdgcn_readfirstlane((int)mp.pattern_len), tlen = __builtin_amdgcn_readfirstlane((int)mp.text_len);
+    const int score = __builtin_amdgcn_readfirstlane(p.score[pair]);
+    const int sh = RAW ? 2 : 4;
+    const int pwords = ((plen + (1 << sh) - 1) >> sh) + 1, twords = ((tlen + (1 << sh) - 1) >> sh) + 1;
+    {
+      const uint32_t* gp = p.packed + ((RAW ? mp.pattern_offset : mp.pattern_offset_packed) >> 2);
+      const uint32_t* gt = p.packed + ((RAW ? mp.text_offset : mp.text_offset_packed) >> 2);
+      for (int i = lane; i < pwords; i += 64) Pw[i] = gp[i];
+      for (int i = lane; i < twords; i += 64) Tw[i] = gt[i];
+    }
+    // the reversed op list (every operation costs at least min(x, e) >= 1: `score` bytes suffice): in LDS when it
+    // fits -- the replay reads one op per step, a round trip to L2 each if they sat in global memory --, else in the
+    // global scratch
+    const uint32_t need_ops = ((uint32_t)score + 3u) & ~3u;
+    bool fail = false;
+    uint8_t* q_begin = ops_lds;
+    if (need_ops > (uint32_t)p.ops_lds_bytes) {
+      unsigned long long ops_off = 0;
+      if (lane == 0) ops_off = atomicAdd(p.ops_top, (unsigned long long)need_ops);
+      ops_off = shfl64(ops_off, 0);
+      fail = ops_off + need_ops > p.ops_cap;
+      q_begin = p.ops + ops_off;
+    }
+    uint8_t* const q_end = q_begin + need_ops;
+    uint8_t* q = q_end;
+    if (!fail) {
+      const uint2* tab = reinterpret_cast<const uint2*>(p.arena + (size_t)p.bt_final_row[pair] * 16);
+      int k = tlen - plen, s = score, state = 0;       // state 0: M, 1: I, 2: D
+      int s_top = -1, kbase = 0;
+      while (s > 0) {
+        if (s > s_top || s_top - s >= TILE_H || (unsigned)(k - kbase) >= (unsigned)TILE_W) {
+          // new tile: scores s .. s-63, diagonals k-8 .. k+7
+          s_top = s; kbase = k - TILE_W / 2;
+          __builtin_amdgcn_wave_barrier();
+          const int sr = s - lane;
+          uint4 v = make_uint4(0, 0, 0, 0);
+          if (sr >= 0) {
+            const uint2 row = tab[sr];
+            // (entries of scores without a wavefront are stale: their cells are never consulted, but the address
+            //  must be a safe one)
+            const long long off = (long long)row.x * 16 + ((long long)kbase - (int)row.y);
+            if (off >= 0 && (unsigned long long)off + 16 <= p.arena_bytes) {
+              struct __attribute__((packed, aligned(1))) U16 { uint32_t w[4]; };
+              const U16 t = *reinterpret_cast<const U16*>(p.arena + off);
+              v = make_uint4(t.w[0], t.w[1], t.w[2], t.w[3]);
+            }
+          }
+          reinterpret_cast<uint4*>(tile)[lane] = v;
+          __builtin_amdgcn_wave_barrier();
+        }
+        if (q == q_begin) { fail = true; break; }
+        const uint32_t code = tile[(s_top - s) * TILE_W + (k - kbase)];
+        uint8_t op;
+        if (state == 0) {
+          const uint32_t org = code & BT_M_MASK;
+          if (org == BT_M_X) { op = OP_X | OP_EXT_AFTER; s -= p.x; }
+          else if (org == BT_M_I) {
+            op = OP_I | OP_EXT_AFTER; --k;
+            if (code & BT_I_EXT) { s -= p.e; state = 1; } else { s -= p.oe; }
+          } else if (org == BT_M_D) {
+            op = OP_D | OP_EXT_AFTER; ++k;
+            if (code & BT_D_EXT) { s -= p.e; state = 2; } else { s -= p.oe; }
+          } else { fail = true; break; }
+        } else if (state == 1) {
+          op = OP_I; --k;
+          if (code & BT_I_EXT) { s -= p.e; } else { s -= p.oe; state = 0; }
+        } else {
+          op = OP_D; ++k;
+          if (code & BT_D_EXT) { s -= p.e; } else { s -= p.oe; state = 0; }
+        }
+        --q;
+        if (lane == 0) *q = op;
+      }
+      if (s != 0 || state != 0 || k != 0) fail = true;
+    }
+    // the op list is read back by this same wavefront: make lane 0's stores visible to all lanes
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t nops = (uint32_t)(q_end - q);
+    // One replay writes the text into LDS (every lane follows along, lane 0 stores); its length then buys the space
+    // in the dense text arena and all 64 lanes copy it out.  A text longer than the LDS buffer is replayed once more,
+    // straight into the arena.
+    uint32_t len = 0;
+    int cost = 0;
+    if (!fail) {
+      len = replay<RAW>(q, nops, Pw, Tw, plen, tlen, lane == 0 ? text_lds : nullptr, p.x, p.oe - p.e, p.e, &cost, (uint32_t)p.text_lds_bytes);
+      if (len == 0xFFFFFFFFu) fail = true;
+    }
+    unsigned long long txt_off = 0;
+    if (!fail) {
+      if (lane == 0) txt_off = atomicAdd(p.text_top, (unsigned long long)len + 1ull);
+      txt_off = shfl64(txt_off, 0);
+      if (txt_off + len + 1 > p.text_cap) fail = true;
+    }
+    if (!fail) {
+      if (len + 1u <= (uint32_t)p.text_lds_bytes) {
+        __builtin_amdgcn_wave_barrier();
+        char* dst = p.text + txt_off;
+        for (uint32_t i = lane; i <= len; i += 64) dst[i] = text_lds[i];
+      } else {
+        replay<RAW>(q, nops, Pw, Tw, plen, tlen, lane == 0 ? p.text + txt_off : nullptr, p.x, p.oe - p.e, p.e, &cost);
+      }
+      if (lane == 0) {
+        p.cigar_off[pair] = txt_off;
+        p.cigar_len[pair] = len;
+        if (cost != score) {
+          if (p.score_fix) p.score_fix[pair] = cost;
+          else p.cigar_len[pair] = 0xFFFFFFFFu;
+        }
+      }
+    } else if (lane == 0) {
+      p.cigar_off[pair] = 0;
+      p.cigar_len[pair] = 0xFFFFFFFFu;
+    }
+    __builtin_amdgcn_wave_barrier();      // (the next alignment overwrites the staged sequences)
+  }
+}
+
 }  // namespace
 
 void wfa_launch_trace(const WfaTraceParams& p, hipStream_t stream) {
   if (p.n_work == 0) return;
+  if (p.wave_kernel) {
+    const size_t lds = (size_t)2 * p.seq_words_cap * 4 + 64 * 16 + (size_t)p.ops_lds_bytes + (size_t)p.text_lds_bytes;
+    const uint32_t grid = p.n_work < 8192u ? p.n_work : 8192u;
+    if (p.raw) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wfa_trace_wave_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(wfa_trace_wave_kernel<true>, dim3(grid), dim3(TRACE_THREADS), lds, stream, p);
+    } else {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wfa_trace_wave_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(wfa_trace_wave_kernel<false>, dim3(grid), dim3(TRACE_THREADS), lds, stream, p);
+    }
+    return;
+  }
   const uint32_t grid = (p.n_work + TRACE_THREADS - 1) / TRACE_THREADS;
   hipLaunchKernelGGL(wfa_walk_kernel, dim3(grid), dim3(TRACE_THREADS), 0, stream, p);
   if (p.seq_lds_stride > 0) {

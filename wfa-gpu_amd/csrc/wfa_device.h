@@ -95,6 +95,11 @@ struct WfaTraceParams {
   int32_t* score_fix;            // banded passes: scores are replaced by the cost of the emitted CIGAR where they differ
   const uint32_t* status;
   const uint8_t* arena;
+  unsigned long long arena_bytes;  // size of the arena (the wave-per-alignment kernel range-checks row-table entries of scores without a wavefront)
+  int wave_kernel;               // 1: one wavefront per alignment (long alignments), 0: one lane per alignment
+  int seq_words_cap;             // wave kernel: LDS words reserved per sequence
+  int ops_lds_bytes;             // wave kernel: LDS bytes for the op list (longer lists go through the global scratch)
+  int text_lds_bytes;            // wave kernel: LDS bytes for the CIGAR text of one alignment (longer texts: second replay)
   const uint32_t* bt_final_row;
   // scratch for the reversed op list, bump allocated (bytes)
   uint8_t* ops;

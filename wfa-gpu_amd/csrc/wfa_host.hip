@@ -80,7 +80,7 @@ struct DevBuf {
 };
 
 // device counters (u64 slots)
-enum { CT_ARENA = 0, CT_OPS = 1, CT_TEXT = 2, CT_LCELLS = 3, CT_LIST = 4, CT_SUM_OPS = 5, CT_SUM_TEXT = 6, CT_CELLS = 7, CT_N = 8 };
+enum { CT_ARENA = 0, CT_OPS = 1, CT_TEXT = 2, CT_LCELLS = 3, CT_LIST = 4, CT_SUM_OPS = 5, CT_SUM_TEXT = 6, CT_CELLS = 7, CT_MAX_SCORE = 8, CT_N = 9 };
 
 constexpr uint32_t MASK(uint32_t st) { return 1u << st; }
 
@@ -134,10 +134,12 @@ __global__ void __launch_bounds__(256) k_trace_bounds(const uint32_t* __restrict
                                unsigned long long* __restrict__ ct) {
   __shared__ unsigned long long part[3][4];
   unsigned long long ops = 0, txt = 0, cl = 0;
+  uint32_t smax = 0;
   for (uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x; gid < n; gid += gridDim.x * blockDim.x) {
     const uint32_t pair = work ? work[gid] : gid;
     if (status[pair] == WFA_ST_DONE) {
       const uint32_t s = (uint32_t)score[pair];
+      smax = max(smax, s);
       ops += (s + 3u) & ~3u;
       const uint32_t m = s / (uint32_t)min_op_cost;
       txt += 6ull * (2ull * m + 1ull) + 1ull;
@@ -148,7 +150,9 @@ __global__ void __launch_bounds__(256) k_trace_bounds(const uint32_t* __restrict
     ops += __shfl_down((unsigned long long)ops, d);
     txt += __shfl_down((unsigned long long)txt, d);
     cl += __shfl_down((unsigned long long)cl, d);
+    smax = max(smax, (uint32_t)__shfl_down((int)smax, d));
   }
+  if ((threadIdx.x & 63) == 0 && smax) atomicMax(&ct[CT_MAX_SCORE], (unsigned long long)smax);
   const int wv = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) { part[0][wv] = ops; part[1][wv] = txt; part[2][wv] = cl; }
   __syncthreads();
@@ -552,6 +556,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
     // ---- backtrace + CIGAR for everything that finished in this pass ---------
     if (zero_counter(c, CT_SUM_OPS, 2)) return -1;
     if (zero_counter(c, CT_OPS)) return -1;
+    if (zero_counter(c, CT_MAX_SCORE)) return -1;
     LAUNCH_K(k_trace_bounds, dim3(std::min<uint32_t>(cdiv(n_pass, 256), 1024u)), dim3(256), 0, st, (const uint32_t*)pending, n_pass,
                        static_cast<const uint32_t*>(c->status.p), (const int32_t*)d_scores,
                        static_cast<const uint32_t*>(c->cells.p), std::min(pen.x, pen.e), ct);
@@ -568,12 +573,25 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         const unsigned per_seq = raw ? (max_len + 3) / 4 + 1 : (max_len + 15) / 16 + 1;
         const unsigned stride = (2 * per_seq) | 1u;
         tp.seq_lds_stride = ((size_t)64 * stride * 4 <= (48u << 10)) ? (int)stride : 0;
+        // sequences too long to stage 64 pairs per wavefront: one wavefront per alignment (sequences of ONE pair in LDS)
+        tp.seq_words_cap = (int)per_seq + 1;
+        tp.wave_kernel = (tp.seq_lds_stride == 0 && !getenv("WFAGPU_NO_WAVE_TRACE")) ? 1 : 0;
+        // op list (one byte per score point of the largest score of the pass) and CIGAR text of one alignment in LDS,
+        // within 40 KiB per wavefront so that at least four of them fit a CU
+        {
+          const size_t seq_b = (size_t)2 * tp.seq_words_cap * 4 + 1024;
+          size_t room = seq_b < (40u << 10) ? (40u << 10) - seq_b : 0;
+          const size_t smax = (size_t)c->h_counters[CT_MAX_SCORE];
+          tp.ops_lds_bytes = (int)(((smax + 3) & ~(size_t)3) <= room ? ((smax + 15) & ~(size_t)15) : 0);
+          room -= (size_t)tp.ops_lds_bytes;
+          tp.text_lds_bytes = (int)(std::min<size_t>(room, 2 * smax + 64) & ~(size_t)15);
+        }
       }
       tp.packed = ap.packed; tp.meta = ap.meta; tp.work = pending; tp.n_work = n_pass;
       tp.x = pen.x; tp.oe = oe; tp.e = pen.e;
       tp.score = d_scores; tp.status = static_cast<const uint32_t*>(c->status.p);
       tp.score_fix = (want_band && !raw) ? d_scores : nullptr;
-      tp.arena = ap.arena; tp.bt_final_row = ap.bt_final_row;
+      tp.arena = ap.arena; tp.arena_bytes = (unsigned long long)c->arena.cap; tp.bt_final_row = ap.bt_final_row;
       tp.ops = static_cast<uint8_t*>(c->ops.p); tp.ops_cap = c->ops.cap; tp.ops_top = ct + CT_OPS;
       tp.text = static_cast<char*>(c->text.p); tp.text_cap = c->text.cap; tp.text_top = ct + CT_TEXT;
       tp.cigar_off = static_cast<unsigned long long*>(c->cig_off.p);

@@ -17,25 +17,51 @@
 // Scratch and text space come from wave-aggregated bump allocations (one
 // atomic per wavefront), so the text arena is dense and can be copied to the
 // host in one piece.
+#include <cstdlib>
+
 #include "wfa_device.h"
 
 namespace {
 
 enum : uint8_t { OP_X = 1, OP_I = 2, OP_D = 3, OP_EXT_AFTER = 0x10 };
 
-template <bool RAW>
-__device__ __forceinline__ int lcp_seq(const uint32_t* __restrict__ Pw,
-                                       const uint32_t* __restrict__ Tw, int plen, int tlen,
-                                       int v, int h) {
+// How the replay reads a packed sequence: words i and i+1 at a time, at positions that only move forward.
+//   SeqDirect  the whole sequence is addressable (LDS copy, or global memory)
+//   SeqWindow  8 words per lane in LDS, refilled from global memory when the position leaves them: 64 bytes of LDS per
+//              alignment instead of both whole sequences, which is what lets the lane-per-alignment emit kernel run at
+//              full occupancy (staging whole sequences capped it at 4 wavefronts per CU: 3.9 ms per 1M cfg3 pairs,
+//              all of it exposed latency)
+struct SeqDirect {
+  const uint32_t* w;
+  __device__ __forceinline__ uint2 pair(int i) const { return make_uint2(w[i], w[i + 1]); }
+};
+struct SeqWindow {
+  static constexpr int WORDS = 8;
+  const uint32_t* g;     // the sequence in global memory
+  int nwords;            // words that may be read there
+  uint32_t* slot;        // this lane's WORDS words of LDS
+  int base;              // word index of slot[0]
+  __device__ __forceinline__ uint2 pair(int i) {
+    if ((unsigned)(i - base) >= (unsigned)(WORDS - 1)) {
+      base = i;
+#pragma unroll
+      for (int t = 0; t < WORDS; ++t) slot[t] = (i + t < nwords) ? g[i + t] : 0u;
+    }
+    return make_uint2(slot[i - base], slot[i - base + 1]);
+  }
+};
+
+template <bool RAW, typename PV, typename TV>
+__device__ __forceinline__ int lcp_seq(PV& Pw, TV& Tw, int plen, int tlen, int v, int h) {
   constexpr int SH = RAW ? 2 : 4;
   constexpr int PER = 1 << SH;
   constexpr int BITS = RAW ? 3 : 1;
   int n_total = 0;
   int rem = min(plen - v, tlen - h);
   while (rem > 0) {
-    const int pi = v >> SH, ti = h >> SH;
-    const uint32_t a = __builtin_amdgcn_alignbit(Pw[pi + 1], Pw[pi], (v & (PER - 1)) << BITS);
-    const uint32_t b = __builtin_amdgcn_alignbit(Tw[ti + 1], Tw[ti], (h & (PER - 1)) << BITS);
+    const uint2 pw = Pw.pair(v >> SH), tw = Tw.pair(h >> SH);
+    const uint32_t a = __builtin_amdgcn_alignbit(pw.y, pw.x, (v & (PER - 1)) << BITS);
+    const uint32_t b = __builtin_amdgcn_alignbit(tw.y, tw.x, (h & (PER - 1)) << BITS);
     const uint32_t d = a ^ b;
     int n = d ? (__builtin_ctz(d) >> BITS) : PER;
     n = min(n, rem);
@@ -98,17 +124,22 @@ struct RleSink {
   }
 };
 
-template <bool RAW>
-__device__ __forceinline__ uint32_t replay(const uint8_t* ops, uint32_t nops,
-                                           const uint32_t* Pw, const uint32_t* Tw,
-                                           int plen, int tlen, char* out, int x, int o, int e, int* cost,
-                                           uint32_t out_cap = 0xFFFFFFFFu) {
+template <bool RAW, typename PV, typename TV>
+__device__ __forceinline__ uint32_t replay_views(const uint8_t* ops, uint32_t nops, PV& Pw, TV& Tw,
+                                                 int plen, int tlen, char* out, int x, int o, int e, int* cost,
+                                                 uint32_t out_cap = 0xFFFFFFFFu) {
   RleSink sink{out, out_cap, 0, 0, 0, x, o, e, 0};
   int v = 0, h = 0;
   int n = lcp_seq<RAW>(Pw, Tw, plen, tlen, v, h);
   sink.push('M', (uint32_t)n); v += n; h += n;
+  // The op list is consumed four ops per aligned 32-bit load: with one byte load per step every iteration of every lane
+  // waited a full round trip to L2 (that, not the LCPs, was most of the emit kernel's time).
+  const uint32_t* ops4 = reinterpret_cast<const uint32_t*>(reinterpret_cast<uintptr_t>(ops) & ~(uintptr_t)3);
+  const uint32_t skip = (uint32_t)(reinterpret_cast<uintptr_t>(ops) & 3);
+  uint32_t word = nops ? (*ops4 >> (8 * skip)) : 0u;
   for (uint32_t i = 0; i < nops; ++i) {
-    const uint8_t op = ops[i];
+    const uint32_t op = word & 0xFFu;
+    if (((i + 1 + skip) & 3u) == 0u) { if (i + 1 < nops) word = ops4[(i + 1 + skip) >> 2]; } else word >>= 8;
     switch (op & 3) {
       case OP_X: sink.push('X', 1); ++v; ++h; break;
       case OP_I: sink.push('I', 1); ++h; break;
@@ -124,6 +155,14 @@ __device__ __forceinline__ uint32_t replay(const uint8_t* ops, uint32_t nops,
   if (cost) *cost = sink.cost;
   // a consistent trace ends exactly at the corner
   return (v == plen && h == tlen) ? sink.len : 0xFFFFFFFFu;
+}
+
+template <bool RAW>
+__device__ __forceinline__ uint32_t replay(const uint8_t* ops, uint32_t nops, const uint32_t* Pw, const uint32_t* Tw,
+                                           int plen, int tlen, char* out, int x, int o, int e, int* cost,
+                                           uint32_t out_cap = 0xFFFFFFFFu) {
+  SeqDirect pv{Pw}, tv{Tw};
+  return replay_views<RAW>(ops, nops, pv, tv, plen, tlen, out, x, o, e, cost, out_cap);
 }
 
 constexpr int TRACE_THREADS = 64;
@@ -190,6 +229,60 @@ __global__ void __launch_bounds__(TRACE_THREADS) wfa_walk_kernel(const WfaTraceP
 // the whole wavefront), so the many small reads of the replay never leave the CU.  Without it
 // every 4-byte read of a packed sequence misses L1 and L2 (the working set of all resident lanes
 // is far larger than both) and the kernel is HBM-transaction bound (57 GB fetched per 1M pairs).
+// Window mode (the default): every lane keeps 8 words of each sequence in LDS (SeqWindow), 4.3 KB per wavefront.
+__global__ void __launch_bounds__(TRACE_THREADS) wfa_emit_win_kernel(const WfaTraceParams p) {
+  __shared__ uint32_t win_lds[64 * (2 * SeqWindow::WORDS + 1)];
+  const uint32_t gid = blockIdx.x * TRACE_THREADS + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  bool active = gid < p.n_work;
+  uint32_t pair = 0;
+  if (active) pair = p.work ? p.work[gid] : gid;
+  if (active && p.status[pair] != WFA_ST_DONE) active = false;
+  int plen = 0, tlen = 0;
+  const uint8_t* q = nullptr; uint32_t nops = 0;
+  bool fail = false;
+  uint32_t* slot = win_lds + lane * (2 * SeqWindow::WORDS + 1);     // (odd stride: lanes at the same window index hit different banks)
+  SeqWindow pv{nullptr, 0, slot, -1000}, tv{nullptr, 0, slot + SeqWindow::WORDS, -1000};
+  if (active) {
+    const WfaSeqPair mp = p.meta[pair];
+    plen = (int)mp.pattern_len; tlen = (int)mp.text_len;
+    const int sh = p.raw ? 2 : 4;
+    pv.g = p.packed + ((p.raw ? mp.pattern_offset : mp.pattern_offset_packed) >> 2);
+    tv.g = p.packed + ((p.raw ? mp.text_offset : mp.text_offset_packed) >> 2);
+    pv.nwords = ((plen + (1 << sh) - 1) >> sh) + 1; tv.nwords = ((tlen + (1 << sh) - 1) >> sh) + 1;
+    q = p.ops + p.cigar_off[pair];
+    nops = p.cigar_len[pair];
+    fail = nops == 0xFFFFFFFFu;
+  }
+  uint32_t len = 0;
+  if (active && !fail) {
+    len = p.raw ? replay_views<true>(q, nops, pv, tv, plen, tlen, nullptr, 0, 0, 0, nullptr)
+                : replay_views<false>(q, nops, pv, tv, plen, tlen, nullptr, 0, 0, 0, nullptr);
+    if (len == 0xFFFFFFFFu) fail = true;
+  }
+  const uint32_t need_txt = (active && !fail) ? len + 1u : 0u;
+  const unsigned long long txt_off = wave_alloc(p.text_top, need_txt, lane);
+  if (active && !fail && txt_off + need_txt > p.text_cap) fail = true;
+  if (active) {
+    if (!fail) {
+      int cost = 0;
+      pv.base = -1000; tv.base = -1000;
+      if (p.raw) replay_views<true>(q, nops, pv, tv, plen, tlen, p.text + txt_off, p.x, p.oe - p.e, p.e, &cost);
+      else replay_views<false>(q, nops, pv, tv, plen, tlen, p.text + txt_off, p.x, p.oe - p.e, p.e, &cost);
+      p.cigar_off[pair] = txt_off;
+      p.cigar_len[pair] = len;
+      // (the text's own gap-affine cost must equal the score; adaptive band: the score follows the text -- see below)
+      if (cost != p.score[pair]) {
+        if (p.score_fix) p.score_fix[pair] = cost;
+        else p.cigar_len[pair] = 0xFFFFFFFFu;
+      }
+    } else {
+      p.cigar_off[pair] = 0;
+      p.cigar_len[pair] = 0xFFFFFFFFu;
+    }
+  }
+}
+
 template <bool SEQ_LDS>
 __global__ void __launch_bounds__(TRACE_THREADS) wfa_emit_kernel(const WfaTraceParams p) {
   extern __shared__ __attribute__((aligned(16))) uint32_t seq_lds[];
@@ -421,6 +514,11 @@ void wfa_launch_trace(const WfaTraceParams& p, hipStream_t stream) {
   }
   const uint32_t grid = (p.n_work + TRACE_THREADS - 1) / TRACE_THREADS;
   hipLaunchKernelGGL(wfa_walk_kernel, dim3(grid), dim3(TRACE_THREADS), 0, stream, p);
+  static const bool use_window = getenv("WFAGPU_EMIT_WINDOW") != nullptr;     // (A/B switch: 8-word LDS windows instead of whole sequences)
+  if (use_window || p.seq_lds_stride == 0) {
+    hipLaunchKernelGGL(wfa_emit_win_kernel, dim3(grid), dim3(TRACE_THREADS), 0, stream, p);
+    return;
+  }
   if (p.seq_lds_stride > 0) {
     const size_t lds = (size_t)64 * p.seq_lds_stride * 4;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wfa_emit_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -179,10 +179,11 @@ def test_full_size_properties(aligner):
 
 
 @pytest.mark.parametrize("n,length,err,beta,lam,max_error,min_recall", [
-    (512, 10000, 0.03, 512, 25, 3000, 0.95),     # BASELINE configs[3] shape: -e 3000 -t 512 -B auto
-    (2000, 1000, 0.05, 128, 25, 300, 0.90),
-    (2000, 1000, 0.05, 64, 10, 300, 0.60),
-    (300, 3000, 0.15, 256, 50, 2000, 0.50),
+    # recall floors = measured (profiles/r02/banded.md: 100 % on i.i.d. single-base edits at every beta/lambda) - 1 %
+    (512, 10000, 0.03, 512, 25, 3000, 0.99),     # BASELINE configs[3] shape: -e 3000 -t 512 -B auto
+    (2000, 1000, 0.05, 128, 25, 300, 0.99),
+    (2000, 1000, 0.05, 64, 10, 300, 0.99),
+    (300, 3000, 0.15, 256, 50, 2000, 0.99),
 ])
 def test_adaptive_band_is_valid_and_mostly_optimal(aligner, n, length, err, beta, lam, max_error, min_recall):
     """the reference's banded mode has no bit-defined output, so parity = every CIGAR replays onto its
@@ -492,3 +493,31 @@ def test_cfg4_hifi_10kbp_exact_with_cigars(aligner, golden_dir):
     so, co = _truth(buf, meta, (2, 3, 1))
     assert np.array_equal(s, so)
     assert c == co
+
+
+# (measured on these 1024 pairs: 0.9658, 0.9785, 0.7432, 0.7188; the floors are those - 1 %)
+@pytest.mark.parametrize("beta,lam,min_recall", [(1024, 10, 0.955), (1024, 750, 0.968), (512, 10, 0.733), (352, 100, 0.708)])
+def test_adaptive_band_on_long_read_shaped_pairs(aligner, beta, lam, min_recall):
+    """The band heuristic on data that can defeat it (profiles/r02/banded.md): 10 kbp pairs with multi-base indels, a few
+    long ones and clustered errors.  Every returned alignment must still be valid, cost == reported score >= optimum,
+    deterministic; pairs the band cannot finish are finished exactly; recall is pinned to the measured value - 1 %."""
+    n = 1024
+    buf, meta = wfagpu.generate_pairs_model(n, 10000, seed=6, error=0.06, indel_frac=0.6, indel_mean=2.5, long_frac=0.02,
+                                            long_min=30, long_max=150, cluster=0.3)
+    batch = aligner.upload(buf, meta)
+    exact, _ = aligner.align(batch, (2, 3, 1), max_error=6000, compute_cigar=False)
+    so, _ = _truth(buf, meta[:32], (2, 3, 1))
+    assert np.array_equal(exact[:32], so)
+    s, c = aligner.align(batch, (2, 3, 1), max_error=6000, compute_cigar=True, band=lam, band_width=beta)
+    st = aligner.stats()
+    s2, c2 = aligner.align(batch, (2, 3, 1), max_error=6000, compute_cigar=True, band=lam, band_width=beta)
+    assert np.array_equal(s, s2) and c == c2
+    assert (s >= exact).all()
+    recall = float((s == exact).mean())
+    print(f"banded(hard) beta={beta} lambda={lam}: recall {recall:.4f}, finished inside the band {st.pairs_banded}/{n}")
+    assert 0 < st.pairs_banded <= n
+    assert recall >= min_recall
+    pairs = wfagpu.pairs_from_layout(buf, meta)
+    for i in range(0, n, 5):
+        ok, cost = oracle_lib.check_cigar(pairs[i][0], pairs[i][1], c[i], (2, 3, 1))
+        assert ok and cost == s[i]

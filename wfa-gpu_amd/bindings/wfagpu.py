@@ -205,6 +205,31 @@ def generate_pairs(n, length, error, seed, nthreads=8):
     return buf[:used], meta
 
 
+class GenModel(C.Structure):  # wfagen_model_t (tools/generate_dataset.c)
+    _fields_ = [("error", C.c_double), ("indel_frac", C.c_double), ("indel_mean", C.c_double), ("long_frac", C.c_double),
+                ("long_min", C.c_int), ("long_max", C.c_int), ("cluster", C.c_double)]
+
+
+def generate_pairs_model(n, length, seed, error=0.1, indel_frac=0.6, indel_mean=2.5, long_frac=0.01, long_min=30, long_max=120,
+                         cluster=0.3, nthreads=8):
+    """Long-read shaped pairs: multi-base indels (geometric + a few long ones) and clustered errors
+    (wfagen_generate_model in tools/generate_dataset.c) -- the hard input for the adaptive band."""
+    g = load_gen()
+    g.wfagen_model_stride.argtypes = [C.c_int, C.POINTER(GenModel)]
+    g.wfagen_model_stride.restype = C.c_size_t
+    g.wfagen_generate_model.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(GenModel), C.c_uint64, C.c_int]
+    g.wfagen_generate_model.restype = C.c_size_t
+    m = GenModel(error, indel_frac, indel_mean, long_frac, long_min, long_max, cluster)
+    stride = g.wfagen_model_stride(length, C.byref(m))
+    cap = stride * n + 64
+    buf = np.zeros(cap, dtype=np.uint8)
+    meta = np.zeros(n, dtype=META_DTYPE)
+    used = g.wfagen_generate_model(buf.ctypes.data, cap, meta.ctypes.data, n, length, C.byref(m), seed, nthreads)
+    if used == 0:
+        raise RuntimeError("wfagen_generate_model failed")
+    return buf[:used], meta
+
+
 def pairs_from_layout(buf, meta):
     out = []
     b = buf.tobytes() if isinstance(buf, np.ndarray) else bytes(buf)

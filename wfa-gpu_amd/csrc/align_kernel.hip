@@ -41,7 +41,11 @@
 
 namespace {
 
-constexpr int OFF_NULL = -32768;       // any negative offset is "no cell"
+// "No cell": any negative offset.  A NULL that is read as a predecessor is incremented once per score along the edges of the
+// wavefront, so it must sit further below zero than an alignment has scores: 16-bit rows serve scores <= 30000, the 32-bit
+// rows (HBM ring of the unbounded tier) get a quarter of the int range.
+template <typename OffT> struct OffNull { static constexpr int value = -32768; };
+template <> struct OffNull<int32_t> { static constexpr int value = INT_MIN / 4; };
 
 template <typename OffT> __device__ __forceinline__ OffT off_store(int v);
 template <> __device__ __forceinline__ int16_t off_store<int16_t>(int v) {
@@ -254,7 +258,7 @@ wfa_align_kernel(const WfaAlignParams p) {
           uint32_t* w = reinterpret_cast<uint32_t*>(Mr);
           for (int i = tid; i < (cells >> 1); i += NT) w[i] = 0x80008000u;
         } else {
-          for (int i = tid; i < cells; i += NT) Mr[i] = (OffT)OFF_NULL;
+          for (int i = tid; i < cells; i += NT) Mr[i] = (OffT)OffNull<OffT>::value;
         }
       }
       if constexpr (NW == 1) book.reset();
@@ -420,11 +424,11 @@ wfa_align_kernel(const WfaAlignParams p) {
               const bool in_or = !bc.mo_null && (unsigned)(k + 1 - bc.molo) <= (unsigned)(bc.mohi - bc.molo);
               const bool in_ie = !bc.ie_null && (unsigned)(k - 1 - bc.ielo) <= (unsigned)(bc.iehi - bc.ielo);
               const bool in_de = !bc.de_null && (unsigned)(k + 1 - bc.delo) <= (unsigned)(bc.dehi - bc.delo);
-              m_x = in_x ? (int)rb_mx[k] : OFF_NULL;
-              m_ol = in_ol ? (int)rb_mo[k] : OFF_NULL;
-              m_or = in_or ? (int)rb_mo[k + 2] : OFF_NULL;
-              i_e = in_ie ? (int)rb_ie[k] : OFF_NULL;
-              d_e = in_de ? (int)rb_de[k] : OFF_NULL;
+              m_x = in_x ? (int)rb_mx[k] : OffNull<OffT>::value;
+              m_ol = in_ol ? (int)rb_mo[k] : OffNull<OffT>::value;
+              m_or = in_or ? (int)rb_mo[k + 2] : OffNull<OffT>::value;
+              i_e = in_ie ? (int)rb_ie[k] : OffNull<OffT>::value;
+              d_e = in_de ? (int)rb_de[k] : OffNull<OffT>::value;
             } else {
               m_x = (int)rb_mx[k];
               m_ol = (int)rb_mo[k];
@@ -495,7 +499,7 @@ wfa_align_kernel(const WfaAlignParams p) {
               }
             }
           }
-          const int mv = ok ? h : OFF_NULL;
+          const int mv = ok ? h : OffNull<OffT>::value;
           wave_touch |= __builtin_amdgcn_ballot_w64(mv == hmax);      // (NULL never equals it)
           // M and D offsets never exceed the text length, so they fit 16 bits as they are; only an I
           // chain running past the text end keeps growing and is saturated by off_store
@@ -519,14 +523,16 @@ wfa_align_kernel(const WfaAlignParams p) {
       bool touched_ever = touched_at_0 || cold_params()->no_lean != 0;    // (WFAGPU_NO_LEAN: the lean path is never entered)
       // ---- score loop ----------------------------------------------------------------------------
       if (!done && status == WFA_ST_DONE) for (;;) {
-        // ---- lean path: gap extension 1, every row the recurrences read is regular (all three components over the
-        // computed limits) and no cell has touched a sequence end.  Then nothing can be trimmed, no "no wavefront"
-        // case can occur, and with e == 1 the limits of wavefront_compute.c:41-71 collapse to [lo - 1, hi + 1] of the
-        // last score (the I and D rows of s-1 span its M limits), clipped by the window and the budget's reach.
+        // ---- lean path: gap extension 1 and no cell has touched a sequence end yet.  Then no value can run past an end,
+        // nothing is ever trimmed, and with e == 1 the limits of wavefront_compute.c:41-71 collapse to [lo - 1, hi + 1] of
+        // the last score (the I and D rows of s-1 span its M limits), clipped by the window and the budget's reach.  It starts
+        // at score 1: wavefronts and components that WFA2 does not create yet (no predecessor row exists) are computed here
+        // as rows of NULL cells from the NULL rows of the ring -- a superset of WFA2's cells whose extra members are not
+        // valid and only feed cells that are not valid either, at most one 64-lane chunk per early score.
         // An inner loop with its own small state: the instruction-issue pipes are what this kernel saturates, and
         // the scalar registers are what the compiler runs out of (every spilled one comes back through the vector unit).
         if constexpr (!BANDED) {
-          if (e == 1 && regular >= dm - 1 && !touched_ever) {
+          if (e == 1 && !touched_ever) {
             int lo = last_lo, hi = last_hi;
             // (e == 1: the reach interval is [kend - (budget - s), kend + (budget - s)]; `reach` is budget - s)
             int reach = bounded ? budget - s : INT_MAX / 2;
@@ -573,7 +579,7 @@ wfa_align_kernel(const WfaAlignParams p) {
               for (int j0 = 0; j0 < 2 * dm; j0 += NT) {
                 const int j = min(j0 + tid, 2 * dm - 1);
                 const int q = (j < dm) ? lo - 1 - j : hi + 1 - dm + j;
-                out_m[q] = (OffT)OFF_NULL; out_i[q] = (OffT)OFF_NULL; out_d[q] = (OffT)OFF_NULL;
+                out_m[q] = (OffT)OffNull<OffT>::value; out_i[q] = (OffT)OffNull<OffT>::value; out_d[q] = (OffT)OffNull<OffT>::value;
               }
               bool my_over = false;
               unsigned long long touch_mask = 0;
@@ -676,7 +682,7 @@ wfa_align_kernel(const WfaAlignParams p) {
             const int o_m = book.get_a((s - dm) & bkm), o_e = book.get_a((s - de) & bkm);
             const int f0 = min(range_lo(o_m), range_lo(o_e)), f1 = max(range_hi(o_m), range_hi(o_e));
             for (int q = f0 + tid; q <= f1; q += NT) {
-              out_m[q] = (OffT)OFF_NULL; out_i[q] = (OffT)OFF_NULL; out_d[q] = (OffT)OFF_NULL;
+              out_m[q] = (OffT)OffNull<OffT>::value; out_i[q] = (OffT)OffNull<OffT>::value; out_d[q] = (OffT)OffNull<OffT>::value;
             }
           }
           block_sync<NW>();
@@ -749,7 +755,7 @@ wfa_align_kernel(const WfaAlignParams p) {
           if (ntot > 0) {
             for (int j = tid; j < ntot; j += NT) {
               const int q = (j < nlo) ? f0 + j : hi + 1 + (j - nlo);
-              out_m[q] = (OffT)OFF_NULL; out_i[q] = (OffT)OFF_NULL; out_d[q] = (OffT)OFF_NULL;
+              out_m[q] = (OffT)OffNull<OffT>::value; out_i[q] = (OffT)OffNull<OffT>::value; out_d[q] = (OffT)OffNull<OffT>::value;
             }
           }
         }
@@ -812,8 +818,8 @@ wfa_align_kernel(const WfaAlignParams p) {
             const int kraw = k0 + tid;
             const bool active = kraw <= hi;
             const int k = active ? kraw : hi;
-            const int iv = have_i ? (int)out_i[wbase + k] : OFF_NULL;
-            const int dv = have_d ? (int)out_d[wbase + k] : OFF_NULL;
+            const int iv = have_i ? (int)out_i[wbase + k] : OffNull<OffT>::value;
+            const int dv = have_d ? (int)out_d[wbase + k] : OffNull<OffT>::value;
             const bool i_ok = ((unsigned)iv <= (unsigned)tlen) && ((unsigned)(iv - k) <= (unsigned)plen);
             const bool d_ok = ((unsigned)dv <= (unsigned)tlen) && ((unsigned)(dv - k) <= (unsigned)plen);
             const int b = k0 + wave * 64;
@@ -836,8 +842,8 @@ wfa_align_kernel(const WfaAlignParams p) {
           if constexpr (!BANDED) {
             // trimmed-away cells read as NULL from now on (wavefront_compute.c:480-520)
             for (int q = lo + tid; q <= hi; q += NT) {
-              if (q < r[0] || q > r[1]) out_i[q] = (OffT)OFF_NULL;
-              if (q < r[2] || q > r[3]) out_d[q] = (OffT)OFF_NULL;
+              if (q < r[0] || q > r[1]) out_i[q] = (OffT)OffNull<OffT>::value;
+              if (q < r[2] || q > r[3]) out_d[q] = (OffT)OffNull<OffT>::value;
             }
             if constexpr (NW > 1) __syncthreads();
           }

@@ -269,10 +269,11 @@ def test_randomised_penalties_and_shapes(aligner):
         assert np.array_equal(s2, so), pen
 
 
-@pytest.mark.parametrize("min_tier", [1, 2, 3])
+@pytest.mark.parametrize("min_tier", [1, 2, 3, 4])
 def test_every_tier_gives_the_same_answers(min_tier, monkeypatch):
-    """The 4-wave, 16-wave and HBM-ring (16-bit offsets) instantiations on a ragged set that the one-wave tier
-    normally takes: WFAGPU_MIN_TIER makes the planner skip the smaller tiers."""
+    """The 4-wave, 16-wave, HBM-ring (16-bit offsets) and hybrid-ring (tier 4: M and I rings in LDS, D ring in HBM)
+    instantiations on a ragged set that the one-wave tier normally takes: WFAGPU_MIN_TIER makes the planner skip the
+    smaller tiers."""
     monkeypatch.setenv("WFAGPU_MIN_TIER", str(min_tier))
     rng = random.Random(1234 + min_tier)
     pairs = _rand_pairs(rng, 96, 400, err=0.08)

@@ -137,9 +137,13 @@ __device__ __forceinline__ ColdParams cold_params() {
   return (ColdParams)v;
 }
 
-template <int NW, bool BT, typename OffT, bool GLOBAL_RING, bool RAW, bool BANDED>
+// HYBRID: the M and I rings in LDS, the D ring (2 of the 9 rows at the default penalties) in global memory -- for
+// wavefronts whose whole ring misses the 160 KiB of a CU by a little (30 kbp at 10 % error: 9 rows x 18 KB).  The
+// all-global ring moves 16 bytes per cell through L2; this one 4.
+template <int NW, bool BT, typename OffT, bool GLOBAL_RING, bool RAW, bool BANDED, bool HYBRID = false>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu((NW == 1 && !BANDED) ? 8 : 1, 8)))   // (the banded one-wave kernels would spill at 8)
 wfa_align_kernel(const WfaAlignParams p) {
+  static_assert(!HYBRID || (!GLOBAL_RING && !BANDED), "the hybrid ring is an exact LDS tier");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NT = NW * 64;
   const int tid = threadIdx.x;
@@ -154,8 +158,9 @@ wfa_align_kernel(const WfaAlignParams p) {
     Mr = reinterpret_cast<OffT*>(static_cast<char*>(p.gring) + (size_t)blockIdx.x * p.gring_stride);
   } else {
     Mr = reinterpret_cast<OffT*>(sp);
-    sp += (((size_t)(dm + 2 * de) * rs * sizeof(OffT)) + 15) & ~(size_t)15;
+    sp += (((size_t)(dm + (HYBRID ? 1 : 2) * de) * rs * sizeof(OffT)) + 15) & ~(size_t)15;
   }
+  OffT* const Dg = HYBRID ? reinterpret_cast<OffT*>(static_cast<char*>(p.gring) + (size_t)blockIdx.x * p.gring_stride) : nullptr;   // the D ring
   uint32_t* Pw = reinterpret_cast<uint32_t*>(sp);
   uint32_t* Tw = Pw + p.seq_words_cap;
   const int bkm = p.book_mask;                                // row book: 64 (or more) entries indexed by score & bkm
@@ -253,10 +258,14 @@ wfa_align_kernel(const WfaAlignParams p) {
         // with, so reads next to a row's ends need no predicate and no per-score guard fill.  It starts
         // here (rows of M, I, D are contiguous) and is kept by clearing, whenever a row is overwritten,
         // what the previous occupant of its slot had beyond the new limits.
-        const int cells = (dm + 2 * de) * rs;     // rs is even
+        const int cells = (dm + (HYBRID ? 1 : 2) * de) * rs;     // rs is even
         if constexpr (sizeof(OffT) == 2) {
           uint32_t* w = reinterpret_cast<uint32_t*>(Mr);
           for (int i = tid; i < (cells >> 1); i += NT) w[i] = 0x80008000u;
+          if constexpr (HYBRID) {
+            uint32_t* wd = reinterpret_cast<uint32_t*>(Dg);
+            for (int i = tid; i < ((de * rs) >> 1); i += NT) wd[i] = 0x80008000u;
+          }
         } else {
           for (int i = tid; i < cells; i += NT) Mr[i] = (OffT)OffNull<OffT>::value;
         }
@@ -318,7 +327,9 @@ wfa_align_kernel(const WfaAlignParams p) {
       OffT* const m_end = m_first + dm * rs;
       OffT* const i_first = m_end;
       OffT* const i_end = i_first + de * rs;
-      const int d_off = de * rs;
+      // the D row that belongs to an I row (same slot of the other ring)
+      OffT* const d_first = HYBRID ? Dg + (BANDED ? 0 : kidx0) : i_first + de * rs;
+      auto d_of = [&](OffT* ip) -> OffT* { return d_first + (ip - i_first); };
       OffT* p_m = m_first; OffT* p_x = m_first + (dm - x) * rs; OffT* p_oe = m_first + (dm - oe) * rs;
       OffT* p_ic = i_first; OffT* p_ip = i_first + (de - e) * rs;
       // From a cell of score s on diagonal k the end is at least |k - kend| more gap bases away (an I or
@@ -390,7 +401,7 @@ wfa_align_kernel(const WfaAlignParams p) {
         for (int k0 = lo; k0 <= hi; k0 += NT) {
           const int k = min(k0 + tid, hi);
           // recurrences (wavefront_compute_affine.c:66-84)
-          constexpr bool TAGGED = LEAN && !GLOBAL_RING && !BANDED && sizeof(OffT) == 2;
+          constexpr bool TAGGED = LEAN && !GLOBAL_RING && !BANDED && sizeof(OffT) == 2;     // (also the hybrid ring: its D row is read through a global pointer)
           int ins, del, mv0;
           uint32_t code = 0;
           int ins_hi = 0, del_hi = 0;           // TAGGED: values whose high halves are stored
@@ -569,7 +580,7 @@ wfa_align_kernel(const WfaAlignParams p) {
                 }
                 codes = p.arena + (size_t)row_s * 16;
               }
-              OffT* out_m = p_m; OffT* out_i = i_cur; OffT* out_d = i_cur + d_off;
+              OffT* out_m = p_m; OffT* out_i = i_cur; OffT* out_d = d_of(i_cur);
               // Ring invariant: the slots written now last held scores s-dm (M) and s-2 (I, D).  Until a cell touches a
               // sequence end the limits move by at most one diagonal per score (wavefronts that exist: [lo - 1, hi + 1]
               // clipped by the window and by the reach interval, which itself moves one diagonal per score; scores
@@ -583,7 +594,7 @@ wfa_align_kernel(const WfaAlignParams p) {
               }
               bool my_over = false;
               unsigned long long touch_mask = 0;
-              cells_of_score(std::true_type{}, lo, hi, codes, p_x, p_oe - 1, i_prev - 1, i_prev + d_off + 1, out_m, out_i, out_d, BandCtx{},
+              cells_of_score(std::true_type{}, lo, hi, codes, p_x, p_oe - 1, i_prev - 1, d_of(i_prev) + 1, out_m, out_i, out_d, BandCtx{},
                              my_over, touch_mask);
               const bool wave_touch = touch_mask != 0ull;
               bool any_touch;
@@ -671,7 +682,7 @@ wfa_align_kernel(const WfaAlignParams p) {
         }
         OffT* out_m = p_m;             // exact mode: [q] = diagonal q
         OffT* out_i = p_ic;
-        OffT* out_d = p_ic + d_off;
+        OffT* out_d = d_of(p_ic);
         if (all_null || lo > hi) {
           // no wavefront at this score (wavefront_compute_affine.c:236-243)
           if constexpr (!BANDED) { if (s > budget) { status = WFA_ST_SCORE; break; } }
@@ -743,7 +754,7 @@ wfa_align_kernel(const WfaAlignParams p) {
         const OffT* row_mx = p_x;
         const OffT* row_mo = p_oe;
         const OffT* row_ie = p_ip;
-        const OffT* row_de = p_ip + d_off;
+        const OffT* row_de = d_of(p_ip);
         const int wbase = BANDED ? -lo : 0;       // index of diagonal 0 in the rows written now
 
         if constexpr (!BANDED) {
@@ -876,9 +887,9 @@ wfa_align_kernel(const WfaAlignParams p) {
   }
 }
 
-template <int NW, bool BT, typename OffT, bool GR, bool RAW, bool BANDED>
+template <int NW, bool BT, typename OffT, bool GR, bool RAW, bool BANDED, bool HYBRID = false>
 void launch_inst(const WfaAlignParams& p, size_t lds, int grid, hipStream_t stream) {
-  auto k = wfa_align_kernel<NW, BT, OffT, GR, RAW, BANDED>;
+  auto k = wfa_align_kernel<NW, BT, OffT, GR, RAW, BANDED, HYBRID>;
   // the opt-in for large dynamic LDS is sticky per device and per kernel: pay the driver call once
   static thread_local size_t allowed[16] = {0};
   int dev = 0;
@@ -890,9 +901,9 @@ void launch_inst(const WfaAlignParams& p, size_t lds, int grid, hipStream_t stre
   hipLaunchKernelGGL(k, dim3(grid), dim3(NW * 64), lds, stream, p);
 }
 
-template <int NW, bool BT, typename OffT, bool GR, bool RAW, bool BANDED>
+template <int NW, bool BT, typename OffT, bool GR, bool RAW, bool BANDED, bool HYBRID = false>
 int occ_inst(size_t lds) {
-  auto k = wfa_align_kernel<NW, BT, OffT, GR, RAW, BANDED>;
+  auto k = wfa_align_kernel<NW, BT, OffT, GR, RAW, BANDED, HYBRID>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   int nb = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k), NW * 64, lds) != hipSuccess) nb = 0;
@@ -906,6 +917,7 @@ void launch_tier(const WfaAlignParams& p, int tier, size_t lds, int grid, hipStr
     case 0: launch_inst<1, BT, int16_t, false, RAW, false>(p, lds, grid, stream); break;
     case 1: launch_inst<4, BT, int16_t, false, RAW, false>(p, lds, grid, stream); break;
     case 2: launch_inst<16, BT, int16_t, false, RAW, false>(p, lds, grid, stream); break;
+    case 4: if constexpr (!RAW) launch_inst<16, BT, int16_t, false, false, false, true>(p, lds, grid, stream); break;    // hybrid ring
     default:
       if (p.ring16) launch_inst<16, BT, int16_t, true, RAW, false>(p, lds, grid, stream);
       else launch_inst<16, BT, int32_t, true, RAW, false>(p, lds, grid, stream);
@@ -926,6 +938,7 @@ int occ_tier(int tier, size_t lds) {
     case 0: return occ_inst<1, BT, int16_t, false, RAW, false>(lds);
     case 1: return occ_inst<4, BT, int16_t, false, RAW, false>(lds);
     case 2: return occ_inst<16, BT, int16_t, false, RAW, false>(lds);
+    case 4: if constexpr (!RAW) return occ_inst<16, BT, int16_t, false, false, false, true>(lds); else return 0;
     default: return occ_inst<16, BT, int32_t, true, RAW, false>(lds);
   }
 }
@@ -942,11 +955,12 @@ int occ_tier_banded(int tier, size_t lds) {
 
 size_t wfa_align_lds_bytes(const WfaAlignParams& p, int tier) {
   size_t ring = 0;
-  if (tier != 3) ring = (((size_t)(p.dm + 2 * p.de) * p.rs * sizeof(int16_t)) + 15) & ~(size_t)15;
+  if (tier == 4) ring = (((size_t)(p.dm + p.de) * p.rs * sizeof(int16_t)) + 15) & ~(size_t)15;       // hybrid: M and I rings
+  else if (tier != 3) ring = (((size_t)(p.dm + 2 * p.de) * p.rs * sizeof(int16_t)) + 15) & ~(size_t)15;
   const size_t seq = (size_t)2 * p.seq_words_cap * 4;
   // reduction slots [24] + broadcast [2] + (NW > 1) row book [3][book]
   const size_t bk = (size_t)p.book_mask + 1;
-  const size_t meta = (size_t)(24 + 2 + (tier == 0 ? 0 : 3 * bk)) * 4;
+  const size_t meta = (size_t)(24 + 2 + (tier == 0 ? 0 : 3 * bk)) * 4;     // (tiers 1, 2, 3, 4: row book in LDS)
   return ((ring + seq + meta) + 15) & ~(size_t)15;
 }
 

@@ -116,7 +116,7 @@ struct WfaTraceParams {
 // Host-side launchers (one per translation unit).
 void wfa_launch_pack(const char* d_ascii, const WfaSeqPair* d_meta, uint32_t n_pairs,
                      uint32_t* d_packed, uint8_t* d_flags, hipStream_t stream);
-// tier: 0 -> 1 wave/alignment (LDS ring), 1 -> 4 waves (LDS), 2 -> 16 waves (LDS),
+// tier: 0 -> 1 wave/alignment (LDS ring), 1 -> 4 waves (LDS), 2 -> 16 waves (LDS), 4 -> 16 waves, M and I rings in LDS + D ring in HBM,
 //       3 -> 16 waves, ring in HBM (int16 or int32 offsets, WfaAlignParams::ring16).  Returns the dynamic LDS bytes used.
 size_t wfa_align_lds_bytes(const WfaAlignParams& p, int tier);
 void wfa_launch_align(const WfaAlignParams& p, int tier, bool with_bt, bool raw, int grid, hipStream_t stream);

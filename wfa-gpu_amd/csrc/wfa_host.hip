@@ -348,6 +348,14 @@ bool plan_tier(const wfagpu_amd_ctx* c, WfaAlignParams& p, int max_score, unsign
     *out = {t, width, max_score, lds, nb};
     return true;
   }
+  // hybrid ring: everything but the D rows in LDS (one workgroup of 16 waves per CU)
+  if (i16_ok && !raw && !getenv("WFAGPU_NO_HYBRID") && !(env_min && atoi(env_min) == 3)) {
+    const size_t lds_h = wfa_align_lds_bytes(p, 4);
+    if (lds_h <= c->lds_per_block_max) {
+      const int nb = wfa_align_max_blocks_per_cu(4, bt, raw, false, lds_h);
+      if (nb >= 1) { *out = {4, width, max_score, lds_h, nb}; return true; }
+    }
+  }
   const size_t lds = wfa_align_lds_bytes(p, 3);
   if (lds > c->lds_per_block_max) return false;   // sequences themselves do not fit LDS
   const int nb = wfa_align_max_blocks_per_cu(3, bt, raw, false, lds);
@@ -503,9 +511,10 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         fprintf(stderr, "[!] ERROR: sequences of %u bases do not fit the LDS staging area\n", max_len);
         return -1;
       }
-      if (tp.tier == 3) {
+      if (tp.tier == 3 || tp.tier == 4) {
         ap.ring16 = max_len <= 32766u ? 1 : 0;
-        const size_t stride = (((size_t)(ap.dm + 2 * ap.de) * ap.rs * (ap.ring16 ? 2 : 4)) + 255) & ~(size_t)255;
+        const size_t stride = tp.tier == 4 ? ((((size_t)ap.de * ap.rs * 2) + 255) & ~(size_t)255)     // hybrid: the D ring only
+                                           : ((((size_t)(ap.dm + 2 * ap.de) * ap.rs * (ap.ring16 ? 2 : 4)) + 255) & ~(size_t)255);
         const int grid = (int)std::min<uint32_t>(n_cur, (uint32_t)(c->num_cus * tp.blocks_per_cu));
         if (c->gring.ensure(stride * grid, st)) return -1;
         ap.gring = c->gring.p; ap.gring_stride = stride;
@@ -541,7 +550,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       c->stats.pairs_tier[tp.tier] += n_cur - n_next;
       if (round == 0) c->stats.pairs_retried += n_next;
       if (n_next == 0) break;
-      if (tp.tier == 3 && max_score == INT_MAX) {
+      if ((tp.tier == 3) && max_score == INT_MAX) {
         fprintf(stderr, "[!] ERROR: %u alignments did not finish in the unbounded tier\n", n_next);
         return -1;
       }

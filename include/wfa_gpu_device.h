@@ -28,6 +28,9 @@ typedef struct {
     size_t text_bytes;     /* CIGAR text arena; 0: automatic                             */
     size_t arena_limit_bytes; /* cap for the automatic arena size (0: none); a batch that needs
                               more runs in several passes                                   */
+    size_t arena_limit_max_bytes; /* > arena_limit_bytes: the cap doubles, up to this value, after every call that
+                              needed several passes -- a one-shot call touches little fresh device memory (first touch
+                              costs ~33 ms per GiB), a long-lived process ends up with the arena its batches need */
 } wfagpu_amd_config_t;
 
 typedef struct {

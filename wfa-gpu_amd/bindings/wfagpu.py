@@ -47,7 +47,7 @@ class Aligner(C.Structure):  # wfagpu_aligner_t
 
 class Config(C.Structure):  # wfagpu_amd_config_t
     _fields_ = [("device", C.c_int), ("stream", C.c_void_p), ("arena_bytes", C.c_size_t), ("text_bytes", C.c_size_t),
-                ("arena_limit_bytes", C.c_size_t)]
+                ("arena_limit_bytes", C.c_size_t), ("arena_limit_max_bytes", C.c_size_t)]
 
 
 class Batch(C.Structure):  # wfagpu_amd_batch_t

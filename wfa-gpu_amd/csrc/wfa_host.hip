@@ -213,7 +213,7 @@ struct wfagpu_amd_ctx {
   bool own_stream = false;
   int num_cus = 0;
   size_t lds_per_block_max = 0;
-  size_t arena_cfg = 0, text_cfg = 0, arena_limit = 0;
+  size_t arena_cfg = 0, text_cfg = 0, arena_limit = 0, arena_limit_max = 0;
   DevBuf packed, flags, status, cells, bt_final, list_a, list_b, list_c, list_d, list_e, work_ctr, sample, ratio, budget, counters, arena, ops, text, cig_off, cig_len, gring;
   unsigned long long* h_counters = nullptr;  // pinned
   hipEvent_t ev_start = nullptr, ev_pack = nullptr, ev_a0 = nullptr, ev_a1 = nullptr, ev_t0 = nullptr, ev_t1 = nullptr, ev_end = nullptr;
@@ -249,6 +249,7 @@ int wfagpu_amd_create(wfagpu_amd_ctx_t** out, const wfagpu_amd_config_t* cfg) {
     c->arena_cfg = cfg ? cfg->arena_bytes : 0;
     c->text_cfg = cfg ? cfg->text_bytes : 0;
     c->arena_limit = cfg ? cfg->arena_limit_bytes : 0;
+    c->arena_limit_max = cfg ? cfg->arena_limit_max_bytes : 0;
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_counters), CT_N * sizeof(unsigned long long), hipHostMallocDefault));
     HIP_TRY(hipEventCreate(&c->ev_start)); HIP_TRY(hipEventCreate(&c->ev_pack));
     HIP_TRY(hipEventCreate(&c->ev_a0)); HIP_TRY(hipEventCreate(&c->ev_a1));
@@ -749,6 +750,10 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, c->ev_start, c->ev_pack)); c->stats.pack_ms = ms;
   HIP_TRY(hipEventElapsedTime(&ms, c->ev_start, c->ev_end)); c->stats.total_ms = ms;
+  // several arena-bound passes under a growable cap: the next call may use twice the arena
+  if (compute_cigar && c->arena_limit && c->arena_limit_max > c->arena_limit && c->stats.sub_batches > 1 &&
+      c->arena.cap >= c->arena_limit - ((size_t)1 << 20))
+    c->arena_limit = std::min(c->arena_limit_max, 2 * c->arena_limit);
   c->stats.align_ms = align_ms;
   c->stats.trace_ms = trace_ms;
   c->stats.text_bytes = text_used;

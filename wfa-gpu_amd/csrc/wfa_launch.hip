@@ -159,15 +159,17 @@ int acquire_dev(int slot, int device, DevState** out) {
   HIP_OK(hipSetDevice(device));
   wfagpu_amd_config_t cfg{};
   cfg.device = device;
-  // The backtrace arena is kept between calls.  Cap: a quarter of the device memory that is free now, at most 32 GiB
-  // (1M x 1 kbp pairs need 18 GB, 1024 x 30 kbp 43 GB: under the round-1 cap of 4 GiB such calls ran in many passes);
-  // a batch that needs more than the cap runs in several passes.
+  // The backtrace arena is kept between calls.  Its cap starts at 4 GiB -- fresh device memory costs ~33 ms per GiB at
+  // first touch, and a batch that needs more simply runs in several passes (1M x 1 kbp pairs: 18 GB of origin bytes,
+  // 5 passes, 130 ms cold instead of 1.2 s) -- and doubles after every call that needed several passes, up to a quarter
+  // of the free device memory or 32 GiB: a long-lived process ends up with one pass per call.
+  cfg.arena_limit_bytes = (size_t)4 << 30;
   {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)16 << 30;
-    cfg.arena_limit_bytes = std::min<size_t>((size_t)32 << 30, free_b / 4);
+    cfg.arena_limit_max_bytes = std::max<size_t>(cfg.arena_limit_bytes, std::min<size_t>((size_t)32 << 30, free_b / 4));
   }
-  if (const char* e = getenv("WFAGPU_ARENA_LIMIT_MB")) cfg.arena_limit_bytes = (size_t)atol(e) << 20;
+  if (const char* e = getenv("WFAGPU_ARENA_LIMIT_MB")) { cfg.arena_limit_bytes = (size_t)atol(e) << 20; cfg.arena_limit_max_bytes = 0; }
   if (wfagpu_amd_create(&d.ctx, &cfg)) return -1;
   d.device = device;
   HIP_OK(hipStreamCreateWithFlags(&d.up, hipStreamNonBlocking));

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o $WL -- python3 $R/bench.py --workload $WL --steps 2 --warmup 1 --no-cpu-baseline --no-host-to-host "$@" > $O/stats.log 2>&1
 for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_WAVES" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
   T=$(echo $C | tr " " "_" | cut -c1-30)
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc/$T -o pmc -- python3 $R/bench.py --workload $WL --steps 1 --warmup 0 --no-cpu-baseline --no-host-to-host "$@" > $O/pmc_$T.log 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc/$T -o pmc -- python3 $R/bench.py --workload $WL --steps 1 --warmup 1 --no-cpu-baseline --no-host-to-host "$@" > $O/pmc_$T.log 2>&1
 done
 cd $R
 python3 - <<PY
@@ -23,7 +23,7 @@ for f in sorted(glob.glob('$O/pmc/*/pmc_counter_collection.csv')):
             k=re.search(r'wfa_\\w+(<[^>]*>)?',kn).group(0)
             rows.append((k,r['Counter_Name'],r['Counter_Value'],(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e6,r['Grid_Size'],r['Workgroup_Size'],r['VGPR_Count'],r['SGPR_Count'],r.get('LDS_Block_Size','')))
 with open('$R/profiles/$TAG/${WL}_pmc_counters.csv','w') as f:
-    f.write('# rocprofv3 --pmc passes (one bench step each) of: python3 bench.py --workload $WL --steps 1 --warmup 0 $@ ; kernel_sha1=%s\n' % bench.kernel_source_hash())
+    f.write('# rocprofv3 --pmc passes (one warm-up step + one step each; bench.py uses the largest launch per counter = the steady-state main launch) of: python3 bench.py --workload $WL --steps 1 --warmup 1 $@ ; kernel_sha1=%s\n' % bench.kernel_source_hash())
     w=csv.writer(f); w.writerow(['kernel','counter','value','kernel_ms_under_pmc','grid','wg','vgpr','sgpr','lds'])
     for r in rows: w.writerow(r)
 print(len(rows),'pmc rows')

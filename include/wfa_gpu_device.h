@@ -104,6 +104,12 @@ int wfagpu_amd_align_device(wfagpu_amd_ctx_t* ctx, const wfagpu_amd_batch_t* bat
 
 void wfagpu_amd_last_stats(const wfagpu_amd_ctx_t* ctx, wfagpu_amd_stats_t* out);
 
+/* on = 1: the following calls on ctx align batches drawn from the same stream of reads (the batches of one
+ * launch_alignments call): the auto-tuned score budgets learnt from a sample of one batch are tried on the next ones
+ * without sampling again (results stay exact: pairs that miss their budget are re-run, and a batch in which more than
+ * 5 % do makes the next one sample again).  on = 0 forgets what was learnt. */
+void wfagpu_amd_hint_same_stream(wfagpu_amd_ctx_t* ctx, int on);
+
 /* Number of devices launch_alignments* shard a call over (default: all
  * visible).  Results stay in input order. */
 void wfagpu_amd_set_num_devices(int n);

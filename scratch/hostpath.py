@@ -13,11 +13,12 @@ length = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 err = float(sys.argv[3]) if len(sys.argv) > 3 else 0.05
 cigar = (sys.argv[4] != "score") if len(sys.argv) > 4 else True
 reps = int(sys.argv[5]) if len(sys.argv) > 5 else 2
+batch = int(sys.argv[6]) if len(sys.argv) > 6 else n
 lib = wfagpu.load()
 buf, meta = wfagpu.generate_pairs(n, length, err, seed=7, nthreads=16)
 res = C.POINTER(wfagpu.AlignmentResult)()
 assert lib.initialize_wfa_results(C.byref(res), n, 256)
-opt = wfagpu.Options(max_error=int(length * 0.1 * 3), threads_per_block=64, num_workers=0, band=-1, batch_size=n,
+opt = wfagpu.Options(max_error=int(length * 0.1 * 3), threads_per_block=64, num_workers=0, band=-1, batch_size=batch,
                      num_alignments=n, penalties=wfagpu.Penalties(2, 3, 1), compute_cigar=cigar)
 fn = lib.launch_alignments if cigar else lib.launch_alignments_distance
 for r in range(reps):

@@ -323,3 +323,33 @@ def test_ragged_call_is_cut_by_work_not_by_count(monkeypatch):
     s, c = _api_align(pairs, (2, 3, 1), cigar=True, max_error=400)
     assert np.array_equal(s, np.asarray(so)) and c == co
     lib.wfagpu_amd_release_cache()
+
+
+def test_budgets_inherited_across_batches_stay_exact_when_the_stream_drifts():
+    """launch_alignments* reuse the auto-tuned score budgets of the first batch of a call for the later ones
+    (wfagpu_amd_hint_same_stream).  Here the error rate jumps from 2 % to 10 % half-way through the call: the inherited
+    budgets are wrong for every pair of batch 3, which must all be re-run (and batch 4 samples again); scores and CIGARs
+    of all 36000 pairs equal the oracle's."""
+    lib = wfagpu.load()
+    parts = [wfagpu.generate_pairs(18000, 300, 0.02, seed=201), wfagpu.generate_pairs(18000, 300, 0.10, seed=202)]
+    bufs, metas, base = [], [], 0
+    for b, m in parts:
+        m = m.copy(); m["pattern_offset"] += base; m["text_offset"] += base
+        pad = (-len(b)) % 4
+        bufs += [b, np.zeros(pad, dtype=np.uint8)]; metas.append(m); base += len(b) + pad
+    buf = np.concatenate(bufs + [np.zeros(64, dtype=np.uint8)]); meta = np.concatenate(metas)
+    n = len(meta)
+    so, co, _ = oracle_lib.oracle_batch(buf, meta, (2, 3, 1), cigar=True, nthreads=16)
+    res = C.POINTER(wfagpu.AlignmentResult)()
+    assert lib.initialize_wfa_results(C.byref(res), n, 64)
+    opt = wfagpu.Options(max_error=200, threads_per_block=64, num_workers=0, band=-1, batch_size=9000, num_alignments=n,
+                         penalties=wfagpu.Penalties(2, 3, 1), compute_cigar=True)
+    lib.wfagpu_amd_set_num_devices(1)
+    meta2 = meta.copy()
+    lib.launch_alignments(buf.ctypes.data, buf.nbytes, meta2.ctypes.data, res, opt, False)
+    s = np.array([res[i].error for i in range(n)], dtype=np.int64)
+    c = [C.string_at(res[i].cigar.buffer).decode() for i in range(n)]
+    lib.destroy_wfa_results(res, n)
+    lib.wfagpu_amd_set_num_devices(0)
+    assert np.array_equal(s, so)
+    assert c == co

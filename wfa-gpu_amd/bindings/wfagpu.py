@@ -73,7 +73,7 @@ ABI_SYMBOLS = [
     # include/wfa_gpu_device.h
     "wfagpu_amd_create", "wfagpu_amd_destroy", "wfagpu_amd_fill_packed_offsets", "wfagpu_amd_pack_device",
     "wfagpu_amd_align_device", "wfagpu_amd_last_stats", "wfagpu_amd_set_num_devices", "wfagpu_amd_release_cache",
-    "wfagpu_amd_check_failures",
+    "wfagpu_amd_check_failures", "wfagpu_amd_hint_same_stream",
 ]
 
 _lib = None

@@ -218,6 +218,10 @@ struct wfagpu_amd_ctx {
   unsigned long long* h_counters = nullptr;  // pinned
   hipEvent_t ev_start = nullptr, ev_pack = nullptr, ev_a0 = nullptr, ev_a1 = nullptr, ev_t0 = nullptr, ev_t1 = nullptr, ev_end = nullptr;
   wfagpu_amd_stats_t stats{};
+  // budgets learnt from the sample of an earlier batch of the same stream (wfagpu_amd_hint_same_stream)
+  bool same_stream = false;
+  struct SavedQ { unsigned bucket_hi; int q; int x, o, e, max_error; } saved_q[8] = {};
+  int n_saved_q = 0;
 };
 
 extern "C" {
@@ -297,6 +301,12 @@ int wfagpu_amd_pack_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_batch_t* b, voi
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;
+}
+
+void wfagpu_amd_hint_same_stream(wfagpu_amd_ctx_t* c, int on) {
+  if (!c) return;
+  c->same_stream = on != 0;
+  if (!on) c->n_saved_q = 0;
 }
 
 void wfagpu_amd_last_stats(const wfagpu_amd_ctx_t* c, wfagpu_amd_stats_t* out) {
@@ -697,7 +707,24 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       int budget_cap = max_error;
       const bool try_budget = !raw && !want_band && n_pending >= 8192 && !getenv("WFAGPU_NO_AUTOBUDGET") &&
                               window_width(max_error, pen.o, pen.e, max_len) > 128;
-      if (try_budget) {
+      int saved_idx = -1;
+      if (try_budget && c->same_stream) {
+        for (int i = 0; i < c->n_saved_q; ++i) {
+          const auto& sq = c->saved_q[i];
+          if (sq.bucket_hi == bucket_hi && sq.x == pen.x && sq.o == pen.o && sq.e == pen.e && sq.max_error == max_error) saved_idx = i;
+        }
+      }
+      if (try_budget && saved_idx >= 0) {
+        // a later batch of the same stream of reads: try the budgets the sample of an earlier batch gave (misses are
+        // re-run with the caller's budget as always; too many of them and the next batch samples again)
+        const int q = c->saved_q[saved_idx].q;
+        const int slack = pen.o + pen.e + pen.x + 2;
+        if (c->budget.ensure((size_t)4 * n, st)) return -1;
+        LAUNCH_K(k_budget, dim3(cdiv(n, 256)), dim3(256), 0, st, ap.meta, n, q, slack, static_cast<int32_t*>(c->budget.p));
+        budgets = static_cast<const int32_t*>(c->budget.p);
+        budget_cap = (int)std::min<long long>(max_error, ((long long)q * max_len * 102 / 100) / 1024 + slack);
+        c->stats.auto_budget = budget_cap;
+      } else if (try_budget) {
         const uint32_t n_s = std::min<uint32_t>(4096u, std::max<uint32_t>(512u, n_pending / 16u)), stride_s = n_pending / n_s;
         if (c->sample.ensure((size_t)4 * n_s, st)) return -1;
         if (c->ratio.ensure((size_t)4 * n_s, st)) return -1;
@@ -721,6 +748,11 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
           budgets = static_cast<const int32_t*>(c->budget.p);
           budget_cap = (int)std::min<long long>(max_error, ((long long)q * max_len * 102 / 100) / 1024 + slack);
           c->stats.auto_budget = budget_cap;
+          // remember it for later batches of the same stream
+          int slot = -1;
+          for (int i = 0; i < c->n_saved_q; ++i) if (c->saved_q[i].bucket_hi == bucket_hi) slot = i;
+          if (slot < 0 && c->n_saved_q < 8) slot = c->n_saved_q++;
+          if (slot >= 0) c->saved_q[slot] = {bucket_hi, q, pen.x, pen.o, pen.e, max_error};
         }
         // the sampled pairs are done: drop them from the bucket's list
         uint32_t* rest = static_cast<uint32_t*>(c->list_e.p);
@@ -731,7 +763,12 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         n_pending = (uint32_t)c->h_counters[CT_LIST];
         HIP_TRY(hipMemcpyAsync(pending, rest, (size_t)4 * n_pending, hipMemcpyDeviceToDevice, st));
       }
+      const unsigned missed_before = c->stats.pairs_budget_missed;
       if (n_pending && run_list(pending, n_pending, raw, budgets, budget_cap, static_cast<uint32_t*>(c->list_d.p), pending)) return -1;
+      if (saved_idx >= 0 && (c->stats.pairs_budget_missed - missed_before) * 20u > n_pending) {
+        // more than 5 % of the batch missed the inherited budgets: the stream has drifted, sample again next time
+        c->saved_q[saved_idx] = c->saved_q[--c->n_saved_q];
+      }
     }
     if (bucket_hi >= batch_max_len) break;
     bucket_lo = bucket_hi + 1u;

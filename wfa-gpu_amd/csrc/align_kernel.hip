@@ -90,7 +90,11 @@ template <int NW> __device__ __forceinline__ uint32_t block_bcast(uint32_t v, ui
 //          past a sequence end; lo = 1, hi = -1 when the component does not exist)
 // NW == 1 keeps each in one VGPR (lane = slot): reading is one v_readlane, no LDS round trip, and
 // everything derived from it stays on the scalar unit.
-constexpr int ROW_NONE_A = (int)0xFFFF0001u;   // lo = 1, hi = -1
+// "No wavefront / no component": lo far above hi, so that min(lo, lo' - 1) / max(hi, hi' + 1) over a mix of existing and
+// missing rows ignore the missing ones by themselves (WFA2's null wavefront carries lo = 1, hi = -1, whose traces in the
+// limits of the next wavefront only ever add cells that are not valid).
+constexpr int ROW_NONE_LO = 16000, ROW_NONE_HI = -16000;
+constexpr int ROW_NONE_A = (int)(((unsigned)ROW_NONE_LO & 0xFFFFu) | ((unsigned)ROW_NONE_HI << 16));
 __device__ __forceinline__ int pack_range(int lo, int hi) { return (lo & 0xFFFF) | (int)((unsigned)hi << 16); }
 __device__ __forceinline__ int range_lo(int a) { return (int)(int16_t)(a & 0xFFFF); }
 __device__ __forceinline__ int range_hi(int a) { return a >> 16; }
@@ -632,6 +636,92 @@ wfa_align_kernel(const WfaAlignParams p) {
             }
           }
         }
+        // ---- lean path, any gap extension: the same cells, but the limits come from the row book (three reads:
+        // lo = min(lo[s-x], lo[s-o-e] - 1, lo[s-e] - 1), hi alike -- every row that exists carries all three components over
+        // its limits here), the reach interval moves one diagonal every e scores, and scores without any predecessor row
+        // (all odd scores of an all-even penalty set) are "no wavefront" scores: their ring slots are cleared and nothing
+        // is computed.
+        if constexpr (!BANDED) {
+          if (e != 1 && !touched_ever) {
+            const int s_in = s;
+            bool nomem = false;
+            for (;;) {
+              const int ns = s + 1;
+              int n_rr = reach_r, n_rlo = rlo, n_rhi = rhi;
+              if (n_rr == 0) { ++n_rlo; --n_rhi; n_rr = e - 1; } else --n_rr;
+              const int a_x = book.get_a((ns - x) & bkm), a_oe = book.get_a((ns - oe) & bkm), a_e = book.get_a((ns - e) & bkm);
+              int lo = min(range_lo(a_x), range_lo(a_oe) - 1), hi = max(range_hi(a_x), range_hi(a_oe) + 1);
+              if constexpr (NW == 1) asm volatile("" : "+s"(lo), "+s"(hi));
+              lo = min(lo, range_lo(a_e) - 1); hi = max(hi, range_hi(a_e) + 1);
+              if constexpr (NW == 1) asm volatile("" : "+s"(lo), "+s"(hi));
+              lo = max(lo, wlo); hi = min(hi, whi);
+              if constexpr (NW == 1) asm volatile("" : "+s"(lo), "+s"(hi));
+              lo = max(lo, n_rlo); hi = min(hi, n_rhi);
+              if (lo > hi && bounded && ns > budget) break;      // budget exhausted: the careful path reports it
+              s = ns; rlo = n_rlo; rhi = n_rhi; reach_r = n_rr;
+              if constexpr (NW > 1) {
+                if (tid < 8) red[8 * ((s + 1) % 3) + tid] = (tid == 6) ? 0 : ((tid & 1) ? INT_MIN : INT_MAX);
+              }
+              p_m += rs;  if (p_m == m_end) p_m = m_first;
+              p_x += rs;  if (p_x == m_end) p_x = m_first;
+              p_oe += rs; if (p_oe == m_end) p_oe = m_first;
+              p_ic += rs; if (p_ic == i_end) p_ic = i_first;
+              p_ip += rs; if (p_ip == i_end) p_ip = i_first;
+              OffT* out_m = p_m; OffT* out_i = p_ic; OffT* out_d = d_of(p_ic);
+              if (lo > hi) {
+                // no wavefront at this score: the slots it would have written must read as NULL everywhere
+                const int o_m = book.get_a((s - dm) & bkm), o_e = book.get_a((s - de) & bkm);
+                const int f0 = min(range_lo(o_m), range_lo(o_e)), f1 = max(range_hi(o_m), range_hi(o_e));
+                for (int q = f0 + tid; q <= f1; q += NT) {
+                  out_m[q] = (OffT)OffNull<OffT>::value; out_i[q] = (OffT)OffNull<OffT>::value; out_d[q] = (OffT)OffNull<OffT>::value;
+                }
+                book.set_a(s & bkm, ROW_NONE_A);
+                block_sync<NW>();
+                continue;
+              }
+              const int width = hi - lo + 1;
+              ncells += (uint32_t)width;
+              uint8_t* codes = nullptr;
+              if constexpr (BT) {
+                if (!alloc_row(width)) { nomem = true; break; }
+                tab_set(s, row_s, lo);
+                codes = p.arena + (size_t)row_s * 16;
+              }
+              // ring invariant: the limits move by at most one diagonal per score (see the e == 1 loop)
+              for (int j0 = 0; j0 < 2 * dm; j0 += NT) {
+                const int j = min(j0 + tid, 2 * dm - 1);
+                const int q = (j < dm) ? lo - 1 - j : hi + 1 - dm + j;
+                out_m[q] = (OffT)OffNull<OffT>::value; out_i[q] = (OffT)OffNull<OffT>::value; out_d[q] = (OffT)OffNull<OffT>::value;
+              }
+              bool my_over = false;
+              unsigned long long touch_mask = 0;
+              cells_of_score(std::true_type{}, lo, hi, codes, p_x, p_oe - 1, p_ip - 1, d_of(p_ip) + 1, out_m, out_i, out_d, BandCtx{},
+                             my_over, touch_mask);
+              const bool wave_touch = touch_mask != 0ull;
+              bool any_touch;
+              if constexpr (NW == 1) {
+                block_sync<NW>();
+                any_touch = wave_touch;
+              } else {
+                int* acc = red + 8 * (s % 3);
+                if (lane == 0 && wave_touch) atomicOr(&acc[6], 4);
+                __syncthreads();
+                any_touch = (acc[6] & 4) != 0;
+              }
+              book.set_a(s & bkm, pack_range(lo, hi));
+              if constexpr (NW == 1) block_sync<NW>();
+              if (any_touch) {
+                touched_ever = true;
+                done = ((unsigned)(kend - lo) <= (unsigned)(hi - lo)) && __builtin_amdgcn_readfirstlane((int)out_m[kend]) >= tlen;
+                break;
+              }
+            }
+            if (s != s_in) book.copy_a_to_id(tid, NT, bkm);
+            regular = 0;      // (the careful path's shortcut for runs of regular scores starts counting afresh)
+            if (nomem) { status = WFA_ST_NOMEM; break; }
+            if (done) break;
+          }
+        }
         ++s;
         // (exact mode: past the budget the reach interval is empty, so the test sits on the "no wavefront" path)
         if constexpr (BANDED) { if (s > budget) { status = WFA_ST_SCORE; break; } }
@@ -847,8 +937,8 @@ wfa_align_kernel(const WfaAlignParams p) {
             __syncthreads();
             r[0] = acc[0]; r[1] = acc[1]; r[2] = acc[2]; r[3] = acc[3];
           }
-          if (r[0] > r[1]) { r[0] = 1; r[1] = -1; }
-          if (r[2] > r[3]) { r[2] = 1; r[3] = -1; }
+          if (r[0] > r[1]) { r[0] = ROW_NONE_LO; r[1] = ROW_NONE_HI; }
+          if (r[2] > r[3]) { r[2] = ROW_NONE_LO; r[3] = ROW_NONE_HI; }
           lim_i = pack_range(r[0], r[1]); lim_d = pack_range(r[2], r[3]);
           if constexpr (!BANDED) {
             // trimmed-away cells read as NULL from now on (wavefront_compute.c:480-520)

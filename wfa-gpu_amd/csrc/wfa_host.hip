@@ -198,6 +198,12 @@ __global__ void k_count_unfinished(uint32_t n, const uint32_t* __restrict__ stat
   if (bal && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(bal)) atomicAdd(count, (unsigned long long)__builtin_popcountll(bal));
 }
 
+// scores of a run with penalties divided by their common factor g -> scores under the caller's penalties
+__global__ void k_scale_scores(int32_t* __restrict__ score, uint32_t n, int g) {
+  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid < n && score[gid] > 0) score[gid] *= g;
+}
+
 __global__ void k_set_pending(const uint32_t* __restrict__ work, uint32_t n, uint32_t* __restrict__ status) {
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
   if (gid < n) status[work ? work[gid] : gid] = WFA_ST_PENDING;
@@ -398,6 +404,18 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
     return -1;
   }
   const bool want_band = band > 0 && band_width > 0;
+  // Penalties with a common factor g (WFA2's default 4,6,2) describe the same alignments as the penalties divided by g,
+  // with every score multiplied by g: same optimal paths, same tie-breaks, hence the same CIGARs.  Running the reduced
+  // set avoids the (g-1)/g of all scores that have no wavefront at all and halves the score-indexed work.
+  int pen_scale = 1;
+  {
+    auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };
+    const int g = gcd(gcd(pen.x, pen.o), pen.e);
+    if (g > 1) {
+      pen_scale = g; pen.x /= g; pen.o /= g; pen.e /= g; max_error = std::max(1, max_error / g);
+      if (want_band) band = std::max(1, band / g);     // (the re-centring period counts scores)
+    }
+  }
   HIP_TRY(hipSetDevice(c->device));
   const uint32_t n = (uint32_t)b->num_pairs;
   c->stats = wfagpu_amd_stats_t{};
@@ -774,6 +792,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
     bucket_lo = bucket_hi + 1u;
   }
   }  // class loop
+  if (pen_scale > 1) LAUNCH_K(k_scale_scores, dim3(cdiv(n, 256)), dim3(256), 0, st, d_scores, n, pen_scale);
   // every pair must have been finished by one of the lists above; anything else is a driver bug and must not
   // be returned as a result
   if (zero_counter(c, CT_LIST)) return -1;
@@ -791,6 +810,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   if (compute_cigar && c->arena_limit && c->arena_limit_max > c->arena_limit && c->stats.sub_batches > 1 &&
       c->arena.cap >= c->arena_limit - ((size_t)1 << 20))
     c->arena_limit = std::min(c->arena_limit_max, 2 * c->arena_limit);
+  c->stats.auto_budget *= pen_scale;
   c->stats.align_ms = align_ms;
   c->stats.trace_ms = trace_ms;
   c->stats.text_bytes = text_used;

@@ -181,6 +181,7 @@ def test_call_sharded_over_several_device_slots(golden_dir, monkeypatch, shards,
     lib = wfagpu.load()
     lib.wfagpu_amd_release_cache.restype = None
     monkeypatch.setenv("WFAGPU_VIRTUAL_DEVICES", str(shards))
+    monkeypatch.setenv("WFAGPU_FORCE_NUMA_PIN", "1")     # slice threads move to the cores of their GPU's NUMA node (best effort)
     pairs = wfagpu.read_seq_file(os.path.join(golden_dir, "seq1k.seq"))[:301]
     buf, meta = wfagpu.layout_pairs(pairs)
     so, co, _ = oracle_lib.oracle_batch(buf, meta, (2, 3, 1), cigar=True, nthreads=8)

@@ -40,6 +40,46 @@ unsigned usable_host_threads() {
   return std::max(1u, std::thread::hardware_concurrency());
 }
 
+// Best effort: run a slice's host threads (this one and the ones it starts: they inherit the mask) on the cores of the
+// NUMA node its GPU hangs off, so that the staging copies and the scatter of eight slices do not all cross the socket
+// interconnect.  Intersected with the mask the process already has; any failure leaves things as
+// they are.  WFAGPU_NO_NUMA_PIN=1 disables it.
+void pin_to_device_node(int device) {
+  if (getenv("WFAGPU_NO_NUMA_PIN")) return;
+  char bdf[64] = {0};
+  if (hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf) - 1, device) != hipSuccess) return;
+  for (char* p = bdf; *p; ++p) if (*p >= 'A' && *p <= 'F') *p = (char)(*p - 'A' + 'a');    // sysfs spells it in lower case
+  char path[256];
+  snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bdf);
+  FILE* f = fopen(path, "r");
+  if (!f) return;
+  int node = -1;
+  const int got = fscanf(f, "%d", &node);
+  fclose(f);
+  if (got != 1 || node < 0) return;
+  snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+  f = fopen(path, "r");
+  if (!f) return;
+  char list[4096] = {0};
+  const size_t len = fread(list, 1, sizeof(list) - 1, f);
+  fclose(f);
+  if (!len) return;
+  cpu_set_t have, want;
+  CPU_ZERO(&want);
+  if (sched_getaffinity(0, sizeof(have), &have) != 0) return;
+  for (char* p = list; *p;) {                     // "0-31,64-95"
+    char* end = nullptr;
+    long a = strtol(p, &end, 10);
+    if (end == p) break;
+    long b = a;
+    if (*end == '-') { p = end + 1; b = strtol(p, &end, 10); if (end == p) break; }
+    for (long c = a; c <= b && c < CPU_SETSIZE; ++c) if (CPU_ISSET((int)c, &have)) CPU_SET((int)c, &want);
+    p = (*end == ',') ? end + 1 : end;
+    if (*end != ',') break;
+  }
+  if (CPU_COUNT(&want) > 0) (void)sched_setaffinity(0, sizeof(want), &want);
+}
+
 struct Shard {
   int device;        // physical device
   int slot;          // index of the cached per-device state (== device unless WFAGPU_VIRTUAL_DEVICES is set)
@@ -430,7 +470,12 @@ void launch_impl(char* seq, size_t seq_bytes, sequence_pair_t* meta, wfa_alignme
     shards[0].rc = run_shard(a, shards[0]);
   } else {
     std::vector<std::thread> th;
-    for (int d = 0; d < ndev; ++d) th.emplace_back([&a, &shards, d] { shards[d].rc = run_shard(a, shards[d]); });
+    // (own threads, one per slice: each may be moved to the cores next to its GPU; the caller's thread is never touched)
+    for (int d = 0; d < ndev; ++d)
+      th.emplace_back([&a, &shards, d, physical] {
+        if (physical > 1 || getenv("WFAGPU_FORCE_NUMA_PIN")) pin_to_device_node(shards[d].device);    // (the variable: test hook for one-GPU boxes)
+        shards[d].rc = run_shard(a, shards[d]);
+      });
     for (auto& t : th) t.join();
   }
   for (auto& s : shards)

@@ -80,7 +80,7 @@ struct DevBuf {
 };
 
 // device counters (u64 slots)
-enum { CT_ARENA = 0, CT_OPS = 1, CT_TEXT = 2, CT_LCELLS = 3, CT_LIST = 4, CT_SUM_OPS = 5, CT_SUM_TEXT = 6, CT_CELLS = 7, CT_MAX_SCORE = 8, CT_N = 9 };
+enum { CT_ARENA = 0, CT_OPS = 1, CT_TEXT = 2, CT_LCELLS = 3, CT_LIST = 4, CT_SUM_OPS = 5, CT_SUM_TEXT = 6, CT_CELLS = 7, CT_MAX_SCORE = 8, CT_NRAW = 9, CT_N = 10 };
 
 constexpr uint32_t MASK(uint32_t st) { return 1u << st; }
 
@@ -122,9 +122,13 @@ __global__ void k_compact_len(uint32_t n, const uint32_t* __restrict__ status, u
 }
 
 // flagged (non-ACGT) pairs never enter the 2-bit tiers
-__global__ void k_flag_alphabet(const uint8_t* __restrict__ flags, uint32_t n, uint32_t* __restrict__ status) {
+__global__ void k_flag_alphabet(const uint8_t* __restrict__ flags, uint32_t n, uint32_t* __restrict__ status,
+                                unsigned long long* __restrict__ n_raw) {
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid < n && (flags[2 * gid] | flags[2 * gid + 1])) status[gid] = WFA_ST_ALPHABET;
+  const bool raw = gid < n && (flags[2 * gid] | flags[2 * gid + 1]);
+  if (raw) status[gid] = WFA_ST_ALPHABET;
+  const unsigned long long bal = __ballot(raw);       // (their number lets the host skip the byte-compare class when it is empty)
+  if (bal && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(bal)) atomicAdd(n_raw, (unsigned long long)__builtin_popcountll(bal));
 }
 
 // bounds for the trace scratch: sum over finished pairs of the op-list and
@@ -491,7 +495,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   HIP_TRY(hipEventRecord(c->ev_start, st));
   wfa_launch_pack(b->d_sequences, ap.meta, n, static_cast<uint32_t*>(c->packed.p), static_cast<uint8_t*>(c->flags.p), st);
   LAUNCH_K(k_flag_alphabet, dim3(cdiv(n, 256)), dim3(256), 0, st, static_cast<const uint8_t*>(c->flags.p), n,
-                     static_cast<uint32_t*>(c->status.p));
+                     static_cast<uint32_t*>(c->status.p), ct + CT_NRAW);
   HIP_TRY(hipEventRecord(c->ev_pack, st));
 
   float align_ms = 0.f, trace_ms = 0.f;
@@ -598,8 +602,8 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
     LAUNCH_K(k_trace_bounds, dim3(std::min<uint32_t>(cdiv(n_pass, 256), 1024u)), dim3(256), 0, st, (const uint32_t*)pending, n_pass,
                        static_cast<const uint32_t*>(c->status.p), (const int32_t*)d_scores,
                        static_cast<const uint32_t*>(c->cells.p), std::min(pen.x, pen.e), ct);
-    if (read_counters(c)) return -1;
     if (compute_cigar) {
+      if (read_counters(c)) return -1;       // (score-only calls need none of these sums before the end of the call)
       const unsigned long long ops_need = c->h_counters[CT_SUM_OPS] + 256;
       const unsigned long long text_need = text_used + c->h_counters[CT_SUM_TEXT] + 256;
       if (c->ops.ensure(ops_need, st)) return -1;
@@ -639,17 +643,19 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipEventRecord(c->ev_t1, st));
     }
-    // ---- pairs that ran out of arena go into the next pass --------------------
-    if (zero_counter(c, CT_LIST)) return -1;
+    // ---- pairs that ran out of arena go into the next pass (CIGAR calls only: score-only calls have no arena) ----
     uint32_t* nxt_pending = (pending == alt0) ? alt1 : alt0;
-    LAUNCH_K(k_compact, dim3(cdiv(n_pass, 256)), dim3(256), 0, st, (const uint32_t*)pending, n_pass,
-                       static_cast<const uint32_t*>(c->status.p), MASK(WFA_ST_NOMEM), nxt_pending, ct + CT_LIST);
-    if (read_counters(c)) return -1;
     if (compute_cigar) {
+      if (zero_counter(c, CT_LIST)) return -1;
+      LAUNCH_K(k_compact, dim3(cdiv(n_pass, 256)), dim3(256), 0, st, (const uint32_t*)pending, n_pass,
+                         static_cast<const uint32_t*>(c->status.p), MASK(WFA_ST_NOMEM), nxt_pending, ct + CT_LIST);
+      if (read_counters(c)) return -1;
       float ms = 0.f;
       HIP_TRY(hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1));
       trace_ms += ms;
       text_used = c->h_counters[CT_TEXT];
+    } else {
+      c->h_counters[CT_LIST] = 0;
     }
     const uint32_t n_nomem = (uint32_t)c->h_counters[CT_LIST];
     if (n_nomem) {
@@ -679,7 +685,6 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
                          static_cast<uint32_t*>(c->status.p));
     }
     c->stats.arena_units = std::max<unsigned long long>(c->stats.arena_units, c->h_counters[CT_ARENA]);
-    c->stats.cells = c->h_counters[CT_CELLS];
     // refine the per-pair estimate from this pass, then queue what was not launched behind the re-runs
     if (compute_cigar && n_pass - n_nomem >= 65536u)   // (few pairs per workgroup: refill slack would dominate)
       est_pair_bytes = std::max(256.0, 1.15 * 16.0 * (double)c->h_counters[CT_ARENA] / (double)(n_pass - n_nomem));
@@ -693,6 +698,8 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   // two classes of pairs: ACGT-only (2-bit packed kernels) and the rest (byte-compare kernels)
   for (int cls = 0; cls < 2; ++cls) {
   const bool raw = cls == 1;
+  // (the first pass of the packed class has synchronised with the device: the number of flagged pairs is known)
+  if (raw && c->h_counters[CT_NRAW] == 0) break;
   max_len = batch_max_len;
   if (raw) ap.packed = reinterpret_cast<const uint32_t*>(b->d_sequences);
   ap.seq_words_cap = raw ? (int)((max_len + 3) / 4 + 1) : (int)((max_len + 15) / 16 + 1);
@@ -803,6 +810,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
     fprintf(stderr, "[!] ERROR: %llu of %u alignments were left unfinished\n", c->h_counters[CT_LIST], n);
     return -1;
   }
+  c->stats.cells = c->h_counters[CT_CELLS];
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, c->ev_start, c->ev_pack)); c->stats.pack_ms = ms;
   HIP_TRY(hipEventElapsedTime(&ms, c->ev_start, c->ev_end)); c->stats.total_ms = ms;

@@ -137,10 +137,11 @@ def cpu_baseline(buf, meta, compute_cigar, budget_pairs):
     return res
 
 
-def host_to_host(buf, meta, wl, max_error, n_devices=1, reps=3, registered=True):
+def host_to_host(buf, meta, wl, max_error, n_devices=1, reps=5, registered=True):
     """The metric as SURVEY.md section 8(d) defines it: N / wall of launch_alignments*() -- pageable host buffers in,
     host results (CIGAR strings scattered into the caller's wfa_alignment_result_t records) out, PCIe both ways.
-    First call = cold (context, allocations), later calls = warm (per-device state cached by the library)."""
+    First call = cold (context, allocations), later calls = warm (per-device state cached by the library; the arena
+    cap doubles after multi-pass calls, so the best of several warm calls is the steady state)."""
     import ctypes as C
     import wfagpu
     lib = wfagpu.load()

@@ -53,7 +53,7 @@ for it in range(iters):
     so, co, _ = oracle_lib.oracle_batch(buf, meta, pen, cigar=True, nthreads=16)
     os.environ.pop("WFAGPU_MIN_TIER", None)
     if rng.random() < 0.25:
-        os.environ["WFAGPU_MIN_TIER"] = str(rng.randint(1, 3))
+        os.environ["WFAGPU_MIN_TIER"] = str(rng.randint(1, 4))
     batch = al.upload(buf, meta)
     for max_error in (rng.choice([1, 5, 20]), rng.choice([60, 200, 1000]), 20000):
         s, c = al.align(batch, pen, max_error=max_error, compute_cigar=True)

@@ -522,3 +522,31 @@ def test_adaptive_band_on_long_read_shaped_pairs(aligner, beta, lam, min_recall)
     for i in range(0, n, 5):
         ok, cost = oracle_lib.check_cigar(pairs[i][0], pairs[i][1], c[i], (2, 3, 1))
         assert ok and cost == s[i]
+
+
+def test_long_non_acgt_pair_backtrace_through_global_scratch(aligner):
+    """One wavefront per alignment keeps the op list and the CIGAR text in LDS when they fit next to the staged sequences;
+    byte-compare (non-ACGT) pairs of 21 kbp leave no room (2 x 21 KB of sequence bytes), so both go through the global
+    scratch and the text is written by a second replay -- the same answers, compared with the checker."""
+    rng = random.Random(4)
+    pairs = []
+    for L in (21000, 20500):
+        t = bytearray(rng.choice(b"ACGT") for _ in range(L))
+        for pos in rng.sample(range(L), 40):
+            t[pos] = ord("N")
+        p = bytearray(t)
+        for _ in range(L // 50):
+            a = rng.randrange(len(p)); r = rng.random()
+            if r < 0.4:
+                p[a] = rng.choice(b"ACGTN")
+            elif r < 0.7:
+                del p[a:a + rng.randint(1, 4)]
+            else:
+                p[a:a] = bytes(rng.choice(b"ACGT") for _ in range(rng.randint(1, 4)))
+        pairs.append((bytes(p), bytes(t)))
+    pairs.append((b"ACGTNACGT" * 20, b"ACGTNACGA" * 20))
+    buf, meta = wfagpu.layout_pairs(pairs)
+    so, co = _truth(buf, meta, (2, 3, 1))
+    s, c = _run(aligner, buf, meta, (2, 3, 1), max_error=4000)
+    assert aligner.stats().pairs_raw == 3
+    assert np.array_equal(s, so) and c == co

@@ -497,7 +497,12 @@ wfa_align_kernel(const WfaAlignParams p) {
               // v_ffbl_b32 returns 0xFFFFFFFF for 0, so "all equal" is a huge positive count
               asm("v_ffbl_b32 %0, %1" : "=v"(fb) : "v"(d0w));
             }
-            h += min(min((int)(fb >> BITS), PER), rem);
+            {
+              // (one v_min3_i32: the compiler splits the two mins into an unsigned and a signed one)
+              int adv;
+              asm("v_min3_i32 %0, %1, %2, %3" : "=v"(adv) : "v"((int)(fb >> BITS)), "v"(rem), "n"(PER));
+              h += adv;
+            }
             // the whole word matched: the run may go on (if anything remains)
             const bool more = ok & (d0w == 0u);
             if (__builtin_amdgcn_ballot_w64(more) != 0ull) {

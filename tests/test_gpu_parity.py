@@ -550,3 +550,20 @@ def test_long_non_acgt_pair_backtrace_through_global_scratch(aligner):
     s, c = _run(aligner, buf, meta, (2, 3, 1), max_error=4000)
     assert aligner.stats().pairs_raw == 3
     assert np.array_equal(s, so) and c == co
+
+
+@pytest.mark.parametrize("pen,max_error", [((4, 6, 2), 400), ((5, 3, 2), 500), ((3, 1, 4), 600), ((1, 0, 1), 150), ((6, 9, 3), 700)])
+def test_penalty_sets_at_scale(aligner, pen, max_error):
+    """Other penalty sets in the regime the headline runs in (>= 8192 pairs: sampled per-pair budgets + the lean score loop).
+    Gap extensions > 1 take the second form of the lean loop (limits from the row book, scores without a wavefront skipped);
+    sets with a common factor -- (4,6,2) = 2 x (2,3,1), (6,9,3) = 3 x (2,3,1) -- run as the reduced set with the scores scaled
+    back.  12k pairs of two lengths, scores and CIGARs byte-identical to the oracle's, score-only mode included."""
+    buf, meta = _concat_layouts([wfagpu.generate_pairs(8000, 600, 0.05, seed=301), wfagpu.generate_pairs(4000, 900, 0.08, seed=302)])
+    so, co, _ = oracle_lib.oracle_batch(buf, meta, pen, cigar=True, nthreads=16)
+    batch = aligner.upload(buf, meta)
+    s, c = aligner.align(batch, pen, max_error=max_error, compute_cigar=True)
+    assert aligner.stats().auto_budget > 0
+    assert np.array_equal(s, so)
+    assert c == co
+    s2, _ = aligner.align(batch, pen, max_error=max_error, compute_cigar=False)
+    assert np.array_equal(s2, so)

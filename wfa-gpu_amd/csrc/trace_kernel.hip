@@ -322,6 +322,30 @@ __global__ void __launch_bounds__(TRACE_THREADS) wfa_emit_kernel(const WfaTraceP
     Pw = seq_lds + (size_t)lane * stride;
     Tw = Pw + pw;
   }
+  if (p.text_scratch) {
+    // single replay: the text goes to this lane's slot of the scratch (sized by the same bound the host sizes the arenas
+    // with: at most score / min(x, e) operations, each with a match run, 6 characters per item); wfa_text_compact_kernel
+    // moves it to its place in the dense arena
+    const uint32_t bound = (active && !fail) ? 6u * (2u * ((uint32_t)p.score[pair] / (uint32_t)p.min_op_cost) + 1u) + 1u : 0u;
+    const unsigned long long s_off = wave_alloc(p.scratch_top, bound, lane);
+    if (active && !fail && s_off + bound > p.text_scratch_cap) fail = true;
+    if (active) {
+      uint32_t len = 0xFFFFFFFFu;
+      if (!fail) {
+        int cost = 0;
+        len = p.raw ? replay<true>(q, nops, Pw, Tw, plen, tlen, p.text_scratch + s_off, p.x, p.oe - p.e, p.e, &cost, bound)
+                    : replay<false>(q, nops, Pw, Tw, plen, tlen, p.text_scratch + s_off, p.x, p.oe - p.e, p.e, &cost, bound);
+        if (len != 0xFFFFFFFFu && len + 1u > bound) len = 0xFFFFFFFFu;
+        if (len != 0xFFFFFFFFu && cost != p.score[pair]) {
+          if (p.score_fix) p.score_fix[pair] = cost;
+          else len = 0xFFFFFFFFu;
+        }
+      }
+      p.cigar_off[pair] = s_off;
+      p.cigar_len[pair] = len;
+    }
+    return;
+  }
   uint32_t len = 0;
   if (active && !fail) {
     len = p.raw ? replay<true>(q, nops, Pw, Tw, plen, tlen, nullptr, 0, 0, 0, nullptr)
@@ -350,6 +374,33 @@ __global__ void __launch_bounds__(TRACE_THREADS) wfa_emit_kernel(const WfaTraceP
       p.cigar_off[pair] = 0;
       p.cigar_len[pair] = 0xFFFFFFFFu;
     }
+  }
+}
+
+// Texts from their scratch slots (cigar_off = scratch offset, cigar_len = length) to the dense arena: one wavefront per
+// 64 alignments, space bought with one atomic per wavefront, every text copied by all 64 lanes.
+__global__ void __launch_bounds__(TRACE_THREADS) wfa_text_compact_kernel(const WfaTraceParams p) {
+  const uint32_t gid = blockIdx.x * TRACE_THREADS + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  bool active = gid < p.n_work;
+  uint32_t pair = 0;
+  if (active) pair = p.work ? p.work[gid] : gid;
+  if (active && p.status[pair] != WFA_ST_DONE) active = false;
+  uint32_t len = active ? p.cigar_len[pair] : 0xFFFFFFFFu;
+  const unsigned long long src = active ? p.cigar_off[pair] : 0ull;
+  const uint32_t need = len != 0xFFFFFFFFu ? len + 1u : 0u;
+  const unsigned long long dst = wave_alloc(p.text_top, need, lane);
+  if (need && dst + need > p.text_cap) len = 0xFFFFFFFFu;
+  for (int j = 0; j < 64; ++j) {
+    const uint32_t nj = __shfl(len != 0xFFFFFFFFu ? len + 1u : 0u, j);
+    if (nj == 0) continue;
+    const char* sj = p.text_scratch + shfl64(src, j);
+    char* dj = p.text + shfl64(dst, j);
+    for (uint32_t t = lane; t < nj; t += 64) dj[t] = sj[t];
+  }
+  if (active) {
+    p.cigar_off[pair] = len != 0xFFFFFFFFu ? dst : 0ull;
+    p.cigar_len[pair] = len;
   }
 }
 
@@ -523,6 +574,7 @@ void wfa_launch_trace(const WfaTraceParams& p, hipStream_t stream) {
     const size_t lds = (size_t)64 * p.seq_lds_stride * 4;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wfa_emit_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(wfa_emit_kernel<true>, dim3(grid), dim3(TRACE_THREADS), lds, stream, p);
+    if (p.text_scratch) hipLaunchKernelGGL(wfa_text_compact_kernel, dim3(grid), dim3(TRACE_THREADS), 0, stream, p);
   } else {
     hipLaunchKernelGGL(wfa_emit_kernel<false>, dim3(grid), dim3(TRACE_THREADS), 0, stream, p);
   }

@@ -109,6 +109,12 @@ struct WfaTraceParams {
   char* text;
   unsigned long long text_cap;
   unsigned long long* text_top;
+  // lane-per-alignment emit, single replay: texts are first written at upper-bound offsets of this scratch and then
+  // compacted into `text` (NULL: two replays, the first one only to size the text)
+  char* text_scratch;
+  unsigned long long text_scratch_cap;
+  unsigned long long* scratch_top;
+  int min_op_cost;               // min(x, e): an alignment of score s has at most s / min_op_cost operations
   unsigned long long* cigar_off; // [pair] out: byte offset of the CIGAR in `text`
   uint32_t* cigar_len;           // [pair] out: strlen; 0xFFFFFFFF if it did not fit
 };

@@ -80,7 +80,7 @@ struct DevBuf {
 };
 
 // device counters (u64 slots)
-enum { CT_ARENA = 0, CT_OPS = 1, CT_TEXT = 2, CT_LCELLS = 3, CT_LIST = 4, CT_SUM_OPS = 5, CT_SUM_TEXT = 6, CT_CELLS = 7, CT_MAX_SCORE = 8, CT_NRAW = 9, CT_N = 10 };
+enum { CT_ARENA = 0, CT_OPS = 1, CT_TEXT = 2, CT_LCELLS = 3, CT_LIST = 4, CT_SUM_OPS = 5, CT_SUM_TEXT = 6, CT_CELLS = 7, CT_MAX_SCORE = 8, CT_NRAW = 9, CT_SCRATCH = 10, CT_N = 11 };
 
 constexpr uint32_t MASK(uint32_t st) { return 1u << st; }
 
@@ -224,7 +224,7 @@ struct wfagpu_amd_ctx {
   int num_cus = 0;
   size_t lds_per_block_max = 0;
   size_t arena_cfg = 0, text_cfg = 0, arena_limit = 0, arena_limit_max = 0;
-  DevBuf packed, flags, status, cells, bt_final, list_a, list_b, list_c, list_d, list_e, work_ctr, sample, ratio, budget, counters, arena, ops, text, cig_off, cig_len, gring;
+  DevBuf packed, flags, status, cells, bt_final, list_a, list_b, list_c, list_d, list_e, work_ctr, sample, ratio, budget, counters, arena, ops, text, text_scratch, cig_off, cig_len, gring;
   unsigned long long* h_counters = nullptr;  // pinned
   hipEvent_t ev_start = nullptr, ev_pack = nullptr, ev_a0 = nullptr, ev_a1 = nullptr, ev_t0 = nullptr, ev_t1 = nullptr, ev_end = nullptr;
   wfagpu_amd_stats_t stats{};
@@ -283,7 +283,7 @@ void wfagpu_amd_destroy(wfagpu_amd_ctx_t* c) {
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
   for (DevBuf* b : {&c->packed, &c->flags, &c->status, &c->cells, &c->bt_final, &c->list_a, &c->list_b, &c->list_c, &c->list_d, &c->list_e, &c->work_ctr, &c->sample, &c->ratio, &c->budget,
-                    &c->counters, &c->arena, &c->ops, &c->text, &c->cig_off, &c->cig_len, &c->gring})
+                    &c->counters, &c->arena, &c->ops, &c->text, &c->text_scratch, &c->cig_off, &c->cig_len, &c->gring})
     b->release();
   if (c->h_counters) hipHostFree(c->h_counters);
   for (hipEvent_t ev : {c->ev_start, c->ev_pack, c->ev_a0, c->ev_a1, c->ev_t0, c->ev_t1, c->ev_end})
@@ -636,6 +636,14 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       tp.arena = ap.arena; tp.arena_bytes = (unsigned long long)c->arena.cap; tp.bt_final_row = ap.bt_final_row;
       tp.ops = static_cast<uint8_t*>(c->ops.p); tp.ops_cap = c->ops.cap; tp.ops_top = ct + CT_OPS;
       tp.text = static_cast<char*>(c->text.p); tp.text_cap = c->text.cap; tp.text_top = ct + CT_TEXT;
+      tp.min_op_cost = std::min(pen.x, pen.e);
+      // lane-per-alignment emit with whole sequences staged: one replay into a scratch + compaction (big passes only: the
+      // scratch holds the upper bounds, ~3x the text)
+      if (!tp.wave_kernel && tp.seq_lds_stride > 0 && n_pass >= 8192u && !getenv("WFAGPU_EMIT_TWO_PASS")) {
+        if (c->text_scratch.ensure(c->h_counters[CT_SUM_TEXT] + 4096, st)) return -1;
+        if (zero_counter(c, CT_SCRATCH)) return -1;
+        tp.text_scratch = static_cast<char*>(c->text_scratch.p); tp.text_scratch_cap = c->text_scratch.cap; tp.scratch_top = ct + CT_SCRATCH;
+      }
       tp.cigar_off = static_cast<unsigned long long*>(c->cig_off.p);
       tp.cigar_len = static_cast<uint32_t*>(c->cig_len.p);
       HIP_TRY(hipEventRecord(c->ev_t0, st));

@@ -344,7 +344,11 @@ bool plan_tier(const wfagpu_amd_ctx* c, WfaAlignParams& p, int max_score, unsign
     // adaptive band: the ring rows hold band_width diagonals whatever the score
     p.rs = (p.band_width + 2 + 1) & ~1;
     // (the single-wavefront kernels keep the row book in VGPR lanes: at most 64 ring rows)
-    const int t = (p.band_width <= 256 && p.dm <= 64) ? 0 : (p.band_width <= 1024 ? 1 : 2);
+    // One wavefront per alignment up to 512 diagonals (beta 352: 26.8 -> 18.4 ms per 16k 10 kbp pairs, 512: 26.4 -> 24.8,
+    // 1024: 33 -> 55, so not beyond): the banded kernels spend most of their
+    // instructions on per-score scalar bookkeeping, which every wave of a workgroup repeats.  WFAGPU_BAND_TIER0_MAX: A/B.
+    static const int t0_max = getenv("WFAGPU_BAND_TIER0_MAX") ? atoi(getenv("WFAGPU_BAND_TIER0_MAX")) : 512;
+    const int t = (p.band_width <= t0_max && p.dm <= 64) ? 0 : (p.band_width <= 1024 ? 1 : 2);
     const size_t lds = wfa_align_lds_bytes(p, t);
     if (lds > c->lds_per_block_max || max_seq_len > 32766u || max_score > 30000) return false;
     const int nb = wfa_align_max_blocks_per_cu(t, bt, false, true, lds);

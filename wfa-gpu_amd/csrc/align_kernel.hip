@@ -20,12 +20,20 @@
 //   * The wavefront ring -- max(x,o+e)+1 rows of M, e+1 rows of I and of D, 16-bit offsets -- and
 //     both 2-bit packed sequences live in LDS.  Only the diagonals an alignment within the score
 //     budget can visit are kept (see "window" below), which halves the ring against the
-//     reference's |k| <= max_error sizing.
+//     reference's |k| <= max_error sizing.  Wider wavefronts: the hybrid tier keeps the M and I rings in LDS
+//     and the D ring in HBM; the last resort keeps the whole ring (16- or 32-bit) in HBM/L2.
 //   * Ring invariant: a row holds NULL everywhere outside the limits it was last written with (set up
 //     once per alignment, kept by clearing what a slot's previous occupant had beyond the new limits),
 //     so the five reads per cell need no range predicate, and lanes past the end of a row recompute its
-//     last cell, so no store needs an exec mask: the per-cell code is straight-line, the only inner
-//     loop (extend) is wave-uniform.  Validity ballots happen once per score, not per chunk.
+//     last cell, so no store needs an exec mask: the per-cell code is straight-line.
+//   * Two score loops.  The CAREFUL one is WFA2 to the letter (limits from the trimmed limits of the input
+//     rows, "no wavefront" scores, trimming of values past a sequence end, termination read per score).  The
+//     LEAN one runs until an M cell first touches a sequence end -- before that no value can run past an
+//     end, nothing is trimmed and no cell can be the last one -- with limits from the previous score(s)
+//     alone, constant-size ring clearing, tie-breaks from one signed max over (offset << 16 | origin bits),
+//     an extend without exec mask whose first 16-base step is straight-line code, and a row table buffered
+//     in VGPR lanes.  Instruction issue (vector pipe 100 % busy on the headline workload) is what this
+//     kernel is bound by; the lean loop exists to issue fewer instructions per cell and per score.
 //   * NW == 1: no barrier anywhere in the score loop (LDS operations of one wavefront execute in
 //     order) and the per-score bookkeeping lives in three VGPRs indexed by lane (v_readlane), not in
 //     memory; the kernel is compiled for 8 waves per SIMD.  NW > 1: one barrier per score.
@@ -34,7 +42,6 @@
 //   * For CIGARs each cell emits ONE origin byte (64 consecutive bytes per wavefront store) into a
 //     bump-allocated arena; a per-alignment row table (8 bytes per score) locates the rows.  No
 //     O(max_error^2) per-alignment reservation and nothing to memset between alignments.
-//   * A last-resort instantiation keeps a 32-bit ring in HBM/L2 for wavefronts too wide for LDS.
 #include <type_traits>
 
 #include "wfa_device.h"

@@ -8,15 +8,18 @@
 // The output string is what WFA2's cigar_sprint(print_matches=true) prints
 // (external/WFA/alignment/cigar.c:394-426): run-length "nM nX nI nD" items.
 //
-// One lane per alignment.  Phase 1 walks the origin bytes written by the
-// align kernel backwards (the alignment's row table locates the rows of
-// scores s-x / s-o-e / s-e) and pushes one byte per edit operation.  Phase 2 replays the operations
-// forwards, re-deriving every match run as a longest-common-prefix on the
-// packed sequences -- identical to the extension the forward pass did, so no
-// offsets had to be stored -- first to size the text, then to write it.
-// Scratch and text space come from wave-aggregated bump allocations (one
-// atomic per wavefront), so the text arena is dense and can be copied to the
-// host in one piece.
+// Two mappings, chosen by the host driver per pass:
+//   * short alignments (64 pairs of packed sequences fit a wavefront's share of LDS): ONE LANE per alignment.
+//     wfa_walk_kernel follows the origin bytes written by the align kernel backwards (the alignment's row table
+//     locates the rows of scores s-x / s-o-e / s-e) and pushes one byte per edit operation; wfa_emit_kernel replays the
+//     operations forwards, re-deriving every match run as a longest-common-prefix on the packed sequences -- identical
+//     to the extension the forward pass did, so no offsets had to be stored -- into an upper-bound slot of a scratch
+//     (big passes; wfa_text_compact_kernel then packs the texts densely) or, for small passes, twice: once to size the
+//     text, once to write it;
+//   * long alignments: ONE WAVEFRONT per alignment (wfa_trace_wave_kernel): sequences of the pair, op list and text in
+//     LDS, origin bytes fetched as tiles by all 64 lanes.
+// Scratch and text space come from wave-aggregated bump allocations (one atomic per wavefront), so the text arena is
+// dense and can be copied to the host in one piece.
 #include <cstdlib>
 
 #include "wfa_device.h"
@@ -224,12 +227,8 @@ __global__ void __launch_bounds__(TRACE_THREADS) wfa_walk_kernel(const WfaTraceP
   }
 }
 
-// Phase 2 kernel: forward replay, once to size the text and once to write it.
-// SEQ_LDS: the 64 pairs of a block are first copied into LDS (coalesced, one pair at a time by
-// the whole wavefront), so the many small reads of the replay never leave the CU.  Without it
-// every 4-byte read of a packed sequence misses L1 and L2 (the working set of all resident lanes
-// is far larger than both) and the kernel is HBM-transaction bound (57 GB fetched per 1M pairs).
-// Window mode (the default): every lane keeps 8 words of each sequence in LDS (SeqWindow), 4.3 KB per wavefront.
+// Forward replay with 8-word LDS windows (SeqWindow): used when whole sequences do not fit and the wave-per-alignment
+// kernel is switched off (WFAGPU_NO_WAVE_TRACE), or for A/B runs (WFAGPU_EMIT_WINDOW); two replays.
 __global__ void __launch_bounds__(TRACE_THREADS) wfa_emit_win_kernel(const WfaTraceParams p) {
   __shared__ uint32_t win_lds[64 * (2 * SeqWindow::WORDS + 1)];
   const uint32_t gid = blockIdx.x * TRACE_THREADS + threadIdx.x;
@@ -283,8 +282,13 @@ __global__ void __launch_bounds__(TRACE_THREADS) wfa_emit_win_kernel(const WfaTr
   }
 }
 
+// Forward replay, the default for short alignments: the 64 pairs of a block are first copied into LDS (coalesced, one
+// pair at a time by the whole wavefront), so the many small reads of the replay never leave the CU.  (Reading the packed
+// sequences straight from global memory made every 4-byte read miss L1 and L2 -- the working set of all resident lanes
+// is far larger than both: 57 GB fetched per 1M pairs in round 1.)
 template <bool SEQ_LDS>
 __global__ void __launch_bounds__(TRACE_THREADS) wfa_emit_kernel(const WfaTraceParams p) {
+  static_assert(SEQ_LDS, "sequences that do not fit LDS go through wfa_emit_win_kernel or wfa_trace_wave_kernel");
   extern __shared__ __attribute__((aligned(16))) uint32_t seq_lds[];
   const uint32_t gid = blockIdx.x * TRACE_THREADS + threadIdx.x;
   const int lane = threadIdx.x & 63;
@@ -570,12 +574,8 @@ void wfa_launch_trace(const WfaTraceParams& p, hipStream_t stream) {
     hipLaunchKernelGGL(wfa_emit_win_kernel, dim3(grid), dim3(TRACE_THREADS), 0, stream, p);
     return;
   }
-  if (p.seq_lds_stride > 0) {
-    const size_t lds = (size_t)64 * p.seq_lds_stride * 4;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wfa_emit_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(wfa_emit_kernel<true>, dim3(grid), dim3(TRACE_THREADS), lds, stream, p);
-    if (p.text_scratch) hipLaunchKernelGGL(wfa_text_compact_kernel, dim3(grid), dim3(TRACE_THREADS), 0, stream, p);
-  } else {
-    hipLaunchKernelGGL(wfa_emit_kernel<false>, dim3(grid), dim3(TRACE_THREADS), 0, stream, p);
-  }
+  const size_t lds = (size_t)64 * p.seq_lds_stride * 4;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wfa_emit_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(wfa_emit_kernel<true>, dim3(grid), dim3(TRACE_THREADS), lds, stream, p);
+  if (p.text_scratch) hipLaunchKernelGGL(wfa_text_compact_kernel, dim3(grid), dim3(TRACE_THREADS), 0, stream, p);
 }

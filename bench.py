@@ -323,7 +323,10 @@ def main():
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {wl['desc']}", "pairs_per_gpu_per_step": n_pairs, "length": wl["length"],
                        "error": wl["error"], "penalties": "x=2,o=3,e=1", "max_error": max_error,
-                       "compute_cigar": wl["cigar"], "band": {"period": band[0], "width": band[1]} if band else None,
+                       "compute_cigar": wl["cigar"],
+                       "band": {"period": band[0], "width": band[1], "forced": bool(os.environ.get("WFAGPU_FORCE_BAND")),
+                                "policy": "the band is used only where the sampled score budgets leave the exact wavefronts wider "
+                                          "than 2.5 bands (tiers.pairs_banded counts the pairs it finished)"} if band else None,
                        "sharding": f"batch-sharded x{world}, no collective", "mode": "ranks"},
             "gcups": round(gcups, 2),
             "stage_ms_per_step": {"pack": round(acc["pack_ms"] / steps, 3), "align": round(acc["align_ms"] / steps, 3),

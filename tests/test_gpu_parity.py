@@ -567,3 +567,31 @@ def test_penalty_sets_at_scale(aligner, pen, max_error):
     assert c == co
     s2, _ = aligner.align(batch, pen, max_error=max_error, compute_cigar=False)
     assert np.array_equal(s2, so)
+
+
+def test_band_is_only_used_where_it_pays(monkeypatch):
+    """-B on a big batch: the sample that tunes the score budgets runs exactly; when the budgets leave the exact wavefronts
+    no wider than 2.5 bands the exact kernels are at least as fast as the band and are used instead (optimal results, no
+    pair counted as banded); WFAGPU_FORCE_BAND=1 keeps the band.  Both ways: valid alignments, cost == score >= optimum."""
+    buf, meta = wfagpu.generate_pairs(9000, 1500, 0.04, seed=401)
+    so, co, _ = oracle_lib.oracle_batch(buf, meta, (2, 3, 1), cigar=True, nthreads=16)
+    pairs = wfagpu.pairs_from_layout(buf, meta)
+    for force in (False, True):
+        if force:
+            monkeypatch.setenv("WFAGPU_FORCE_BAND", "1")
+        al = wfagpu.DeviceAligner(0)
+        try:
+            batch = al.upload(buf, meta)
+            s, c = al.align(batch, (2, 3, 1), max_error=450, compute_cigar=True, band=25, band_width=128)
+            st = al.stats()
+            if force:
+                assert st.pairs_banded > 8000
+                assert (s >= so).all()
+                for i in range(0, len(pairs), 9):
+                    ok, cost = oracle_lib.check_cigar(pairs[i][0], pairs[i][1], c[i], (2, 3, 1))
+                    assert ok and cost == s[i]
+            else:
+                assert st.pairs_banded == 0 and st.auto_budget > 0
+                assert np.array_equal(s, so) and c == co
+        finally:
+            al.close()

@@ -519,7 +519,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   // yet).  The caller picks them so that neither is a list it still needs (the sampled run of the auto-budget step
   // must not touch the bucket's own list).
   auto run_list = [&](uint32_t* pending, uint32_t n_pending, const bool raw, const int32_t* budgets, const int budget_cap,
-                      uint32_t* alt0, uint32_t* alt1) -> int {
+                      uint32_t* alt0, uint32_t* alt1, const bool allow_band = true) -> int {
   grid_cap = UINT32_MAX;
   if (budgets) {
     // tight budgets make the wavefront a diamond: at most half the budget square of origin bytes
@@ -546,7 +546,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       TierPlan tp;
       ap.budget = budget_round ? budgets : nullptr;
       // banded first attempt (packed class only); whatever it cannot finish goes to the exact tiers
-      ap.band_width = (want_band && !raw && round == 0 && !budgets) ? band_width : 0;
+      ap.band_width = (want_band && allow_band && !raw && round == 0 && !budgets) ? band_width : 0;
       ap.band_period = band;
       if (ap.band_width > 0 && !plan_tier(c, ap, std::min(max_score, 30000), max_len, compute_cigar, raw, &tp)) ap.band_width = 0;
       if (ap.band_width > 0) c->stats.pairs_banded += n_cur;
@@ -748,7 +748,12 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       // diamond).
       const int32_t* budgets = nullptr;
       int budget_cap = max_error;
-      const bool try_budget = !raw && !want_band && n_pending >= 8192 && !getenv("WFAGPU_NO_AUTOBUDGET") &&
+      // With a band requested the sample still runs (exactly): if the budgets it yields make the exact wavefronts no
+      // wider than 2.5 bands, the exact search is at least as fast as the band (16k x 10 kbp @ 3 %, window 1017: 20.3 ms
+      // exact against 24.8 ms with beta 512 and 18.8 ms with beta 352) and the band -- a permission to approximate, not an obligation -- is not used
+      // for this bucket; WFAGPU_FORCE_BAND=1 keeps it.
+      const bool band_optional = want_band && !getenv("WFAGPU_FORCE_BAND");
+      const bool try_budget = !raw && (!want_band || band_optional) && n_pending >= 8192 && !getenv("WFAGPU_NO_AUTOBUDGET") &&
                               window_width(max_error, pen.o, pen.e, max_len) > 128;
       int saved_idx = -1;
       if (try_budget && c->same_stream) {
@@ -776,7 +781,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         LAUNCH_K(k_sample, dim3(cdiv(n_s, 256)), dim3(256), 0, st, (const uint32_t*)pending, n_s, stride_s, static_cast<uint32_t*>(c->sample.p));
         // (leftovers of the sampled run ping-pong between list_d and list_e; list_c keeps the bucket)
         if (run_list(static_cast<uint32_t*>(c->sample.p), n_s, raw, nullptr, max_error, static_cast<uint32_t*>(c->list_d.p),
-                     static_cast<uint32_t*>(c->list_e.p))) return -1;
+                     static_cast<uint32_t*>(c->list_e.p), /*allow_band=*/false)) return -1;
         LAUNCH_K(k_ratio, dim3(cdiv(n_s, 256)), dim3(256), 0, st, static_cast<const uint32_t*>(c->sample.p), n_s,
                            static_cast<const uint32_t*>(c->status.p), (const int32_t*)d_scores, ap.meta, static_cast<int32_t*>(c->ratio.p));
         std::vector<int32_t> hr(n_s);
@@ -805,6 +810,10 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         if (read_counters(c)) return -1;
         n_pending = (uint32_t)c->h_counters[CT_LIST];
         HIP_TRY(hipMemcpyAsync(pending, rest, (size_t)4 * n_pending, hipMemcpyDeviceToDevice, st));
+      }
+      if (want_band && budgets && 2 * window_width(budget_cap, pen.o, pen.e, max_len) > 5 * band_width) {
+        budgets = nullptr; budget_cap = max_error;       // wide wavefronts: the band is worth having
+        c->stats.auto_budget = 0;
       }
       const unsigned missed_before = c->stats.pairs_budget_missed;
       if (n_pending && run_list(pending, n_pending, raw, budgets, budget_cap, static_cast<uint32_t*>(c->list_d.p), pending)) return -1;

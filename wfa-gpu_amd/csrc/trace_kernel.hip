@@ -174,6 +174,11 @@ constexpr int TRACE_THREADS = 64;
 // chain of dependent HBM reads, so it wants every wave slot of the CU.  Leaves the op list of
 // each pair in the scratch arena (ops_off/nops per pair).
 __global__ void __launch_bounds__(TRACE_THREADS) wfa_walk_kernel(const WfaTraceParams p) {
+  // The walk is bound by memory TRANSACTIONS (one dependent 64-byte access per step, half a million lanes in flight: no
+  // line survives in L2 until its next use), not by bytes.  Per operation it needs a row-table entry, an origin byte and
+  // an op store; two of the three are batched: row-table entries are fetched 8 at a time (one 64-byte line) into this
+  // lane's LDS slot, ops are collected four to a register and stored as one word.
+  __shared__ uint2 tab_cache[TRACE_THREADS][9];          // [lane][entry & 7] (9: bank spread)
   const uint32_t gid = blockIdx.x * TRACE_THREADS + threadIdx.x;
   const int lane = threadIdx.x & 63;
   bool active = gid < p.n_work;
@@ -189,41 +194,62 @@ __global__ void __launch_bounds__(TRACE_THREADS) wfa_walk_kernel(const WfaTraceP
   const uint32_t need_ops = active ? (((uint32_t)score + 3u) & ~3u) : 0u;
   const unsigned long long ops_off = wave_alloc(p.ops_top, need_ops, lane);
   bool fail = active && (ops_off + need_ops > p.ops_cap);
-  uint8_t* q_end = p.ops + ops_off + need_ops;
-  uint8_t* q = q_end;
+  uint8_t* const q_begin = p.ops + ops_off;
+  uint8_t* const q_end = q_begin + need_ops;       // (4-byte aligned: the allocations are multiples of 4)
+  uint32_t nops = 0, word = 0;
   if (active && !fail) {
     // row table of the pair: [score] = {arena unit of the origin bytes, lo}
     const uint2* tab = reinterpret_cast<const uint2*>(p.arena + (size_t)p.bt_final_row[pair] * 16);
     int k = tlen - plen, s = score;
     int state = 0;  // 0: M, 1: I, 2: D
+    int cached = -1;
     while (s > 0) {
-      if (q == p.ops + ops_off) { fail = true; break; }
-      const uint2 row = tab[s];
+      if (nops >= need_ops) { fail = true; break; }
+      if ((s >> 3) != cached) {
+        cached = s >> 3;
+        const uint4* src = reinterpret_cast<const uint4*>(tab + (cached << 3));
+        const uint4 a = src[0], b = src[1], c2 = src[2], d = src[3];
+        tab_cache[lane][0] = make_uint2(a.x, a.y); tab_cache[lane][1] = make_uint2(a.z, a.w);
+        tab_cache[lane][2] = make_uint2(b.x, b.y); tab_cache[lane][3] = make_uint2(b.z, b.w);
+        tab_cache[lane][4] = make_uint2(c2.x, c2.y); tab_cache[lane][5] = make_uint2(c2.z, c2.w);
+        tab_cache[lane][6] = make_uint2(d.x, d.y); tab_cache[lane][7] = make_uint2(d.z, d.w);
+      }
+      const uint2 row = tab_cache[lane][s & 7];
       const uint32_t code = p.arena[(size_t)row.x * 16 + (uint32_t)(k - (int)row.y)];
+      uint32_t op;
       if (state == 0) {
         const uint32_t org = code & BT_M_MASK;
-        if (org == BT_M_X) { *--q = OP_X | OP_EXT_AFTER; s -= p.x; }
+        if (org == BT_M_X) { op = OP_X | OP_EXT_AFTER; s -= p.x; }
         else if (org == BT_M_I) {
-          *--q = OP_I | OP_EXT_AFTER; --k;
+          op = OP_I | OP_EXT_AFTER; --k;
           if (code & BT_I_EXT) { s -= p.e; state = 1; } else { s -= p.oe; }
         } else if (org == BT_M_D) {
-          *--q = OP_D | OP_EXT_AFTER; ++k;
+          op = OP_D | OP_EXT_AFTER; ++k;
           if (code & BT_D_EXT) { s -= p.e; state = 2; } else { s -= p.oe; }
         } else { fail = true; break; }
       } else if (state == 1) {
-        *--q = OP_I; --k;
+        op = OP_I; --k;
         if (code & BT_I_EXT) { s -= p.e; } else { s -= p.oe; state = 0; }
       } else {
-        *--q = OP_D; ++k;
+        op = OP_D; ++k;
         if (code & BT_D_EXT) { s -= p.e; } else { s -= p.oe; state = 0; }
       }
+      // the list grows downwards from q_end: op number n (0 = last operation of the alignment) is byte q_end[-1-n]
+      word = (word << 8) | op;
+      ++nops;
+      if ((nops & 3u) == 0u) reinterpret_cast<uint32_t*>(q_end)[-(int)(nops >> 2)] = word;
     }
     if (s != 0 || state != 0 || k != 0) fail = true;
+    if (!fail && (nops & 3u)) {
+      // the last, partial word: its ops are the first operations of the alignment
+      uint8_t* qq = q_end - (nops & ~3u);
+      for (int r = (int)(nops & 3u) - 1; r >= 0; --r) *--qq = (uint8_t)(word >> (8 * r));     // (oldest of them first: highest address)
+    }
   }
   if (active) {
-    // the op list now sits at [q, q_end); cigar_off/cigar_len carry it to the emit kernel
-    p.cigar_off[pair] = (unsigned long long)(q - p.ops);
-    p.cigar_len[pair] = fail ? 0xFFFFFFFFu : (uint32_t)(q_end - q);
+    // the op list now sits at [q_end - nops, q_end); cigar_off/cigar_len carry it to the emit kernel
+    p.cigar_off[pair] = (unsigned long long)(q_end - nops - p.ops);
+    p.cigar_len[pair] = fail ? 0xFFFFFFFFu : nops;
   }
 }
 

@@ -497,7 +497,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
     want = std::min<size_t>(want, ((size_t)1 << 36) - 4096);
     if (c->arena.cap < want && c->arena.ensure(want, st)) return -1;
     ap.arena = static_cast<uint8_t*>(c->arena.p);
-    ap.arena_units = c->arena.cap / 16;
+    ap.arena_units = c->arena.cap / 16 - 8;      // (128 bytes of slack: the walk reads row-table entries a line at a time)
   }
 
   HIP_TRY(hipMemsetAsync(c->status.p, 0, (size_t)4 * n, st));
@@ -687,7 +687,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       if (can_grow) {
         if (c->arena.ensure(grown, st)) return -1;
         ap.arena = static_cast<uint8_t*>(c->arena.p);
-        ap.arena_units = c->arena.cap / 16;
+        ap.arena_units = c->arena.cap / 16 - 8;      // (128 bytes of slack: the walk reads row-table entries a line at a time)
       }
       if (n_nomem == n_pass && !can_grow) {
         if (grid_cap == 1) {

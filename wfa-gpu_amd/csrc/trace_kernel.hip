@@ -577,10 +577,163 @@ __global__ void __launch_bounds__(TRACE_THREADS) wfa_trace_wave_kernel(const Wfa
   }
 }
 
+
+// ---- alignments a little too long for the lane-per-alignment kernels: G alignments per wavefront -------------------
+// One wavefront per alignment issues its walk and replay instructions for ONE alignment; with a hundred operations per
+// alignment and hundreds of thousands of alignments (2 kbp reads) that is mostly launch and staging overhead per wave.  Here the 64 lanes form G groups of L = 64/G lanes, each group with its own alignment and its
+// own share of LDS (sequences, tile of L rows x 16 origin bytes, op list, text): the L lanes of a group stage, fetch
+// tiles and copy the text out together; the walk and the replay run on the group's first lane -- G of them per wave
+// instruction.  Groups progress independently (divergent loops), everything a group shares goes through its LDS share.
+template <bool RAW, int G>
+__global__ void __launch_bounds__(TRACE_THREADS) wfa_trace_group_kernel(const WfaTraceParams p) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t glds[];
+  constexpr int L = 64 / G, TILE_W = 16, TILE_H = L;       // one row per lane of the group (short alignments: taller tiles cost more than they save)
+  const int lane = threadIdx.x & 63, grp = lane / L, sub = lane % L, lead = grp * L;
+  const size_t share_words = ((size_t)2 * p.seq_words_cap * 4 + (size_t)TILE_H * TILE_W + (size_t)p.ops_lds_bytes + (size_t)p.text_lds_bytes + 15) / 16 * 4;
+  uint32_t* Pw = glds + (size_t)grp * share_words;
+  uint32_t* Tw = Pw + p.seq_words_cap;
+  uint8_t* tile = reinterpret_cast<uint8_t*>(Tw + p.seq_words_cap);       // [L rows][16 bytes]
+  uint8_t* ops_lds = tile + TILE_H * TILE_W;
+  char* text_lds = reinterpret_cast<char*>(ops_lds + p.ops_lds_bytes);
+  for (uint32_t base = blockIdx.x * G; base < p.n_work; base += gridDim.x * G) {
+    const uint32_t w = base + grp;
+    bool active = w < p.n_work;
+    uint32_t pair = 0;
+    if (active) pair = p.work ? p.work[w] : w;
+    if (active && p.status[pair] != WFA_ST_DONE) active = false;
+    int plen = 0, tlen = 0, score = 0, pwords = 0, twords = 0;
+    if (active) {
+      const WfaSeqPair mp = p.meta[pair];
+      plen = (int)mp.pattern_len; tlen = (int)mp.text_len; score = p.score[pair];
+      const int sh = RAW ? 2 : 4;
+      pwords = ((plen + (1 << sh) - 1) >> sh) + 1; twords = ((tlen + (1 << sh) - 1) >> sh) + 1;
+      const uint32_t* gp = p.packed + ((RAW ? mp.pattern_offset : mp.pattern_offset_packed) >> 2);
+      const uint32_t* gt = p.packed + ((RAW ? mp.text_offset : mp.text_offset_packed) >> 2);
+      for (int i = sub; i < pwords; i += L) Pw[i] = gp[i];
+      for (int i = sub; i < twords; i += L) Tw[i] = gt[i];
+    }
+    const uint32_t need_ops = active ? (((uint32_t)score + 3u) & ~3u) : 0u;
+    bool fail = false;
+    uint8_t* q_begin = ops_lds;
+    if (need_ops > (uint32_t)p.ops_lds_bytes) {
+      unsigned long long ops_off = 0;
+      if (sub == 0) ops_off = atomicAdd(p.ops_top, (unsigned long long)need_ops);
+      ops_off = shfl64(ops_off, lead);
+      fail = ops_off + need_ops > p.ops_cap;
+      q_begin = p.ops + ops_off;
+    }
+    uint8_t* const q_end = q_begin + need_ops;
+    uint8_t* q = q_end;
+    if (active && !fail) {
+      const uint2* tab = reinterpret_cast<const uint2*>(p.arena + (size_t)p.bt_final_row[pair] * 16);
+      int k = tlen - plen, s = score, state = 0;       // state 0: M, 1: I, 2: D
+      int s_top = -1, kbase = 0;
+      while (s > 0) {
+        if (s > s_top || s_top - s >= TILE_H || (unsigned)(k - kbase) >= (unsigned)TILE_W) {
+          // new tile for this group: scores s .. s-L+1, diagonals k-8 .. k+7 (lane `sub` fetches row s - sub)
+          s_top = s; kbase = k - TILE_W / 2;
+          const int sr = s - sub;
+          uint4 v = make_uint4(0, 0, 0, 0);
+          if (sr >= 0) {
+            const uint2 row = tab[sr];
+            const long long off = (long long)row.x * 16 + ((long long)kbase - (int)row.y);
+            if (off >= 0 && (unsigned long long)off + 16 <= p.arena_bytes) {
+              struct __attribute__((packed, aligned(1))) U16 { uint32_t w[4]; };
+              const U16 t = *reinterpret_cast<const U16*>(p.arena + off);
+              v = make_uint4(t.w[0], t.w[1], t.w[2], t.w[3]);
+            }
+          }
+          reinterpret_cast<uint4*>(tile)[sub] = v;
+          __builtin_amdgcn_wave_barrier();
+        }
+        if (q == q_begin) { fail = true; break; }
+        const uint32_t code = tile[(s_top - s) * TILE_W + (k - kbase)];
+        uint8_t op;
+        if (state == 0) {
+          const uint32_t org = code & BT_M_MASK;
+          if (org == BT_M_X) { op = OP_X | OP_EXT_AFTER; s -= p.x; }
+          else if (org == BT_M_I) {
+            op = OP_I | OP_EXT_AFTER; --k;
+            if (code & BT_I_EXT) { s -= p.e; state = 1; } else { s -= p.oe; }
+          } else if (org == BT_M_D) {
+            op = OP_D | OP_EXT_AFTER; ++k;
+            if (code & BT_D_EXT) { s -= p.e; state = 2; } else { s -= p.oe; }
+          } else { fail = true; break; }
+        } else if (state == 1) {
+          op = OP_I; --k;
+          if (code & BT_I_EXT) { s -= p.e; } else { s -= p.oe; state = 0; }
+        } else {
+          op = OP_D; ++k;
+          if (code & BT_D_EXT) { s -= p.e; } else { s -= p.oe; state = 0; }
+        }
+        --q;
+        if (sub == 0) *q = op;
+      }
+      if (s != 0 || state != 0 || k != 0) fail = true;
+    }
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t nops = (uint32_t)(q_end - q);
+    // replay on the group's first lane: once into the LDS text buffer (longer texts: a second time into the arena)
+    uint32_t len = 0;
+    int cost = 0;
+    if (active && !fail && sub == 0) {
+      len = replay<RAW>(q, nops, Pw, Tw, plen, tlen, text_lds, p.x, p.oe - p.e, p.e, &cost, (uint32_t)p.text_lds_bytes);
+    }
+    len = __shfl(len, lead);
+    if (active && !fail && len == 0xFFFFFFFFu) fail = true;
+    unsigned long long txt_off = 0;
+    if (active && !fail && sub == 0) txt_off = atomicAdd(p.text_top, (unsigned long long)len + 1ull);
+    txt_off = shfl64(txt_off, lead);
+    if (active && !fail && txt_off + len + 1 > p.text_cap) fail = true;
+    if (active && !fail) {
+      if (len + 1u <= (uint32_t)p.text_lds_bytes) {
+        __builtin_amdgcn_wave_barrier();
+        char* dst = p.text + txt_off;
+        for (uint32_t i = sub; i <= len; i += L) dst[i] = text_lds[i];
+      } else if (sub == 0) {
+        replay<RAW>(q, nops, Pw, Tw, plen, tlen, p.text + txt_off, p.x, p.oe - p.e, p.e, &cost);
+      }
+    }
+    if (active && sub == 0) {
+      if (!fail) {
+        p.cigar_off[pair] = txt_off;
+        p.cigar_len[pair] = len;
+        if (cost != score) {
+          if (p.score_fix) p.score_fix[pair] = cost;
+          else p.cigar_len[pair] = 0xFFFFFFFFu;
+        }
+      } else {
+        p.cigar_off[pair] = 0;
+        p.cigar_len[pair] = 0xFFFFFFFFu;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();      // (the next alignments overwrite the staged sequences)
+  }
+}
+
+template <bool RAW, int G>
+void launch_group(const WfaTraceParams& p, hipStream_t stream) {
+  const size_t share = ((size_t)2 * p.seq_words_cap * 4 + (size_t)(64 / G) * 16 + (size_t)p.ops_lds_bytes + (size_t)p.text_lds_bytes + 15) / 16 * 16;
+  const size_t lds = share * G;
+  const uint32_t blocks = (p.n_work + G - 1) / G;
+  const uint32_t grid = blocks < 8192u ? blocks : 8192u;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wfa_trace_group_kernel<RAW, G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((wfa_trace_group_kernel<RAW, G>), dim3(grid), dim3(TRACE_THREADS), lds, stream, p);
+}
+
 }  // namespace
 
 void wfa_launch_trace(const WfaTraceParams& p, hipStream_t stream) {
   if (p.n_work == 0) return;
+  if (p.wave_kernel && p.group > 1) {
+    switch (p.group) {
+      case 8: if (p.raw) launch_group<true, 8>(p, stream); else launch_group<false, 8>(p, stream); break;
+      case 4: if (p.raw) launch_group<true, 4>(p, stream); else launch_group<false, 4>(p, stream); break;
+      default: if (p.raw) launch_group<true, 2>(p, stream); else launch_group<false, 2>(p, stream); break;
+    }
+    return;
+  }
   if (p.wave_kernel) {
     const size_t lds = (size_t)2 * p.seq_words_cap * 4 + 64 * 16 + (size_t)p.ops_lds_bytes + (size_t)p.text_lds_bytes;
     const uint32_t grid = p.n_work < 8192u ? p.n_work : 8192u;

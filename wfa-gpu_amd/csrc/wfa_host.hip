@@ -637,6 +637,14 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
           tp.ops_lds_bytes = (int)(((smax + 3) & ~(size_t)3) <= room ? ((smax + 15) & ~(size_t)15) : 0);
           room -= (size_t)tp.ops_lds_bytes;
           tp.text_lds_bytes = (int)(std::min<size_t>(room, 2 * smax + 64) & ~(size_t)15);
+          // Several alignments per wavefront (64/G lanes and one LDS share each) for SHORT op lists only (2 kbp reads, G = 8:
+          // 262k pairs 13.2 -> 6.6 ms).  With hundreds of operations per alignment the replays of the groups diverge and
+          // the wavefront per alignment wins again (16k x 10 kbp: 2.7 ms against 4.0 ms with G = 4).
+          const size_t share = seq_b - 1024 + (size_t)tp.ops_lds_bytes + (size_t)tp.text_lds_bytes;
+          tp.group = 1;
+          if (!getenv("WFAGPU_NO_GROUP_TRACE") && tp.ops_lds_bytes > 0 && smax <= 512)
+            for (int g = 8; g >= 2; g >>= 1)
+              if ((share + (size_t)(64 / g) * 16 + 16) * g <= (40u << 10) && n_pass >= (uint32_t)g * 1024u) { tp.group = g; break; }
         }
       }
       tp.packed = ap.packed; tp.meta = ap.meta; tp.work = pending; tp.n_work = n_pass;

@@ -160,6 +160,7 @@ wfa_align_kernel(const WfaAlignParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int dm = p.dm, de = p.de, rs = p.rs;
+  constexpr int ROW_PAD = (!GLOBAL_RING && !BANDED && sizeof(OffT) == 2) ? WFA_RING_ROW_PAD : 0;     // (see wfa_device.h)
   const int x = p.x, oe = p.oe, e = p.e;
 
   // ---- carve LDS -----------------------------------------------------------------------------
@@ -255,7 +256,7 @@ wfa_align_kernel(const WfaAlignParams p) {
 
     if (!feasible) {
       status = WFA_ST_SCORE;
-    } else if ((!BANDED && whi - wlo + 1 + 2 * dm > rs) || pwords > p.seq_words_cap || twords > p.seq_words_cap) {
+    } else if ((!BANDED && whi - wlo + 1 + 2 * dm + ROW_PAD > rs) || pwords > p.seq_words_cap || twords > p.seq_words_cap) {
       status = WFA_ST_BAND;
     } else {
       // ---- stage the sequences, reset the ring ---------------------------------------------
@@ -359,9 +360,9 @@ wfa_align_kernel(const WfaAlignParams p) {
       // arena chunk, refilled with one atomic when it runs dry.  false: arena exhausted.
       auto alloc_row = [&](int width) -> bool {
         const uint32_t need = ((uint32_t)width + 15u) >> 4;
-        if (need > chunk_left) {
+        if (need + WFA_ARENA_ROW_SLACK > chunk_left) {
           ColdParams cp = cold_params();
-          const uint32_t grab = max(need, cp->chunk_units);
+          const uint32_t grab = max(need + WFA_ARENA_ROW_SLACK, cp->chunk_units);
           uint32_t base = WFA_ROW_NONE;
           if (tid == 0) {
             const unsigned long long b = atomicAdd(cp->arena_top, (unsigned long long)grab);
@@ -409,35 +410,123 @@ wfa_align_kernel(const WfaAlignParams p) {
                                 const OffT* rb_ie, const OffT* rb_de, OffT* wb_m, OffT* wb_i, OffT* wb_d, const BandCtx& bc,
                                 bool& my_over, unsigned long long& wave_touch) {
         constexpr bool LEAN = decltype(lean_tag)::value;
-        for (int k0 = lo; k0 <= hi; k0 += NT) {
-          const int k = min(k0 + tid, hi);
-          // recurrences (wavefront_compute_affine.c:66-84)
-          constexpr bool TAGGED = LEAN && !GLOBAL_RING && !BANDED && sizeof(OffT) == 2;     // (also the hybrid ring: its D row is read through a global pointer)
-          int ins, del, mv0;
-          uint32_t code = 0;
-          int ins_hi = 0, del_hi = 0;           // TAGGED: values whose high halves are stored
-          if constexpr (TAGGED) {
-            // Offsets go to the high halves, the role of each value (its origin bits, see wfa_device.h) to the low
-            // halves -- one v_lshl_add/v_lshl_or per value, which also carries the "+1" of the insertion and
-            // mismatch candidates.  A signed max then picks the larger offset and, on equal offsets, the source WFA2
-            // prefers (extension over open; mismatch, then deletion, then insertion), and the origin byte is two
-            // bit-field inserts of the winners' low bits.  (The MI355X runs with SRAM ECC on, where d16_hi loads zero
-            // the other half of their destination: the role bits cannot simply be left standing in the registers.)
-            const uint32_t u_ol = (uint16_t)rb_mo[k], u_or = (uint16_t)rb_mo[k + 2], u_ie = (uint16_t)rb_ie[k],
-                           u_de = (uint16_t)rb_de[k], u_x = (uint16_t)rb_mx[k];
-            const int ins_c = max((int)((u_ol << 16) + (0x10000u | BT_M_I)), (int)((u_ie << 16) + (0x10000u | BT_M_I | BT_I_EXT)));
-            const int del_t = max((int)((u_or << 16) | BT_M_D), (int)((u_de << 16) | (BT_M_D | BT_D_EXT)));
+        constexpr bool TAGGED = LEAN && !GLOBAL_RING && !BANDED && sizeof(OffT) == 2;     // (also the hybrid ring: its D row is read through a global pointer)
+        if constexpr (TAGGED) {
+          // ---- lean cells with 16-bit offsets in LDS.  Every row is addressed as (lane's base of this score) + a
+          // compile-time chunk offset, which the DS instructions carry as their immediate: the seven row bases are
+          // formed once per score instead of once per 64-diagonal chunk (groups of U chunks; a wavefront wider than
+          // U chunks bumps the bases once per group).  No lane is ever switched off (see `chunk`).
+          // Offsets go to the high halves, the role of each value (its origin bits, see wfa_device.h) to the low
+          // halves -- one v_lshl_add/v_lshl_or per value, which also carries the "+1" of the insertion and
+          // mismatch candidates.  A signed max then picks the larger offset and, on equal offsets, the source WFA2
+          // prefers (extension over open; mismatch, then deletion, then insertion), and the origin byte is two
+          // bit-field inserts of the winners' low bits.  (The MI355X runs with SRAM ECC on, where d16_hi loads zero
+          // the other half of their destination: the role bits cannot simply be left standing in the registers.)
+          constexpr int U = 4;
+          static_assert(U == 4, "the group below is written out for four chunks");
+          constexpr int SH = RAW ? 2 : 4, PER = 1 << SH, BITS = RAW ? 3 : 1;
+          const OffT* q_mx = rb_mx + lo + tid; const OffT* q_mo = rb_mo + lo + tid;
+          const OffT* q_ie = rb_ie + lo + tid; const OffT* q_de = rb_de + lo + tid;
+          OffT* w_m = wb_m + lo + tid; OffT* w_i = wb_i + lo + tid; OffT* w_d = wb_d + lo + tid;
+          uint8_t* q_codes = codes + tid;
+          int kq = lo + tid;
+          const int wave_k = (NW == 1) ? lo : lo + __builtin_amdgcn_readfirstlane(tid & ~63);    // first diagonal of this wave
+          // One chunk: `uc` = its compile-time position in the group, `PARTIAL` = some lanes lie beyond `hi` (mask `act`
+          // of those that do not).  Lanes beyond `hi` run along and store NULL into their cells (the rows are padded by
+          // one chunk for that, and NULL is what a cell outside a row's limits has to hold anyway) and a meaningless
+          // origin byte into the slack the arena keeps behind every row.
+          auto chunk = [&](auto uc, auto partial_tag, const unsigned long long act) {
+            constexpr int O = decltype(uc)::value * NT;
+            constexpr bool PARTIAL = decltype(partial_tag)::value;
+            const int k = kq + O;
+            const uint32_t u_ol = (uint16_t)q_mo[O], u_or = (uint16_t)q_mo[O + 2], u_ie = (uint16_t)q_ie[O],
+                           u_de = (uint16_t)q_de[O], u_x = (uint16_t)q_mx[O];
+            int ins_c = max((int)((u_ol << 16) + (0x10000u | BT_M_I)), (int)((u_ie << 16) + (0x10000u | BT_M_I | BT_I_EXT)));
+            int del_t = max((int)((u_or << 16) | BT_M_D), (int)((u_de << 16) | (BT_M_D | BT_D_EXT)));
             const int mis_c = (int)((u_x << 16) + (0x10000u | BT_M_X));
             const int mv_t = max(del_t, max(mis_c, ins_c));
+            uint32_t code = 0;
             if constexpr (BT) {
               uint32_t c1;
               asm("v_bfi_b32 %0, 2, %1, %2" : "=v"(c1) : "v"(del_t), "v"(mv_t));      // bit 1 from the deletion winner
               asm("v_bfi_b32 %0, 1, %1, %2" : "=v"(code) : "v"(ins_c), "v"(c1));      // bit 0 from the insertion winner
             }
-            mv0 = mv_t >> 16;
-            ins_hi = ins_c; del_hi = del_t;
-            ins = 0; del = 0;
-          } else {
+            const int mv0 = mv_t >> 16;
+            // No cell has touched a sequence end so far, so no candidate lies beyond one (M, I and D of the earlier
+            // scores are all < min(plen + k, tlen), and a candidate is at most one more): "not valid" just means NULL,
+            // i.e. negative.
+            const bool ok = mv_t >= 0;
+            // extend = longest common prefix from (v,h) (wavefront_extend.c:174-199), see the notes in the general loop below
+            int h = mv0;
+            const int hmax = min(plen + k, tlen);
+            {
+              const int v = mv0 - k;
+              const int rem = hmax - h;
+              const char* pp = reinterpret_cast<const char*>(Pw + (v >> SH));
+              const char* tp = reinterpret_cast<const char*>(Tw + (h >> SH));
+              const uint32_t sa = (uint32_t)v << BITS, sb = (uint32_t)h << BITS;
+              uint32_t fb, d0w;
+              {
+                const uint32_t* pw = reinterpret_cast<const uint32_t*>(pp);
+                const uint32_t* tw = reinterpret_cast<const uint32_t*>(tp);
+                d0w = __builtin_amdgcn_alignbit(pw[1], pw[0], sa) ^ __builtin_amdgcn_alignbit(tw[1], tw[0], sb);
+                asm("v_ffbl_b32 %0, %1" : "=v"(fb) : "v"(d0w));
+              }
+              {
+                int adv;
+                asm("v_min3_i32 %0, %1, %2, %3" : "=v"(adv) : "v"((int)(fb >> BITS)), "v"(rem), "n"(PER));
+                h += adv;
+              }
+              const bool more = ok & (d0w == 0u);
+              if (__builtin_amdgcn_ballot_w64(more) != 0ull) {
+                int left = more ? max(rem - PER, 0) : 0;
+                while (__builtin_amdgcn_ballot_w64(left > 0) != 0ull) {
+                  pp += 4; tp += 4;
+                  const uint32_t* pw = reinterpret_cast<const uint32_t*>(pp);
+                  const uint32_t* tw = reinterpret_cast<const uint32_t*>(tp);
+                  const uint32_t d = __builtin_amdgcn_alignbit(pw[1], pw[0], sa) ^ __builtin_amdgcn_alignbit(tw[1], tw[0], sb);
+                  asm("v_ffbl_b32 %0, %1" : "=v"(fb) : "v"(d));
+                  const int nn = min(min((int)(fb >> BITS), PER), left);
+                  h += nn;
+                  left = (nn == PER) ? left - PER : 0;
+                }
+              }
+            }
+            bool keep = ok;
+            if constexpr (PARTIAL) {
+              const bool active = __builtin_amdgcn_inverse_ballot_w64(act);
+              keep &= active;
+              ins_c = active ? ins_c : (int)0x80000000u; del_t = active ? del_t : (int)0x80000000u;
+            }
+            const int mv = keep ? h : OffNull<OffT>::value;
+            wave_touch |= __builtin_amdgcn_ballot_w64(mv == hmax);      // (NULL never equals it)
+            w_m[O] = (OffT)mv;
+            w_i[O] = (OffT)(ins_c >> 16);     // (high halves: ds_write_b16_d16_hi, no unpacking)
+            w_d[O] = (OffT)(del_t >> 16);
+            if constexpr (BT) q_codes[O] = (uint8_t)code;
+          };
+          auto chunk_at = [&](auto uc, const int k0) -> bool {
+            const int n_act = hi - (k0 + decltype(uc)::value * NT) + 1;     // lanes of this chunk that carry a cell (wave-uniform)
+            if (n_act <= 0) return false;
+            if (n_act >= 64) chunk(uc, std::false_type{}, 0ull);
+            else chunk(uc, std::true_type{}, (1ull << n_act) - 1ull);
+            return n_act > NT;      // this wave has another chunk in the row
+          };
+          for (int k0 = wave_k; k0 <= hi; k0 += U * NT) {
+            if (chunk_at(std::integral_constant<int, 0>{}, k0) && chunk_at(std::integral_constant<int, 1>{}, k0) &&
+                chunk_at(std::integral_constant<int, 2>{}, k0) && chunk_at(std::integral_constant<int, 3>{}, k0)) {
+              q_mx += U * NT; q_mo += U * NT; q_ie += U * NT; q_de += U * NT;
+              w_m += U * NT; w_i += U * NT; w_d += U * NT; q_codes += U * NT; kq += U * NT;
+            } else break;
+          }
+          return;
+        }
+        for (int k0 = lo; k0 <= hi; k0 += NT) {
+          const int k = min(k0 + tid, hi);
+          // recurrences (wavefront_compute_affine.c:66-84)
+          int ins, del, mv0;
+          uint32_t code = 0;
+          {
             int m_x, m_ol, m_or, i_e, d_e;
             if constexpr (BANDED) {
               // rows live at their own window base: form the index only for diagonals inside the row
@@ -531,13 +620,8 @@ wfa_align_kernel(const WfaAlignParams p) {
           // M and D offsets never exceed the text length, so they fit 16 bits as they are; only an I
           // chain running past the text end keeps growing and is saturated by off_store
           wb_m[k] = (OffT)mv;
-          if constexpr (TAGGED) {
-            wb_i[k] = (OffT)(ins_hi >> 16);     // (high halves: ds_write_b16_d16_hi, no unpacking)
-            wb_d[k] = (OffT)(del_hi >> 16);
-          } else {
-            if constexpr (LEAN) wb_i[k] = (OffT)ins; else wb_i[k] = off_store<OffT>(ins);
-            wb_d[k] = (OffT)del;
-          }
+          if constexpr (LEAN) wb_i[k] = (OffT)ins; else wb_i[k] = off_store<OffT>(ins);
+          wb_d[k] = (OffT)del;
           if constexpr (BT) codes[(uint32_t)(k - lo)] = (uint8_t)code;
         }
       };
@@ -558,7 +642,207 @@ wfa_align_kernel(const WfaAlignParams p) {
         // valid and only feed cells that are not valid either, at most one 64-lane chunk per early score.
         // An inner loop with its own small state: the instruction-issue pipes are what this kernel saturates, and
         // the scalar registers are what the compiler runs out of (every spilled one comes back through the vector unit).
-        if constexpr (!BANDED) {
+        // ---- the same lean path written out for the one-wavefront 16-bit LDS tier (BASELINE's short-read configs live
+        // here).  Vector and scalar instructions of a wavefront share its issue slots (one instruction per wave every
+        // four cycles), so the per-score bookkeeping -- as many instructions as a 64-diagonal chunk of cells -- is cut
+        // to the bone: limits in closed form, row addresses as one lane base (lo + lane - 1) plus a scalar slot base each
+        // (every neighbour is a non-negative immediate away), row book written when the loop is left (its entries are
+        // a function of the score), row-table entries by v_writelane, guard cells re-NULLed only once the budget's
+        // reach makes the wavefront shrink (a growing wavefront overwrites everything its slot held before).
+        constexpr bool HOT = NW == 1 && !BANDED && !GLOBAL_RING && !HYBRID && sizeof(OffT) == 2;
+        if constexpr (HOT) {
+          if (e == 1 && !touched_ever) {
+            typedef __attribute__((address_space(3))) OffT* LdsRow;
+            typedef __attribute__((address_space(3))) const uint32_t* LdsWords;
+            constexpr int SH = RAW ? 2 : 4, PER = 1 << SH, BITS = RAW ? 3 : 1;
+            const int s_in = s, lo_in = last_lo, hi_in = last_hi;
+            // lo(s) = max(lo_in - (s - s_in), wlo, s + c_lo), hi(s) = min(hi_in + (s - s_in), whi, c_hi - s)
+            const int c_lo = bounded ? kend - budget : INT_MIN / 2, c_hi = bounded ? kend + budget : INT_MAX / 2;
+            // first score at which a limit can move inwards (the reach bound has caught up with the window or the growing
+            // front); from dm scores before... after it on, the slots written hold cells beyond the new limits
+            int s_clear = INT_MAX;
+            if (bounded) {
+              const int t_lo = min(wlo - c_lo, (lo_in + s_in - c_lo) >> 1), t_hi = min(c_hi - whi, (c_hi - hi_in + s_in) >> 1);
+              s_clear = min(t_lo, t_hi) - 1;
+            }
+            s_clear = __builtin_amdgcn_readfirstlane(s_clear);     // (a scalar, whatever unit the compiler formed it on)
+            const uint32_t rsb = (uint32_t)rs * 2u;
+            const uint32_t a_first = lds_addr(m_first), a_end = lds_addr(m_end);
+            uint32_t a_m = lds_addr(p_m), a_x = lds_addr(p_x), a_oe = lds_addr(p_oe);
+            uint32_t a_ic = lds_addr(p_ic), a_ip = lds_addr(p_ip);
+            const uint32_t a_iswap = a_ic ^ a_ip;
+            const uint32_t d_off = (uint32_t)(de * rs) * 2u;       // D row of an I row
+            const uint32_t pw_addr = lds_addr(Pw), tw_addr = lds_addr(Tw);
+            int lo = lo_in, hi = hi_in;
+            bool nomem = false;
+            unsigned long long touch = 0;
+            uint32_t a_last = a_m;
+            for (;;) {
+              const int ns = s + 1;
+              int nlo = max(lo - 1, wlo), nhi = min(hi + 1, whi);
+              asm volatile("" : "+s"(nlo), "+s"(nhi));   // (keeps the chains off v_max3/v_min3)
+              nlo = max(nlo, ns + c_lo); nhi = min(nhi, c_hi - ns);
+              if (nlo > nhi) break;
+              lo = nlo; hi = nhi; s = ns;
+              a_m += rsb;  if (a_m == a_end) a_m = a_first;
+              a_x += rsb;  if (a_x == a_end) a_x = a_first;
+              a_oe += rsb; if (a_oe == a_end) a_oe = a_first;
+              a_ic ^= a_iswap; a_ip ^= a_iswap;
+              const int wm1 = hi - lo;            // width - 1
+              ncells += (uint32_t)wm1;            // (+ 1 per score when the loop is left)
+              uint8_t* codes = nullptr;
+              if constexpr (BT) {
+                const uint32_t need = ((uint32_t)wm1 + 16u) >> 4;
+                if (__builtin_expect(need + WFA_ARENA_ROW_SLACK > chunk_left, 0)) {
+                  ColdParams cp = cold_params();
+                  const uint32_t grab = max(need + WFA_ARENA_ROW_SLACK, cp->chunk_units);
+                  uint32_t base = WFA_ROW_NONE;
+                  if (tid == 0) {
+                    const unsigned long long b = atomicAdd(cp->arena_top, (unsigned long long)grab);
+                    if (b + grab <= cp->arena_units) base = (uint32_t)b;
+                  }
+                  base = block_bcast<NW>(base, bslot);
+                  chunk_cur = base; chunk_left = (base == WFA_ROW_NONE) ? 0u : grab;
+                }
+                if (chunk_left < need) { nomem = true; break; }
+                row_s = chunk_cur; chunk_cur += need; chunk_left -= need;
+                // row table, buffered by lane: a new group of 64 scores starts at every multiple of 64
+                const int sl = s & 63;
+                if (sl == 0) tab[s - 64 + lane] = make_uint2((uint32_t)tabv_row, (uint32_t)tabv_lo);
+                asm("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
+                    : "+v"(tabv_row), "+v"(tabv_lo) : "s"((int)row_s), "s"(lo), "s"(sl));      // (m0: scratch, the compiler sets it before each use of its own)
+                codes = p.arena + (size_t)row_s * 16;
+              }
+              if (__builtin_expect(s >= s_clear, 0)) {
+                // the slots written now last held scores s-dm (M) and s-2 (I, D), whose limits lay up to dm diagonals
+                // further out: NULL the dm cells beyond each end (rows carry dm guard cells per side)
+                const int j = min(lane, 2 * dm - 1);
+                const int q = (j < dm) ? lo - 1 - j : hi + 1 - dm + j;
+                const uint32_t qa = (uint32_t)q << 1;
+                *(LdsRow)(qa + a_m) = (OffT)OffNull<OffT>::value;
+                *(LdsRow)(qa + a_ic) = (OffT)OffNull<OffT>::value;
+                *(LdsRow)(qa + a_ic + d_off) = (OffT)OffNull<OffT>::value;
+              }
+              // lane bases: cell (lo + lane - 1) of every row involved; all neighbours are immediates from there
+              uint32_t vb = (uint32_t)(lane + (lo - 1)) << 1;
+              int kq = lane + lo;
+              uint32_t code_off = (uint32_t)lane;
+              int left = wm1 + 1;
+              for (;;) {
+                // (one v_add each, once per score: the empty asm keeps the compiler from re-forming them in every chunk)
+                uint32_t q_mo = vb + a_oe, q_mx = vb + a_x, q_wm = vb + a_m, q_ri = vb + a_ip, q_wi = vb + a_ic;
+                asm volatile("" : "+v"(q_mo), "+v"(q_mx), "+v"(q_wm), "+v"(q_ri), "+v"(q_wi));
+                uint32_t q_rd = q_ri + d_off, q_wd = q_wi + d_off;
+                asm volatile("" : "+v"(q_rd), "+v"(q_wd));
+                const LdsRow r_mo = (LdsRow)q_mo, r_mx = (LdsRow)q_mx, w_m = (LdsRow)q_wm;
+                const LdsRow r_i = (LdsRow)q_ri, w_i = (LdsRow)q_wi, r_d = (LdsRow)q_rd, w_d = (LdsRow)q_wd;
+                auto chunk = [&](auto uc, auto partial_tag, const unsigned long long act) {
+                  constexpr int O = decltype(uc)::value * 64;
+                  constexpr bool PARTIAL = decltype(partial_tag)::value;
+                  const int k = kq + O;
+                  const uint32_t u_ol = (uint16_t)r_mo[O], u_or = (uint16_t)r_mo[O + 2], u_ie = (uint16_t)r_i[O],
+                                 u_de = (uint16_t)r_d[O + 2], u_x = (uint16_t)r_mx[O + 1];
+                  int ins_c = max((int)((u_ol << 16) + (0x10000u | BT_M_I)), (int)((u_ie << 16) + (0x10000u | BT_M_I | BT_I_EXT)));
+                  int del_t = max((int)((u_or << 16) | BT_M_D), (int)((u_de << 16) | (BT_M_D | BT_D_EXT)));
+                  const int mis_c = (int)((u_x << 16) + (0x10000u | BT_M_X));
+                  const int mv_t = max(del_t, max(mis_c, ins_c));
+                  uint32_t code = 0;
+                  if constexpr (BT) {
+                    uint32_t c1;
+                    asm("v_bfi_b32 %0, 2, %1, %2" : "=v"(c1) : "v"(del_t), "v"(mv_t));      // bit 1 from the deletion winner
+                    asm("v_bfi_b32 %0, 1, %1, %2" : "=v"(code) : "v"(ins_c), "v"(c1));      // bit 0 from the insertion winner
+                  }
+                  const int mv0 = mv_t >> 16;
+                  const bool ok = mv_t >= 0;      // (nothing has touched a sequence end: not valid = NULL = negative)
+                  int h = mv0;
+                  const int hmax = min(plen + k, tlen);
+                  {
+                    const int v = mv0 - k;
+                    const int rem = hmax - h;
+                    uint32_t pa, ta;      // word addresses: base + 4 * (symbol index / PER)
+                    asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(pa) : "v"(v >> SH), "s"(pw_addr));
+                    asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(ta) : "v"(h >> SH), "s"(tw_addr));
+                    const uint32_t sa = (uint32_t)v << BITS, sb = (uint32_t)h << BITS;
+                    uint32_t fb, d0w;
+                    {
+                      const LdsWords pw = (LdsWords)pa; const LdsWords tw = (LdsWords)ta;
+                      d0w = __builtin_amdgcn_alignbit(pw[1], pw[0], sa) ^ __builtin_amdgcn_alignbit(tw[1], tw[0], sb);
+                      asm("v_ffbl_b32 %0, %1" : "=v"(fb) : "v"(d0w));
+                    }
+                    {
+                      int adv;
+                      asm("v_min3_i32 %0, %1, %2, %3" : "=v"(adv) : "v"((int)(fb >> BITS)), "v"(rem), "n"(PER));
+                      h += adv;
+                    }
+                    const bool more = ok & (d0w == 0u);
+                    if (__builtin_amdgcn_ballot_w64(more) != 0ull) {
+                      int togo = more ? max(rem - PER, 0) : 0;
+                      while (__builtin_amdgcn_ballot_w64(togo > 0) != 0ull) {
+                        pa += 4; ta += 4;
+                        const LdsWords pw = (LdsWords)pa; const LdsWords tw = (LdsWords)ta;
+                        const uint32_t d = __builtin_amdgcn_alignbit(pw[1], pw[0], sa) ^ __builtin_amdgcn_alignbit(tw[1], tw[0], sb);
+                        asm("v_ffbl_b32 %0, %1" : "=v"(fb) : "v"(d));
+                        const int nn = min(min((int)(fb >> BITS), PER), togo);
+                        h += nn;
+                        togo = (nn == PER) ? togo - PER : 0;
+                      }
+                    }
+                  }
+                  bool keep = ok;
+                  if constexpr (PARTIAL) {
+                    const bool active = __builtin_amdgcn_inverse_ballot_w64(act);
+                    keep &= active;
+                    ins_c = active ? ins_c : (int)0x80000000u; del_t = active ? del_t : (int)0x80000000u;
+                  }
+                  const int mv = keep ? h : OffNull<OffT>::value;
+                  touch |= __builtin_amdgcn_ballot_w64(mv == hmax);      // (NULL never equals it)
+                  w_m[O + 1] = (OffT)mv;
+                  w_i[O + 1] = (OffT)(ins_c >> 16);     // (high halves: ds_write_b16_d16_hi, no unpacking)
+                  w_d[O + 1] = (OffT)(del_t >> 16);
+                  if constexpr (BT) codes[code_off + O] = (uint8_t)code;
+                };
+                auto chunk_at = [&](auto uc) -> bool {
+                  const int n_act = left - decltype(uc)::value * 64;
+                  if (n_act >= 64) chunk(uc, std::false_type{}, 0ull);
+                  else chunk(uc, std::true_type{}, (1ull << n_act) - 1ull);
+                  return n_act > 64;
+                };
+                if (!(chunk_at(std::integral_constant<int, 0>{}) && chunk_at(std::integral_constant<int, 1>{}) &&
+                      chunk_at(std::integral_constant<int, 2>{}) && chunk_at(std::integral_constant<int, 3>{}))) break;
+                vb += 512u; kq += 256; code_off += 256u; left -= 256;
+              }
+              block_sync<NW>();
+              a_last = a_m;
+              if (touch != 0ull) {
+                // a cell sits on a sequence end: it may be the last one (wavefront_extend.c:47-67), and from the next
+                // score on values may run past the ends -- the careful path takes over
+                touched_ever = true;
+                break;
+              }
+            }
+            // back to the general state
+            const int n_lean = s - s_in;
+            ncells += (uint32_t)n_lean;
+            if (touched_ever && n_lean > 0)
+              done = ((unsigned)(kend - lo) <= (unsigned)(hi - lo)) &&
+                     __builtin_amdgcn_readfirstlane((int)*(LdsRow)(a_last + ((uint32_t)kend << 1))) >= tlen;
+            // row book: the last dm scores (older entries are never read again)
+            for (int j = max(s_in + 1, s - dm + 1); j <= s; ++j) {
+              const int jl = max(max(lo_in - (j - s_in), wlo), j + c_lo), jh = min(min(hi_in + (j - s_in), whi), c_hi - j);
+              book.set_a(j & bkm, pack_range(jl, jh));
+            }
+            if (n_lean > 0) book.copy_a_to_id(tid, NT, bkm);
+            regular += n_lean;
+            last_lo = lo; last_hi = hi;
+            p_m = m_first + (a_m - a_first) / 2; p_x = m_first + (a_x - a_first) / 2; p_oe = m_first + (a_oe - a_first) / 2;
+            p_ic = m_first + (a_ic - a_first) / 2; p_ip = m_first + (a_ip - a_first) / 2;
+            if (bounded) { rlo += n_lean; rhi -= n_lean; }
+            tab_group = s >> 6;
+            if (nomem) { status = WFA_ST_NOMEM; break; }
+            if (done) break;
+          }
+        }
+        if constexpr (!BANDED && !HOT) {
           if (e == 1 && !touched_ever) {
             int lo = last_lo, hi = last_hi;
             // (e == 1: the reach interval is [kend - (budget - s), kend + (budget - s)]; `reach` is budget - s)

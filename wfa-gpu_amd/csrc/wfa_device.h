@@ -46,6 +46,12 @@ enum : uint32_t {
 enum : uint32_t { BT_M_NONE = 0, BT_M_X = 12, BT_M_D = 8, BT_M_I = 4, BT_M_MASK = 12, BT_D_EXT = 2, BT_I_EXT = 1 };
 
 #define WFA_ROW_NONE 0xFFFFFFFFu
+// The lean cells of the 16-bit LDS tiers (0, 1, 2, 4) never switch a lane off: the lanes of a row's last 64-diagonal
+// chunk that lie beyond its upper limit store NULL offsets into that many cells behind the row (every ring row carries
+// WFA_RING_ROW_PAD extra cells for it) and origin bytes behind the row's bytes in the arena (every arena chunk keeps
+// WFA_ARENA_ROW_SLACK 16-byte units unallocated at its end; the arena itself ends with 8 spare units).
+#define WFA_RING_ROW_PAD 64
+#define WFA_ARENA_ROW_SLACK 4u
 
 // Backtrace arena, 16-byte units.  Per alignment: a row table [score] = {unit of the row, lo} (8 bytes
 // per score up to the score budget) followed, wherever the block's bump allocator puts them, by one

@@ -357,7 +357,9 @@ bool plan_tier(const wfagpu_amd_ctx* c, WfaAlignParams& p, int max_score, unsign
     return true;
   }
   const int width = window_width(max_score, p.oe - p.e, p.e, max_seq_len);
-  p.rs = (width + 1 + 2 * p.dm + 1) & ~1;     // dm guard cells on each side of a row (see the kernel's lean path)
+  // dm guard cells on each side of a row (see the kernel's lean path); the 16-bit LDS tiers add a chunk of padding
+  const int rs_plain = (width + 1 + 2 * p.dm + 1) & ~1;
+  p.rs = rs_plain + WFA_RING_ROW_PAD;
   const bool i16_ok = max_seq_len <= 32766u && max_score <= 30000;
   const size_t budget[3] = {40u << 10, 80u << 10, c->lds_per_block_max};
   // WFAGPU_MIN_TIER (tests): skip the smaller tiers so that the rarely needed ones get exercised
@@ -387,6 +389,7 @@ bool plan_tier(const wfagpu_amd_ctx* c, WfaAlignParams& p, int max_score, unsign
       if (nb >= 1) { *out = {4, width, max_score, lds_h, nb}; return true; }
     }
   }
+  p.rs = rs_plain;
   const size_t lds = wfa_align_lds_bytes(p, 3);
   if (lds > c->lds_per_block_max) return false;   // sequences themselves do not fit LDS
   const int nb = wfa_align_max_blocks_per_cu(3, bt, raw, false, lds);

@@ -625,6 +625,116 @@ wfa_align_kernel(const WfaAlignParams p) {
           if constexpr (BT) codes[(uint32_t)(k - lo)] = (uint8_t)code;
         }
       };
+      // ---- the lean cells of one score for the one-wavefront 16-bit LDS tier: rows given as LDS byte addresses of their
+      // diagonal 0 (a_oe: M[s-o-e], a_x: M[s-x], a_ip / a_dp: I / D of s-e, a_m / a_ic / a_dc: the rows written), `codes`:
+      // this lane's origin byte in the row of origin bytes (global), wm1 = hi - lo.  Same cells, values and origin bytes
+      // as cells_of_score's lean form.
+      constexpr bool HOT = NW == 1 && !BANDED && !GLOBAL_RING && !HYBRID && sizeof(OffT) == 2;
+      typedef __attribute__((address_space(3))) OffT* LdsRow;
+      typedef __attribute__((address_space(3))) const uint32_t* LdsWords;
+      typedef __attribute__((address_space(1))) uint8_t* GlobalBytes;
+      const uint32_t pw_addr = lds_addr(Pw), tw_addr = lds_addr(Tw);
+      auto hot_cells = [&](const int lo, const int wm1, GlobalBytes codes, const uint32_t a_oe, const uint32_t a_x, const uint32_t a_m,
+                           const uint32_t a_ip, const uint32_t a_ic, const uint32_t a_dp, const uint32_t a_dc, unsigned long long& touch) {
+        constexpr int SH = RAW ? 2 : 4, PER = 1 << SH, BITS = RAW ? 3 : 1;
+        // a group of up to four chunks from lane bases vb (cell lo + lane - 1 of every row involved: all neighbours are
+        // immediates from there), kq (this lane's diagonal) and codes; returns whether the row goes on beyond the group
+        auto group = [&](const uint32_t vb, const int kq, GlobalBytes codes, const int left) -> bool {
+          bool more_groups;
+          // (one v_add each, once per score: the empty asm keeps the compiler from re-forming them in every chunk)
+          uint32_t q_mo = vb + a_oe, q_mx = vb + a_x, q_wm = vb + a_m, q_ri = vb + a_ip, q_wi = vb + a_ic;
+          uint32_t q_rd = vb + a_dp, q_wd = vb + a_dc;
+          asm volatile("" : "+v"(q_mo), "+v"(q_mx), "+v"(q_wm), "+v"(q_ri), "+v"(q_wi), "+v"(q_rd), "+v"(q_wd));
+          const LdsRow r_mo = (LdsRow)q_mo, r_mx = (LdsRow)q_mx, w_m = (LdsRow)q_wm;
+          const LdsRow r_i = (LdsRow)q_ri, w_i = (LdsRow)q_wi, r_d = (LdsRow)q_rd, w_d = (LdsRow)q_wd;
+          auto chunk = [&](auto uc, auto partial_tag, const unsigned long long act) {
+            constexpr int O = decltype(uc)::value * 64;
+            constexpr bool PARTIAL = decltype(partial_tag)::value;
+            const int k = kq + O;
+            const uint32_t u_ol = (uint16_t)r_mo[O], u_or = (uint16_t)r_mo[O + 2], u_ie = (uint16_t)r_i[O],
+                           u_de = (uint16_t)r_d[O + 2], u_x = (uint16_t)r_mx[O + 1];
+            int ins_c = max((int)((u_ol << 16) + (0x10000u | BT_M_I)), (int)((u_ie << 16) + (0x10000u | BT_M_I | BT_I_EXT)));
+            int del_t = max((int)((u_or << 16) | BT_M_D), (int)((u_de << 16) | (BT_M_D | BT_D_EXT)));
+            const int mis_c = (int)((u_x << 16) + (0x10000u | BT_M_X));
+            const int mv_t = max(del_t, max(mis_c, ins_c));
+            uint32_t code = 0;
+            if constexpr (BT) {
+              uint32_t c1;
+              asm("v_bfi_b32 %0, 2, %1, %2" : "=v"(c1) : "v"(del_t), "v"(mv_t));      // bit 1 from the deletion winner
+              asm("v_bfi_b32 %0, 1, %1, %2" : "=v"(code) : "v"(ins_c), "v"(c1));      // bit 0 from the insertion winner
+            }
+            const int mv0 = mv_t >> 16;
+            const bool ok = mv_t >= 0;      // (nothing has touched a sequence end: not valid = NULL = negative)
+            int h = mv0;
+            const int hmax = min(plen + k, tlen);
+            {
+              const int v = mv0 - k;
+              const int rem = hmax - h;
+              uint32_t pa, ta;      // word addresses: base + 4 * (symbol index / PER)
+              asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(pa) : "v"(v >> SH), "s"(pw_addr));
+              asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(ta) : "v"(h >> SH), "s"(tw_addr));
+              const uint32_t sa = (uint32_t)v << BITS, sb = (uint32_t)h << BITS;
+              uint32_t fb, d0w;
+              {
+                const LdsWords pw = (LdsWords)pa; const LdsWords tw = (LdsWords)ta;
+                d0w = __builtin_amdgcn_alignbit(pw[1], pw[0], sa) ^ __builtin_amdgcn_alignbit(tw[1], tw[0], sb);
+                asm("v_ffbl_b32 %0, %1" : "=v"(fb) : "v"(d0w));
+              }
+              {
+                int adv;
+                asm("v_min3_i32 %0, %1, %2, %3" : "=v"(adv) : "v"((int)(fb >> BITS)), "v"(rem), "n"(PER));
+                h += adv;
+              }
+              const bool more = ok & (d0w == 0u);
+              if (__builtin_amdgcn_ballot_w64(more) != 0ull) {
+                int togo = more ? max(rem - PER, 0) : 0;
+                while (__builtin_amdgcn_ballot_w64(togo > 0) != 0ull) {
+                  pa += 4; ta += 4;
+                  const LdsWords pw = (LdsWords)pa; const LdsWords tw = (LdsWords)ta;
+                  const uint32_t d = __builtin_amdgcn_alignbit(pw[1], pw[0], sa) ^ __builtin_amdgcn_alignbit(tw[1], tw[0], sb);
+                  asm("v_ffbl_b32 %0, %1" : "=v"(fb) : "v"(d));
+                  const int nn = min(min((int)(fb >> BITS), PER), togo);
+                  h += nn;
+                  togo = (nn == PER) ? togo - PER : 0;
+                }
+              }
+            }
+            bool keep = ok;
+            if constexpr (PARTIAL) {
+              const bool active = __builtin_amdgcn_inverse_ballot_w64(act);
+              keep &= active;
+              ins_c = active ? ins_c : (int)0x80000000u; del_t = active ? del_t : (int)0x80000000u;
+            }
+            const int mv = keep ? h : OffNull<OffT>::value;
+            touch |= __builtin_amdgcn_ballot_w64(mv == hmax);      // (NULL never equals it)
+            w_m[O + 1] = (OffT)mv;
+            w_i[O + 1] = (OffT)(ins_c >> 16);     // (high halves: ds_write_b16_d16_hi, no unpacking)
+            w_d[O + 1] = (OffT)(del_t >> 16);
+            if constexpr (BT) codes[O] = (uint8_t)code;
+          };
+          // chunks 0..3 of the group, nested so that every decision is one scalar compare and branch
+          more_groups = false;
+          auto from = [&](auto&& self, auto uc) -> void {
+            constexpr int Uc = decltype(uc)::value;
+            const int n_act = left - Uc * 64;
+            if (n_act >= 64) {
+              chunk(uc, std::false_type{}, 0ull);
+              if constexpr (Uc < 3) { if (n_act > 64) self(self, std::integral_constant<int, Uc + 1>{}); }
+              else more_groups = n_act > 64;
+            } else {
+              chunk(uc, std::true_type{}, (1ull << n_act) - 1ull);
+            }
+          };
+          from(from, std::integral_constant<int, 0>{});
+          return more_groups;
+        };
+        const uint32_t vb0 = (uint32_t)(lane + (lo - 1)) << 1;
+        if (__builtin_expect(group(vb0, lane + lo, codes, wm1 + 1), 0)) {
+          // (wider than four chunks: rare in this tier, kept out of the way of the common case)
+          uint32_t vb = vb0; int kq = lane + lo, left = wm1 + 1;
+          do { vb += 512u; kq += 256; codes += 256; left -= 256; } while (group(vb, kq, codes, left));
+        }
+      };
       // Limits of the last score (the lean path derives the next ones from them alone).
       int last_lo = 0, last_hi = 0;
       // Has any M cell reached the end of a sequence (offset == min(plen + k, tlen)) so far?  Only after that can an
@@ -649,12 +759,8 @@ wfa_align_kernel(const WfaAlignParams p) {
         // (every neighbour is a non-negative immediate away), row book written when the loop is left (its entries are
         // a function of the score), row-table entries by v_writelane, guard cells re-NULLed only once the budget's
         // reach makes the wavefront shrink (a growing wavefront overwrites everything its slot held before).
-        constexpr bool HOT = NW == 1 && !BANDED && !GLOBAL_RING && !HYBRID && sizeof(OffT) == 2;
         if constexpr (HOT) {
           if (e == 1 && !touched_ever) {
-            typedef __attribute__((address_space(3))) OffT* LdsRow;
-            typedef __attribute__((address_space(3))) const uint32_t* LdsWords;
-            constexpr int SH = RAW ? 2 : 4, PER = 1 << SH, BITS = RAW ? 3 : 1;
             const int s_in = s, lo_in = last_lo, hi_in = last_hi;
             // lo(s) = max(lo_in - (s - s_in), wlo, s + c_lo), hi(s) = min(hi_in + (s - s_in), whi, c_hi - s)
             const int c_lo = bounded ? kend - budget : INT_MIN / 2, c_hi = bounded ? kend + budget : INT_MAX / 2;
@@ -671,28 +777,32 @@ wfa_align_kernel(const WfaAlignParams p) {
             uint32_t a_m = lds_addr(p_m), a_x = lds_addr(p_x), a_oe = lds_addr(p_oe);
             uint32_t a_ic = lds_addr(p_ic), a_ip = lds_addr(p_ip);
             const uint32_t a_iswap = a_ic ^ a_ip;
-            const uint32_t d_off = (uint32_t)(de * rs) * 2u;       // D row of an I row
-            const uint32_t pw_addr = lds_addr(Pw), tw_addr = lds_addr(Tw);
+            uint32_t a_dc = a_ic + (uint32_t)(de * rs) * 2u, a_dp = a_ip + (uint32_t)(de * rs) * 2u;       // the D rows of those I rows
+            const uint32_t a_dswap = a_dc ^ a_dp;
             int lo = lo_in, hi = hi_in;
-            bool nomem = false;
             unsigned long long touch = 0;
             uint32_t a_last = a_m;
-            for (;;) {
-              const int ns = s + 1;
-              int nlo = max(lo - 1, wlo), nhi = min(hi + 1, whi);
-              asm volatile("" : "+s"(nlo), "+s"(nhi));   // (keeps the chains off v_max3/v_min3)
-              nlo = max(nlo, ns + c_lo); nhi = min(nhi, c_hi - ns);
-              if (nlo > nhi) break;
-              lo = nlo; hi = nhi; s = ns;
-              a_m += rsb;  if (a_m == a_end) a_m = a_first;
-              a_x += rsb;  if (a_x == a_end) a_x = a_first;
-              a_oe += rsb; if (a_oe == a_end) a_oe = a_first;
-              a_ic ^= a_iswap; a_ip ^= a_iswap;
+            // address of this lane's origin byte in the row of the current score (64-bit, bumped by the row size)
+            uint64_t code_addr = 0;
+            uint32_t need_prev = 0;
+            if constexpr (BT) code_addr = (uint64_t)(uintptr_t)p.arena + (uint64_t)chunk_cur * 16u + (uint32_t)lane;
+            // why the loop ends: 1 = the reach interval is empty, 2 = arena exhausted, 3 = a cell touched a sequence end
+            // (one exit at the bottom: several would be funnelled through a guard variable anyway)
+            int why = 0;
+            do {
+              // (everything is updated in place -- no second set of registers to copy back at the bottom; when the loop
+              // ends without having computed this score, the state of the last computed one is re-derived below)
+              ++s;
+              lo = max(lo - 1, wlo); hi = min(hi + 1, whi);
+              asm volatile("" : "+s"(lo), "+s"(hi));   // (keeps the chains off v_max3/v_min3)
+              lo = max(lo, s + c_lo); hi = min(hi, c_hi - s);
+              if (__builtin_expect(lo > hi, 0)) { why = 1; continue; }
               const int wm1 = hi - lo;            // width - 1
-              ncells += (uint32_t)wm1;            // (+ 1 per score when the loop is left)
-              uint8_t* codes = nullptr;
+              uint32_t need = 0;
               if constexpr (BT) {
-                const uint32_t need = ((uint32_t)wm1 + 16u) >> 4;
+                // the row of origin bytes (before anything of this score is committed: a failure leaves the loop right here)
+                need = ((uint32_t)wm1 + 16u) >> 4;
+                code_addr += (uint64_t)(need_prev << 4);
                 if (__builtin_expect(need + WFA_ARENA_ROW_SLACK > chunk_left, 0)) {
                   ColdParams cp = cold_params();
                   const uint32_t grab = max(need + WFA_ARENA_ROW_SLACK, cp->chunk_units);
@@ -703,15 +813,23 @@ wfa_align_kernel(const WfaAlignParams p) {
                   }
                   base = block_bcast<NW>(base, bslot);
                   chunk_cur = base; chunk_left = (base == WFA_ROW_NONE) ? 0u : grab;
+                  code_addr = (uint64_t)(uintptr_t)cp->arena + (uint64_t)chunk_cur * 16u + (uint32_t)lane;
+                  need_prev = 0;
+                  if (chunk_left < need) { why = 2; continue; }
                 }
-                if (chunk_left < need) { nomem = true; break; }
-                row_s = chunk_cur; chunk_cur += need; chunk_left -= need;
+              }
+              a_m += rsb;  if (a_m == a_end) a_m = a_first;
+              a_x += rsb;  if (a_x == a_end) a_x = a_first;
+              a_oe += rsb; if (a_oe == a_end) a_oe = a_first;
+              a_ic ^= a_iswap; a_ip ^= a_iswap; a_dc ^= a_dswap; a_dp ^= a_dswap;
+              ncells += (uint32_t)wm1;            // (+ 1 per score when the loop is left)
+              if constexpr (BT) {
+                row_s = chunk_cur; chunk_cur += need; chunk_left -= need; need_prev = need;
                 // row table, buffered by lane: a new group of 64 scores starts at every multiple of 64
                 const int sl = s & 63;
                 if (sl == 0) tab[s - 64 + lane] = make_uint2((uint32_t)tabv_row, (uint32_t)tabv_lo);
                 asm("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
                     : "+v"(tabv_row), "+v"(tabv_lo) : "s"((int)row_s), "s"(lo), "s"(sl));      // (m0: scratch, the compiler sets it before each use of its own)
-                codes = p.arena + (size_t)row_s * 16;
               }
               if (__builtin_expect(s >= s_clear, 0)) {
                 // the slots written now last held scores s-dm (M) and s-2 (I, D), whose limits lay up to dm diagonals
@@ -721,104 +839,21 @@ wfa_align_kernel(const WfaAlignParams p) {
                 const uint32_t qa = (uint32_t)q << 1;
                 *(LdsRow)(qa + a_m) = (OffT)OffNull<OffT>::value;
                 *(LdsRow)(qa + a_ic) = (OffT)OffNull<OffT>::value;
-                *(LdsRow)(qa + a_ic + d_off) = (OffT)OffNull<OffT>::value;
+                *(LdsRow)(qa + a_dc) = (OffT)OffNull<OffT>::value;
               }
-              // lane bases: cell (lo + lane - 1) of every row involved; all neighbours are immediates from there
-              uint32_t vb = (uint32_t)(lane + (lo - 1)) << 1;
-              int kq = lane + lo;
-              uint32_t code_off = (uint32_t)lane;
-              int left = wm1 + 1;
-              for (;;) {
-                // (one v_add each, once per score: the empty asm keeps the compiler from re-forming them in every chunk)
-                uint32_t q_mo = vb + a_oe, q_mx = vb + a_x, q_wm = vb + a_m, q_ri = vb + a_ip, q_wi = vb + a_ic;
-                asm volatile("" : "+v"(q_mo), "+v"(q_mx), "+v"(q_wm), "+v"(q_ri), "+v"(q_wi));
-                uint32_t q_rd = q_ri + d_off, q_wd = q_wi + d_off;
-                asm volatile("" : "+v"(q_rd), "+v"(q_wd));
-                const LdsRow r_mo = (LdsRow)q_mo, r_mx = (LdsRow)q_mx, w_m = (LdsRow)q_wm;
-                const LdsRow r_i = (LdsRow)q_ri, w_i = (LdsRow)q_wi, r_d = (LdsRow)q_rd, w_d = (LdsRow)q_wd;
-                auto chunk = [&](auto uc, auto partial_tag, const unsigned long long act) {
-                  constexpr int O = decltype(uc)::value * 64;
-                  constexpr bool PARTIAL = decltype(partial_tag)::value;
-                  const int k = kq + O;
-                  const uint32_t u_ol = (uint16_t)r_mo[O], u_or = (uint16_t)r_mo[O + 2], u_ie = (uint16_t)r_i[O],
-                                 u_de = (uint16_t)r_d[O + 2], u_x = (uint16_t)r_mx[O + 1];
-                  int ins_c = max((int)((u_ol << 16) + (0x10000u | BT_M_I)), (int)((u_ie << 16) + (0x10000u | BT_M_I | BT_I_EXT)));
-                  int del_t = max((int)((u_or << 16) | BT_M_D), (int)((u_de << 16) | (BT_M_D | BT_D_EXT)));
-                  const int mis_c = (int)((u_x << 16) + (0x10000u | BT_M_X));
-                  const int mv_t = max(del_t, max(mis_c, ins_c));
-                  uint32_t code = 0;
-                  if constexpr (BT) {
-                    uint32_t c1;
-                    asm("v_bfi_b32 %0, 2, %1, %2" : "=v"(c1) : "v"(del_t), "v"(mv_t));      // bit 1 from the deletion winner
-                    asm("v_bfi_b32 %0, 1, %1, %2" : "=v"(code) : "v"(ins_c), "v"(c1));      // bit 0 from the insertion winner
-                  }
-                  const int mv0 = mv_t >> 16;
-                  const bool ok = mv_t >= 0;      // (nothing has touched a sequence end: not valid = NULL = negative)
-                  int h = mv0;
-                  const int hmax = min(plen + k, tlen);
-                  {
-                    const int v = mv0 - k;
-                    const int rem = hmax - h;
-                    uint32_t pa, ta;      // word addresses: base + 4 * (symbol index / PER)
-                    asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(pa) : "v"(v >> SH), "s"(pw_addr));
-                    asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(ta) : "v"(h >> SH), "s"(tw_addr));
-                    const uint32_t sa = (uint32_t)v << BITS, sb = (uint32_t)h << BITS;
-                    uint32_t fb, d0w;
-                    {
-                      const LdsWords pw = (LdsWords)pa; const LdsWords tw = (LdsWords)ta;
-                      d0w = __builtin_amdgcn_alignbit(pw[1], pw[0], sa) ^ __builtin_amdgcn_alignbit(tw[1], tw[0], sb);
-                      asm("v_ffbl_b32 %0, %1" : "=v"(fb) : "v"(d0w));
-                    }
-                    {
-                      int adv;
-                      asm("v_min3_i32 %0, %1, %2, %3" : "=v"(adv) : "v"((int)(fb >> BITS)), "v"(rem), "n"(PER));
-                      h += adv;
-                    }
-                    const bool more = ok & (d0w == 0u);
-                    if (__builtin_amdgcn_ballot_w64(more) != 0ull) {
-                      int togo = more ? max(rem - PER, 0) : 0;
-                      while (__builtin_amdgcn_ballot_w64(togo > 0) != 0ull) {
-                        pa += 4; ta += 4;
-                        const LdsWords pw = (LdsWords)pa; const LdsWords tw = (LdsWords)ta;
-                        const uint32_t d = __builtin_amdgcn_alignbit(pw[1], pw[0], sa) ^ __builtin_amdgcn_alignbit(tw[1], tw[0], sb);
-                        asm("v_ffbl_b32 %0, %1" : "=v"(fb) : "v"(d));
-                        const int nn = min(min((int)(fb >> BITS), PER), togo);
-                        h += nn;
-                        togo = (nn == PER) ? togo - PER : 0;
-                      }
-                    }
-                  }
-                  bool keep = ok;
-                  if constexpr (PARTIAL) {
-                    const bool active = __builtin_amdgcn_inverse_ballot_w64(act);
-                    keep &= active;
-                    ins_c = active ? ins_c : (int)0x80000000u; del_t = active ? del_t : (int)0x80000000u;
-                  }
-                  const int mv = keep ? h : OffNull<OffT>::value;
-                  touch |= __builtin_amdgcn_ballot_w64(mv == hmax);      // (NULL never equals it)
-                  w_m[O + 1] = (OffT)mv;
-                  w_i[O + 1] = (OffT)(ins_c >> 16);     // (high halves: ds_write_b16_d16_hi, no unpacking)
-                  w_d[O + 1] = (OffT)(del_t >> 16);
-                  if constexpr (BT) codes[code_off + O] = (uint8_t)code;
-                };
-                auto chunk_at = [&](auto uc) -> bool {
-                  const int n_act = left - decltype(uc)::value * 64;
-                  if (n_act >= 64) chunk(uc, std::false_type{}, 0ull);
-                  else chunk(uc, std::true_type{}, (1ull << n_act) - 1ull);
-                  return n_act > 64;
-                };
-                if (!(chunk_at(std::integral_constant<int, 0>{}) && chunk_at(std::integral_constant<int, 1>{}) &&
-                      chunk_at(std::integral_constant<int, 2>{}) && chunk_at(std::integral_constant<int, 3>{}))) break;
-                vb += 512u; kq += 256; code_off += 256u; left -= 256;
-              }
+              hot_cells(lo, wm1, (GlobalBytes)(uintptr_t)code_addr, a_oe, a_x, a_m, a_ip, a_ic, a_dp, a_dc, touch);
               block_sync<NW>();
               a_last = a_m;
-              if (touch != 0ull) {
-                // a cell sits on a sequence end: it may be the last one (wavefront_extend.c:47-67), and from the next
-                // score on values may run past the ends -- the careful path takes over
-                touched_ever = true;
-                break;
-              }
+              // a cell sits on a sequence end: it may be the last one (wavefront_extend.c:47-67), and from the next
+              // score on values may run past the ends -- the careful path takes over
+              if (touch != 0ull) why = 3;
+            } while (why == 0);
+            const bool nomem = why == 2;
+            if (why == 3) touched_ever = true;
+            if (why != 3) {
+              // the score at which the loop gave up was not computed: back to the limits of the one before
+              --s;
+              lo = max(max(lo_in - (s - s_in), wlo), s + c_lo); hi = min(min(hi_in + (s - s_in), whi), c_hi - s);
             }
             // back to the general state
             const int n_lean = s - s_in;
@@ -991,8 +1026,13 @@ wfa_align_kernel(const WfaAlignParams p) {
               }
               bool my_over = false;
               unsigned long long touch_mask = 0;
-              cells_of_score(std::true_type{}, lo, hi, codes, p_x, p_oe - 1, p_ip - 1, d_of(p_ip) + 1, out_m, out_i, out_d, BandCtx{},
-                             my_over, touch_mask);
+              if constexpr (HOT) {
+                hot_cells(lo, hi - lo, (GlobalBytes)(uintptr_t)codes + lane, lds_addr(p_oe), lds_addr(p_x), lds_addr(out_m), lds_addr(p_ip),
+                          lds_addr(out_i), lds_addr(d_of(p_ip)), lds_addr(out_d), touch_mask);
+              } else {
+                cells_of_score(std::true_type{}, lo, hi, codes, p_x, p_oe - 1, p_ip - 1, d_of(p_ip) + 1, out_m, out_i, out_d, BandCtx{},
+                               my_over, touch_mask);
+              }
               const bool wave_touch = touch_mask != 0ull;
               bool any_touch;
               if constexpr (NW == 1) {

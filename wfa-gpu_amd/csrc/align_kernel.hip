@@ -161,6 +161,8 @@ wfa_align_kernel(const WfaAlignParams p) {
   const int lane = tid & 63;
   const int dm = p.dm, de = p.de, rs = p.rs;
   constexpr int ROW_PAD = (!GLOBAL_RING && !BANDED && sizeof(OffT) == 2) ? WFA_RING_ROW_PAD : 0;     // (see wfa_device.h)
+  // the one-wavefront 16-bit LDS tier (BASELINE's short-read configs): its lean loops have a form of their own
+  constexpr bool HOT = NW == 1 && !BANDED && !GLOBAL_RING && !HYBRID && sizeof(OffT) == 2;
   const int x = p.x, oe = p.oe, e = p.e;
 
   // ---- carve LDS -----------------------------------------------------------------------------
@@ -170,7 +172,8 @@ wfa_align_kernel(const WfaAlignParams p) {
     Mr = reinterpret_cast<OffT*>(static_cast<char*>(p.gring) + (size_t)blockIdx.x * p.gring_stride);
   } else {
     Mr = reinterpret_cast<OffT*>(sp);
-    sp += (((size_t)(dm + (HYBRID ? 1 : 2) * de) * rs * sizeof(OffT)) + 15) & ~(size_t)15;
+    // (HOT: one more row, min(plen + k, tlen) per diagonal k -- how far a run on k can go)
+    sp += (((size_t)(dm + (HYBRID ? 1 : 2) * de + (HOT ? 1 : 0)) * rs * sizeof(OffT)) + 15) & ~(size_t)15;
   }
   OffT* const Dg = HYBRID ? reinterpret_cast<OffT*>(static_cast<char*>(p.gring) + (size_t)blockIdx.x * p.gring_stride) : nullptr;   // the D ring
   uint32_t* Pw = reinterpret_cast<uint32_t*>(sp);
@@ -280,6 +283,10 @@ wfa_align_kernel(const WfaAlignParams p) {
           }
         } else {
           for (int i = tid; i < cells; i += NT) Mr[i] = (OffT)OffNull<OffT>::value;
+        }
+        if constexpr (HOT) {
+          OffT* hm = Mr + cells;        // [kidx0 + k] = min(plen + k, tlen)
+          for (int i = tid; i < rs; i += NT) hm[i] = (OffT)max(min(plen + (i - kidx0), tlen), 0);
         }
       }
       if constexpr (NW == 1) book.reset();
@@ -629,33 +636,38 @@ wfa_align_kernel(const WfaAlignParams p) {
       // diagonal 0 (a_oe: M[s-o-e], a_x: M[s-x], a_ip / a_dp: I / D of s-e, a_m / a_ic / a_dc: the rows written), `codes`:
       // this lane's origin byte in the row of origin bytes (global), wm1 = hi - lo.  Same cells, values and origin bytes
       // as cells_of_score's lean form.
-      constexpr bool HOT = NW == 1 && !BANDED && !GLOBAL_RING && !HYBRID && sizeof(OffT) == 2;
       typedef __attribute__((address_space(3))) OffT* LdsRow;
       typedef __attribute__((address_space(3))) const uint32_t* LdsWords;
       typedef __attribute__((address_space(1))) uint8_t* GlobalBytes;
       const uint32_t pw_addr = lds_addr(Pw), tw_addr = lds_addr(Tw);
+      const uint32_t a_hm = lds_addr(Mr + (dm + 2 * de) * rs + (BANDED ? 0 : kidx0));      // (HOT) diagonal 0 of the run-limit row
       auto hot_cells = [&](const int lo, const int wm1, GlobalBytes codes, const uint32_t a_oe, const uint32_t a_x, const uint32_t a_m,
                            const uint32_t a_ip, const uint32_t a_ic, const uint32_t a_dp, const uint32_t a_dc, unsigned long long& touch) {
         constexpr int SH = RAW ? 2 : 4, PER = 1 << SH, BITS = RAW ? 3 : 1;
+        // Every role tag carries TB >= PER besides its origin bits (the backtrace masks them off), so that any tagged value
+        // that is valid (offset >= 0) is >= PER and v_med3(value, 0, PER) is PER for a valid cell and 0 for a NULL one.
+        constexpr uint32_t TB = 16;
+        static_assert(TB >= (uint32_t)PER && (TB & (BT_M_MASK | BT_D_EXT | BT_I_EXT)) == 0, "tag base");
         // a group of up to four chunks from lane bases vb (cell lo + lane - 1 of every row involved: all neighbours are
         // immediates from there), kq (this lane's diagonal) and codes; returns whether the row goes on beyond the group
         auto group = [&](const uint32_t vb, const int kq, GlobalBytes codes, const int left) -> bool {
           bool more_groups;
           // (one v_add each, once per score: the empty asm keeps the compiler from re-forming them in every chunk)
           uint32_t q_mo = vb + a_oe, q_mx = vb + a_x, q_wm = vb + a_m, q_ri = vb + a_ip, q_wi = vb + a_ic;
-          uint32_t q_rd = vb + a_dp, q_wd = vb + a_dc;
-          asm volatile("" : "+v"(q_mo), "+v"(q_mx), "+v"(q_wm), "+v"(q_ri), "+v"(q_wi), "+v"(q_rd), "+v"(q_wd));
+          uint32_t q_rd = vb + a_dp, q_wd = vb + a_dc, q_hm = vb + a_hm;
+          asm volatile("" : "+v"(q_mo), "+v"(q_mx), "+v"(q_wm), "+v"(q_ri), "+v"(q_wi), "+v"(q_rd), "+v"(q_wd), "+v"(q_hm));
           const LdsRow r_mo = (LdsRow)q_mo, r_mx = (LdsRow)q_mx, w_m = (LdsRow)q_wm;
-          const LdsRow r_i = (LdsRow)q_ri, w_i = (LdsRow)q_wi, r_d = (LdsRow)q_rd, w_d = (LdsRow)q_wd;
+          const LdsRow r_i = (LdsRow)q_ri, w_i = (LdsRow)q_wi, r_d = (LdsRow)q_rd, w_d = (LdsRow)q_wd, r_hm = (LdsRow)q_hm;
           auto chunk = [&](auto uc, auto partial_tag, const unsigned long long act) {
             constexpr int O = decltype(uc)::value * 64;
             constexpr bool PARTIAL = decltype(partial_tag)::value;
             const int k = kq + O;
             const uint32_t u_ol = (uint16_t)r_mo[O], u_or = (uint16_t)r_mo[O + 2], u_ie = (uint16_t)r_i[O],
                            u_de = (uint16_t)r_d[O + 2], u_x = (uint16_t)r_mx[O + 1];
-            int ins_c = max((int)((u_ol << 16) + (0x10000u | BT_M_I)), (int)((u_ie << 16) + (0x10000u | BT_M_I | BT_I_EXT)));
-            int del_t = max((int)((u_or << 16) | BT_M_D), (int)((u_de << 16) | (BT_M_D | BT_D_EXT)));
-            const int mis_c = (int)((u_x << 16) + (0x10000u | BT_M_X));
+            const int hmax = (int)(uint16_t)r_hm[O + 1];      // min(plen + k, tlen): how far a run on this diagonal can go
+            int ins_c = max((int)((u_ol << 16) + (0x10000u | TB | BT_M_I)), (int)((u_ie << 16) + (0x10000u | TB | BT_M_I | BT_I_EXT)));
+            int del_t = max((int)((u_or << 16) | (TB | BT_M_D)), (int)((u_de << 16) | (TB | BT_M_D | BT_D_EXT)));
+            const int mis_c = (int)((u_x << 16) + (0x10000u | TB | BT_M_X));
             const int mv_t = max(del_t, max(mis_c, ins_c));
             uint32_t code = 0;
             if constexpr (BT) {
@@ -664,9 +676,11 @@ wfa_align_kernel(const WfaAlignParams p) {
               asm("v_bfi_b32 %0, 1, %1, %2" : "=v"(code) : "v"(ins_c), "v"(c1));      // bit 0 from the insertion winner
             }
             const int mv0 = mv_t >> 16;
-            const bool ok = mv_t >= 0;      // (nothing has touched a sequence end: not valid = NULL = negative)
+            // Nothing has touched a sequence end: "not valid" = NULL = negative.  A NULL cell gets a run length of 0 and is
+            // stored as it is -- NULL plus at most one per score, which stays negative for every score 16 bits can hold.
+            int cap;
+            asm("v_med3_i32 %0, %1, 0, %2" : "=v"(cap) : "v"(mv_t), "n"(PER));
             int h = mv0;
-            const int hmax = min(plen + k, tlen);
             {
               const int v = mv0 - k;
               const int rem = hmax - h;
@@ -674,18 +688,17 @@ wfa_align_kernel(const WfaAlignParams p) {
               asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(pa) : "v"(v >> SH), "s"(pw_addr));
               asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(ta) : "v"(h >> SH), "s"(tw_addr));
               const uint32_t sa = (uint32_t)v << BITS, sb = (uint32_t)h << BITS;
-              uint32_t fb, d0w;
+              uint32_t fb;
               {
                 const LdsWords pw = (LdsWords)pa; const LdsWords tw = (LdsWords)ta;
-                d0w = __builtin_amdgcn_alignbit(pw[1], pw[0], sa) ^ __builtin_amdgcn_alignbit(tw[1], tw[0], sb);
-                asm("v_ffbl_b32 %0, %1" : "=v"(fb) : "v"(d0w));
+                const uint32_t d0w = __builtin_amdgcn_alignbit(pw[1], pw[0], sa) ^ __builtin_amdgcn_alignbit(tw[1], tw[0], sb);
+                asm("v_ffbl_b32 %0, %1" : "=v"(fb) : "v"(d0w));       // (0xFFFFFFFF for 0: "all equal" is a huge count)
               }
-              {
-                int adv;
-                asm("v_min3_i32 %0, %1, %2, %3" : "=v"(adv) : "v"((int)(fb >> BITS)), "v"(rem), "n"(PER));
-                h += adv;
-              }
-              const bool more = ok & (d0w == 0u);
+              int adv;
+              asm("v_min3_i32 %0, %1, %2, %3" : "=v"(adv) : "v"((int)(fb >> BITS)), "v"(rem), "v"(cap));
+              h += adv;
+              // a whole word matched (a valid cell with at least a word to go): the run may go on
+              const bool more = adv == PER;
               if (__builtin_amdgcn_ballot_w64(more) != 0ull) {
                 int togo = more ? max(rem - PER, 0) : 0;
                 while (__builtin_amdgcn_ballot_w64(togo > 0) != 0ull) {
@@ -699,14 +712,13 @@ wfa_align_kernel(const WfaAlignParams p) {
                 }
               }
             }
-            bool keep = ok;
+            int mv = h;
             if constexpr (PARTIAL) {
               const bool active = __builtin_amdgcn_inverse_ballot_w64(act);
-              keep &= active;
+              mv = active ? h : OffNull<OffT>::value;
               ins_c = active ? ins_c : (int)0x80000000u; del_t = active ? del_t : (int)0x80000000u;
             }
-            const int mv = keep ? h : OffNull<OffT>::value;
-            touch |= __builtin_amdgcn_ballot_w64(mv == hmax);      // (NULL never equals it)
+            touch |= __builtin_amdgcn_ballot_w64(mv == hmax);      // (a NULL never equals it)
             w_m[O + 1] = (OffT)mv;
             w_i[O + 1] = (OffT)(ins_c >> 16);     // (high halves: ds_write_b16_d16_hi, no unpacking)
             w_d[O + 1] = (OffT)(del_t >> 16);
@@ -1382,7 +1394,7 @@ int occ_tier_banded(int tier, size_t lds) {
 size_t wfa_align_lds_bytes(const WfaAlignParams& p, int tier) {
   size_t ring = 0;
   if (tier == 4) ring = (((size_t)(p.dm + p.de) * p.rs * sizeof(int16_t)) + 15) & ~(size_t)15;       // hybrid: M and I rings
-  else if (tier != 3) ring = (((size_t)(p.dm + 2 * p.de) * p.rs * sizeof(int16_t)) + 15) & ~(size_t)15;
+  else if (tier != 3) ring = (((size_t)(p.dm + 2 * p.de + ((tier == 0 && p.band_width <= 0) ? 1 : 0)) * p.rs * sizeof(int16_t)) + 15) & ~(size_t)15;     // (+ the run-limit row of the one-wavefront exact kernels)
   const size_t seq = (size_t)2 * p.seq_words_cap * 4;
   // reduction slots [24] + broadcast [2] + (NW > 1) row book [3][book]
   const size_t bk = (size_t)p.book_mask + 1;

@@ -442,15 +442,20 @@ wfa_align_kernel(const WfaAlignParams p) {
           // of those that do not).  Lanes beyond `hi` run along and store NULL into their cells (the rows are padded by
           // one chunk for that, and NULL is what a cell outside a row's limits has to hold anyway) and a meaningless
           // origin byte into the slack the arena keeps behind every row.
+          // (every role tag carries TB >= PER besides its origin bits -- the backtrace masks them off --, so a valid tagged
+          // value is >= PER and v_med3(value, 0, PER) is PER for a valid cell, 0 for a NULL one: the run length of a NULL
+          // cell is 0 and it is stored as it is, NULL plus at most one per score, negative for every score 16 bits hold)
+          constexpr uint32_t TB = 16;
+          static_assert(TB >= (uint32_t)PER && (TB & (BT_M_MASK | BT_D_EXT | BT_I_EXT)) == 0, "tag base");
           auto chunk = [&](auto uc, auto partial_tag, const unsigned long long act) {
             constexpr int O = decltype(uc)::value * NT;
             constexpr bool PARTIAL = decltype(partial_tag)::value;
             const int k = kq + O;
             const uint32_t u_ol = (uint16_t)q_mo[O], u_or = (uint16_t)q_mo[O + 2], u_ie = (uint16_t)q_ie[O],
                            u_de = (uint16_t)q_de[O], u_x = (uint16_t)q_mx[O];
-            int ins_c = max((int)((u_ol << 16) + (0x10000u | BT_M_I)), (int)((u_ie << 16) + (0x10000u | BT_M_I | BT_I_EXT)));
-            int del_t = max((int)((u_or << 16) | BT_M_D), (int)((u_de << 16) | (BT_M_D | BT_D_EXT)));
-            const int mis_c = (int)((u_x << 16) + (0x10000u | BT_M_X));
+            int ins_c = max((int)((u_ol << 16) + (0x10000u | TB | BT_M_I)), (int)((u_ie << 16) + (0x10000u | TB | BT_M_I | BT_I_EXT)));
+            int del_t = max((int)((u_or << 16) | (TB | BT_M_D)), (int)((u_de << 16) | (TB | BT_M_D | BT_D_EXT)));
+            const int mis_c = (int)((u_x << 16) + (0x10000u | TB | BT_M_X));
             const int mv_t = max(del_t, max(mis_c, ins_c));
             uint32_t code = 0;
             if constexpr (BT) {
@@ -462,7 +467,8 @@ wfa_align_kernel(const WfaAlignParams p) {
             // No cell has touched a sequence end so far, so no candidate lies beyond one (M, I and D of the earlier
             // scores are all < min(plen + k, tlen), and a candidate is at most one more): "not valid" just means NULL,
             // i.e. negative.
-            const bool ok = mv_t >= 0;
+            int cap;
+            asm("v_med3_i32 %0, %1, 0, %2" : "=v"(cap) : "v"(mv_t), "n"(PER));
             // extend = longest common prefix from (v,h) (wavefront_extend.c:174-199), see the notes in the general loop below
             int h = mv0;
             const int hmax = min(plen + k, tlen);
@@ -472,19 +478,17 @@ wfa_align_kernel(const WfaAlignParams p) {
               const char* pp = reinterpret_cast<const char*>(Pw + (v >> SH));
               const char* tp = reinterpret_cast<const char*>(Tw + (h >> SH));
               const uint32_t sa = (uint32_t)v << BITS, sb = (uint32_t)h << BITS;
-              uint32_t fb, d0w;
+              uint32_t fb;
               {
                 const uint32_t* pw = reinterpret_cast<const uint32_t*>(pp);
                 const uint32_t* tw = reinterpret_cast<const uint32_t*>(tp);
-                d0w = __builtin_amdgcn_alignbit(pw[1], pw[0], sa) ^ __builtin_amdgcn_alignbit(tw[1], tw[0], sb);
+                const uint32_t d0w = __builtin_amdgcn_alignbit(pw[1], pw[0], sa) ^ __builtin_amdgcn_alignbit(tw[1], tw[0], sb);
                 asm("v_ffbl_b32 %0, %1" : "=v"(fb) : "v"(d0w));
               }
-              {
-                int adv;
-                asm("v_min3_i32 %0, %1, %2, %3" : "=v"(adv) : "v"((int)(fb >> BITS)), "v"(rem), "n"(PER));
-                h += adv;
-              }
-              const bool more = ok & (d0w == 0u);
+              int adv;
+              asm("v_min3_i32 %0, %1, %2, %3" : "=v"(adv) : "v"((int)(fb >> BITS)), "v"(rem), "v"(cap));
+              h += adv;
+              const bool more = adv == PER;       // a whole word matched (a valid cell with at least a word to go)
               if (__builtin_amdgcn_ballot_w64(more) != 0ull) {
                 int left = more ? max(rem - PER, 0) : 0;
                 while (__builtin_amdgcn_ballot_w64(left > 0) != 0ull) {
@@ -499,14 +503,13 @@ wfa_align_kernel(const WfaAlignParams p) {
                 }
               }
             }
-            bool keep = ok;
+            int mv = h;
             if constexpr (PARTIAL) {
               const bool active = __builtin_amdgcn_inverse_ballot_w64(act);
-              keep &= active;
+              mv = active ? h : OffNull<OffT>::value;
               ins_c = active ? ins_c : (int)0x80000000u; del_t = active ? del_t : (int)0x80000000u;
             }
-            const int mv = keep ? h : OffNull<OffT>::value;
-            wave_touch |= __builtin_amdgcn_ballot_w64(mv == hmax);      // (NULL never equals it)
+            wave_touch |= __builtin_amdgcn_ballot_w64(mv == hmax);      // (a NULL never equals it)
             w_m[O] = (OffT)mv;
             w_i[O] = (OffT)(ins_c >> 16);     // (high halves: ds_write_b16_d16_hi, no unpacking)
             w_d[O] = (OffT)(del_t >> 16);

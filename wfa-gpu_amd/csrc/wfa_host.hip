@@ -495,7 +495,14 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
     if (!want) {
       want = (size_t)std::min<double>(est_pair_bytes * 1.1 * n, 0.45 * (double)(free_b + c->arena.cap));
       want = std::max<size_t>(want, (size_t)64 << 20);
-      if (c->arena_limit) want = std::min(want, std::max<size_t>(c->arena_limit, (size_t)64 << 20));
+      if (c->arena_limit) {
+        // (the starting cap keeps first calls cheap; it gives way, up to the maximum, when it could not even hold the
+        // pairs that are in flight at once -- long reads: 1024 x 30 kbp @ 10 % went through five failed passes and
+        // re-allocations, ~2 s, on a process's first call)
+        const double inflight = std::min<double>(n, 2.0 * c->num_cus) * est_pair_bytes * 2.0;
+        const size_t lim = std::max<size_t>(c->arena_limit, (size_t)std::min<double>((double)c->arena_limit_max, inflight));
+        want = std::min(want, std::max<size_t>(lim, (size_t)64 << 20));
+      }
     }
     want = std::min<size_t>(want, ((size_t)1 << 36) - 4096);
     if (c->arena.cap < want && c->arena.ensure(want, st)) return -1;
@@ -513,6 +520,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
 
   float align_ms = 0.f, trace_ms = 0.f;
   uint32_t grid_cap = UINT32_MAX;   // lowered when a pass makes no progress for lack of arena
+  unsigned long long arena_units_call = 0;
   unsigned long long text_used = 0;
   int rc = 0;
 
@@ -714,6 +722,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
                          static_cast<uint32_t*>(c->status.p));
     }
     c->stats.arena_units = std::max<unsigned long long>(c->stats.arena_units, c->h_counters[CT_ARENA]);
+    arena_units_call += std::min<unsigned long long>(c->h_counters[CT_ARENA], ap.arena_units);      // (over all passes)
     // refine the per-pair estimate from this pass, then queue what was not launched behind the re-runs
     if (compute_cigar && n_pass - n_nomem >= 65536u)   // (few pairs per workgroup: refill slack would dominate)
       est_pair_bytes = std::max(256.0, 1.15 * 16.0 * (double)c->h_counters[CT_ARENA] / (double)(n_pass - n_nomem));
@@ -855,7 +864,9 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   // several arena-bound passes under a growable cap: the next call may use twice the arena
   if (compute_cigar && c->arena_limit && c->arena_limit_max > c->arena_limit && c->stats.sub_batches > 1 &&
       c->arena.cap >= c->arena_limit - ((size_t)1 << 20))
-    c->arena_limit = std::min(c->arena_limit_max, 2 * c->arena_limit);
+    // (straight to what this call used over all its passes, if that is more than twice the cap: every re-allocation
+    // of a multi-GiB arena is paid for again when the fresh memory is first written)
+    c->arena_limit = std::min(c->arena_limit_max, std::max<size_t>(2 * c->arena_limit, (size_t)((double)arena_units_call * 16.0 * 1.1)));
   c->stats.auto_budget *= pen_scale;
   c->stats.align_ms = align_ms;
   c->stats.trace_ms = trace_ms;

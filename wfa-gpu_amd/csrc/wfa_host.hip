@@ -522,6 +522,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
 
   float align_ms = 0.f, trace_ms = 0.f;
   uint32_t grid_cap = UINT32_MAX;   // lowered when a pass makes no progress for lack of arena
+  bool cigar_now = compute_cigar;   // (false while the sample of the auto-budget step runs: scores only)
   unsigned long long arena_units_call = 0;
   unsigned long long text_used = 0;
   int rc = 0;
@@ -543,7 +544,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
     c->stats.sub_batches++;
     // pairs launched in this pass: what the arena is expected to hold (at least one wave of workgroups)
     uint32_t n_pass = n_pending;
-    if (compute_cigar) {
+    if (cigar_now) {
       const double fit = (double)c->arena.cap / std::max(1.0, est_pair_bytes);
       n_pass = (uint32_t)std::min<double>(n_pending, std::max<double>(fit, 4.0 * c->num_cus));
     }
@@ -561,9 +562,9 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       // banded first attempt (packed class only); whatever it cannot finish goes to the exact tiers
       ap.band_width = (want_band && allow_band && !raw && round == 0 && !budgets) ? band_width : 0;
       ap.band_period = band;
-      if (ap.band_width > 0 && !plan_tier(c, ap, std::min(max_score, 30000), max_len, compute_cigar, raw, &tp)) ap.band_width = 0;
+      if (ap.band_width > 0 && !plan_tier(c, ap, std::min(max_score, 30000), max_len, cigar_now, raw, &tp)) ap.band_width = 0;
       if (ap.band_width > 0) c->stats.pairs_banded += n_cur;
-      if (ap.band_width == 0 && !plan_tier(c, ap, max_score, max_len, compute_cigar, raw, &tp)) {
+      if (ap.band_width == 0 && !plan_tier(c, ap, max_score, max_len, cigar_now, raw, &tp)) {
         fprintf(stderr, "[!] ERROR: sequences of %u bases do not fit the LDS staging area\n", max_len);
         return -1;
       }
@@ -581,12 +582,12 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       // arena refill size: as large as lets every workgroup hold a few chunks -- each refill is a
       // returning atomic on ONE word (~88 per microsecond on this chip), which at 4 KiB refills
       // was the whole kernel time
-      if (compute_cigar) ap.chunk_units = (uint32_t)std::min<unsigned long long>(env_chunk ? (unsigned)atoi(env_chunk) : 4096u, std::max<unsigned long long>(256, ap.arena_units / (4ull * (unsigned)grid)));
+      if (cigar_now) ap.chunk_units = (uint32_t)std::min<unsigned long long>(env_chunk ? (unsigned)atoi(env_chunk) : 4096u, std::max<unsigned long long>(256, ap.arena_units / (4ull * (unsigned)grid)));
       { const char* es = getenv("WFAGPU_SHARDS"); ap.work_shards = es ? (uint32_t)atoi(es) : 8u; }
       if (zero_counter(c, CT_LCELLS, 2)) return -1;   // CT_LCELLS and CT_LIST
       HIP_TRY(hipMemsetAsync(c->work_ctr.p, 0, 8 * 64, st));
       HIP_TRY(hipEventRecord(c->ev_a0, st));
-      wfa_launch_align(ap, tp.tier, compute_cigar, raw, grid, st);
+      wfa_launch_align(ap, tp.tier, cigar_now, raw, grid, st);
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipEventRecord(c->ev_a1, st));
       uint32_t* nxt = spare[flip]; flip ^= 1;
@@ -625,7 +626,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
     LAUNCH_K(k_trace_bounds, dim3(std::min<uint32_t>(cdiv(n_pass, 256), 1024u)), dim3(256), 0, st, (const uint32_t*)pending, n_pass,
                        static_cast<const uint32_t*>(c->status.p), (const int32_t*)d_scores,
                        static_cast<const uint32_t*>(c->cells.p), std::min(pen.x, pen.e), ct);
-    if (compute_cigar) {
+    if (cigar_now) {
       if (read_counters(c)) return -1;       // (score-only calls need none of these sums before the end of the call)
       const unsigned long long ops_need = c->h_counters[CT_SUM_OPS] + 256;
       const unsigned long long text_need = text_used + c->h_counters[CT_SUM_TEXT] + 256;
@@ -684,7 +685,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
     }
     // ---- pairs that ran out of arena go into the next pass (CIGAR calls only: score-only calls have no arena) ----
     uint32_t* nxt_pending = (pending == alt0) ? alt1 : alt0;
-    if (compute_cigar) {
+    if (cigar_now) {
       if (zero_counter(c, CT_LIST)) return -1;
       LAUNCH_K(k_compact, dim3(cdiv(n_pass, 1024)), dim3(1024), 0, st, (const uint32_t*)pending, n_pass,
                          static_cast<const uint32_t*>(c->status.p), MASK(WFA_ST_NOMEM), nxt_pending, ct + CT_LIST);
@@ -726,7 +727,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
     c->stats.arena_units = std::max<unsigned long long>(c->stats.arena_units, c->h_counters[CT_ARENA]);
     arena_units_call += std::min<unsigned long long>(c->h_counters[CT_ARENA], ap.arena_units);      // (over all passes)
     // refine the per-pair estimate from this pass, then queue what was not launched behind the re-runs
-    if (compute_cigar && n_pass - n_nomem >= 65536u)   // (few pairs per workgroup: refill slack would dominate)
+    if (cigar_now && n_pass - n_nomem >= 65536u)   // (few pairs per workgroup: refill slack would dominate)
       est_pair_bytes = std::max(256.0, 1.15 * 16.0 * (double)c->h_counters[CT_ARENA] / (double)(n_pass - n_nomem));
     if (n_pending > n_pass)
       HIP_TRY(hipMemcpyAsync(nxt_pending + n_nomem, pending + n_pass, (size_t)4 * (n_pending - n_pass), hipMemcpyDeviceToDevice, st));
@@ -802,8 +803,13 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         if (c->list_e.ensure((size_t)4 * n, st)) return -1;
         LAUNCH_K(k_sample, dim3(cdiv(n_s, 256)), dim3(256), 0, st, (const uint32_t*)pending, n_s, stride_s, static_cast<uint32_t*>(c->sample.p));
         // (leftovers of the sampled run ping-pong between list_d and list_e; list_c keeps the bucket)
-        if (run_list(static_cast<uint32_t*>(c->sample.p), n_s, raw, nullptr, max_error, static_cast<uint32_t*>(c->list_d.p),
-                     static_cast<uint32_t*>(c->list_e.p), /*allow_band=*/false)) return -1;
+        // The sample only has to yield scores: it runs without backtrace (no arena, no trace launches) and its pairs stay
+        // in the bucket -- 0.4 % of the batch aligned twice is cheaper than a separate backtrace pass and a list compaction.
+        cigar_now = false;
+        const int rc_s = run_list(static_cast<uint32_t*>(c->sample.p), n_s, raw, nullptr, max_error, static_cast<uint32_t*>(c->list_d.p),
+                                  static_cast<uint32_t*>(c->list_e.p), /*allow_band=*/false);
+        cigar_now = compute_cigar;
+        if (rc_s) return -1;
         LAUNCH_K(k_ratio, dim3(cdiv(n_s, 256)), dim3(256), 0, st, static_cast<const uint32_t*>(c->sample.p), n_s,
                            static_cast<const uint32_t*>(c->status.p), (const int32_t*)d_scores, ap.meta, static_cast<int32_t*>(c->ratio.p));
         std::vector<int32_t> hr(n_s);
@@ -824,14 +830,19 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
           if (slot < 0 && c->n_saved_q < 8) slot = c->n_saved_q++;
           if (slot >= 0) c->saved_q[slot] = {bucket_hi, q, pen.x, pen.o, pen.e, max_error};
         }
-        // the sampled pairs are done: drop them from the bucket's list
-        uint32_t* rest = static_cast<uint32_t*>(c->list_e.p);
-        if (zero_counter(c, CT_LIST)) return -1;
-        LAUNCH_K(k_compact, dim3(cdiv(n_pending, 1024)), dim3(1024), 0, st, (const uint32_t*)pending, n_pending,
-                           static_cast<const uint32_t*>(c->status.p), class_mask, rest, ct + CT_LIST);
-        if (read_counters(c)) return -1;
-        n_pending = (uint32_t)c->h_counters[CT_LIST];
-        HIP_TRY(hipMemcpyAsync(pending, rest, (size_t)4 * n_pending, hipMemcpyDeviceToDevice, st));
+        if (compute_cigar) {
+          // the sampled pairs go through the bucket's run like everybody else
+          LAUNCH_K(k_set_pending, dim3(cdiv(n_s, 256)), dim3(256), 0, st, static_cast<const uint32_t*>(c->sample.p), n_s, static_cast<uint32_t*>(c->status.p));
+        } else {
+          // score-only call: the sampled pairs are done, drop them from the bucket's list
+          uint32_t* rest = static_cast<uint32_t*>(c->list_e.p);
+          if (zero_counter(c, CT_LIST)) return -1;
+          LAUNCH_K(k_compact, dim3(cdiv(n_pending, 1024)), dim3(1024), 0, st, (const uint32_t*)pending, n_pending,
+                             static_cast<const uint32_t*>(c->status.p), class_mask, rest, ct + CT_LIST);
+          if (read_counters(c)) return -1;
+          n_pending = (uint32_t)c->h_counters[CT_LIST];
+          HIP_TRY(hipMemcpyAsync(pending, rest, (size_t)4 * n_pending, hipMemcpyDeviceToDevice, st));
+        }
       }
       if (want_band && budgets && 2 * window_width(budget_cap, pen.o, pen.e, max_len) > 5 * band_width) {
         budgets = nullptr; budget_cap = max_error;       // wide wavefronts: the band is worth having

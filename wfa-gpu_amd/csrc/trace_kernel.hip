@@ -106,13 +106,23 @@ struct RleSink {
   char op;
   int x, o, e;    // penalties: the gap-affine cost of the emitted items is accumulated while writing
   int cost;
+  bool words;     // the slot at `out` is this lane's own up to `cap`: an item may be stored as one (unaligned) 32-bit word
   __device__ __forceinline__ void flush() {
     if (run == 0) return;
     const int nd = dec_digits(run);
     if (out && len + (uint32_t)nd + 2u <= cap) {
-      uint32_t r = run;
-      for (int i = nd - 1; i >= 0; --i) { out[len + i] = (char)('0' + r % 10); r /= 10; }
-      out[len + nd] = op;
+      if (words && run < 1000u && len + 4u <= cap) {
+        // up to three digits and the operation, assembled in a register (branch-free: the lanes of a wavefront hold
+        // runs of every length) and written with one store; the bytes beyond the item belong to the next one
+        const uint32_t d2 = run / 100u, r2 = run - 100u * d2, d1 = r2 / 10u, d0 = r2 - 10u * d1;
+        const uint32_t w4 = (0x30u + d2) | ((0x30u + d1) << 8) | ((0x30u + d0) << 16) | ((uint32_t)(uint8_t)op << 24);
+        const uint32_t w = w4 >> (8u * (uint32_t)(3 - nd));
+        __builtin_memcpy(out + len, &w, 4);
+      } else {
+        uint32_t r = run;
+        for (int i = nd - 1; i >= 0; --i) { out[len + i] = (char)('0' + r % 10); r /= 10; }
+        out[len + nd] = op;
+      }
     }
     // (utils/verification.c:91-146 of the reference: a new gap wherever the operation changes)
     if (op == 'X') cost += x * (int)run;
@@ -130,8 +140,8 @@ struct RleSink {
 template <bool RAW, typename PV, typename TV>
 __device__ __forceinline__ uint32_t replay_views(const uint8_t* ops, uint32_t nops, PV& Pw, TV& Tw,
                                                  int plen, int tlen, char* out, int x, int o, int e, int* cost,
-                                                 uint32_t out_cap = 0xFFFFFFFFu) {
-  RleSink sink{out, out_cap, 0, 0, 0, x, o, e, 0};
+                                                 uint32_t out_cap = 0xFFFFFFFFu, bool words = false) {
+  RleSink sink{out, out_cap, 0, 0, 0, x, o, e, 0, words};
   int v = 0, h = 0;
   int n = lcp_seq<RAW>(Pw, Tw, plen, tlen, v, h);
   sink.push('M', (uint32_t)n); v += n; h += n;
@@ -163,9 +173,9 @@ __device__ __forceinline__ uint32_t replay_views(const uint8_t* ops, uint32_t no
 template <bool RAW>
 __device__ __forceinline__ uint32_t replay(const uint8_t* ops, uint32_t nops, const uint32_t* Pw, const uint32_t* Tw,
                                            int plen, int tlen, char* out, int x, int o, int e, int* cost,
-                                           uint32_t out_cap = 0xFFFFFFFFu) {
+                                           uint32_t out_cap = 0xFFFFFFFFu, bool words = false) {
   SeqDirect pv{Pw}, tv{Tw};
-  return replay_views<RAW>(ops, nops, pv, tv, plen, tlen, out, x, o, e, cost, out_cap);
+  return replay_views<RAW>(ops, nops, pv, tv, plen, tlen, out, x, o, e, cost, out_cap, words);
 }
 
 constexpr int TRACE_THREADS = 64;
@@ -340,13 +350,34 @@ __global__ void __launch_bounds__(TRACE_THREADS) wfa_emit_kernel(const WfaTraceP
     const int sh = p.raw ? 2 : 4;
     const int pw = active ? ((plen + (1 << sh) - 1) >> sh) + 1 : 0, tw = active ? ((tlen + (1 << sh) - 1) >> sh) + 1 : 0;
     const int stride = p.seq_lds_stride;   // odd number of words per lane
-    for (int j = 0; j < 64; ++j) {
-      const uint32_t* gp = reinterpret_cast<const uint32_t*>(shfl64(reinterpret_cast<unsigned long long>(Pw), j));
-      const uint32_t* gt = reinterpret_cast<const uint32_t*>(shfl64(reinterpret_cast<unsigned long long>(Tw), j));
-      const int pwj = __shfl(pw, j), twj = __shfl(tw, j);
-      uint32_t* dst = seq_lds + (size_t)j * stride;
-      for (int i = lane; i < pwj; i += 64) dst[i] = gp[i];
-      for (int i = lane; i < twj; i += 64) dst[pwj + i] = gt[i];
+    // Eight pairs at a time: all sixteen loads of a round are issued before the first LDS store (one pair per
+    // iteration waited a full memory round trip per load: 128 of them in a row, half of this kernel's time).
+    constexpr int SG = 8;
+    for (int j0 = 0; j0 < 64; j0 += SG) {
+      const uint32_t* gp[SG]; const uint32_t* gt[SG]; int pwj[SG], twj[SG];
+      int maxw = 0;
+#pragma unroll
+      for (int u = 0; u < SG; ++u) {
+        const int j = j0 + u;     // (uniform: the lanes' values come over as scalars)
+        gp[u] = reinterpret_cast<const uint32_t*>(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(reinterpret_cast<unsigned long long>(Pw) >> 32), j) << 32) |
+                                                  (uint32_t)__builtin_amdgcn_readlane((int)reinterpret_cast<unsigned long long>(Pw), j));
+        gt[u] = reinterpret_cast<const uint32_t*>(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(reinterpret_cast<unsigned long long>(Tw) >> 32), j) << 32) |
+                                                  (uint32_t)__builtin_amdgcn_readlane((int)reinterpret_cast<unsigned long long>(Tw), j));
+        pwj[u] = __builtin_amdgcn_readlane(pw, j); twj[u] = __builtin_amdgcn_readlane(tw, j);
+        maxw = max(maxw, max(pwj[u], twj[u]));
+      }
+      for (int i0 = 0; i0 < maxw; i0 += 64) {
+        const int i = i0 + lane;
+        uint32_t a[SG], b[SG];
+#pragma unroll
+        for (int u = 0; u < SG; ++u) { a[u] = i < pwj[u] ? gp[u][i] : 0u; b[u] = i < twj[u] ? gt[u][i] : 0u; }
+#pragma unroll
+        for (int u = 0; u < SG; ++u) {
+          uint32_t* dst = seq_lds + (size_t)(j0 + u) * stride;
+          if (i < pwj[u]) dst[i] = a[u];
+          if (i < twj[u]) dst[pwj[u] + i] = b[u];
+        }
+      }
     }
     __syncthreads();
     Pw = seq_lds + (size_t)lane * stride;
@@ -363,8 +394,8 @@ __global__ void __launch_bounds__(TRACE_THREADS) wfa_emit_kernel(const WfaTraceP
       uint32_t len = 0xFFFFFFFFu;
       if (!fail) {
         int cost = 0;
-        len = p.raw ? replay<true>(q, nops, Pw, Tw, plen, tlen, p.text_scratch + s_off, p.x, p.oe - p.e, p.e, &cost, bound)
-                    : replay<false>(q, nops, Pw, Tw, plen, tlen, p.text_scratch + s_off, p.x, p.oe - p.e, p.e, &cost, bound);
+        len = p.raw ? replay<true>(q, nops, Pw, Tw, plen, tlen, p.text_scratch + s_off, p.x, p.oe - p.e, p.e, &cost, bound, true)
+                    : replay<false>(q, nops, Pw, Tw, plen, tlen, p.text_scratch + s_off, p.x, p.oe - p.e, p.e, &cost, bound, true);
         if (len != 0xFFFFFFFFu && len + 1u > bound) len = 0xFFFFFFFFu;
         if (len != 0xFFFFFFFFu && cost != p.score[pair]) {
           if (p.score_fix) p.score_fix[pair] = cost;

@@ -452,12 +452,32 @@ __global__ void __launch_bounds__(TRACE_THREADS) wfa_text_compact_kernel(const W
   const uint32_t need = len != 0xFFFFFFFFu ? len + 1u : 0u;
   const unsigned long long dst = wave_alloc(p.text_top, need, lane);
   if (need && dst + need > p.text_cap) len = 0xFFFFFFFFu;
-  for (int j = 0; j < 64; ++j) {
+  // Eight texts at a time, eight lanes each, 32-bit words (unaligned on both sides), up to eight words per lane loaded
+  // before the first store: a text was copied byte-wise by the whole wavefront, one load-store round trip after the other.
+  const int grp = lane >> 3, sub = lane & 7;
+  for (int j0 = 0; j0 < 64; j0 += 8) {
+    const int j = j0 + grp;
     const uint32_t nj = __shfl(len != 0xFFFFFFFFu ? len + 1u : 0u, j);
-    if (nj == 0) continue;
     const char* sj = p.text_scratch + shfl64(src, j);
     char* dj = p.text + shfl64(dst, j);
-    for (uint32_t t = lane; t < nj; t += 64) dj[t] = sj[t];
+    const uint32_t nmax = __builtin_amdgcn_readfirstlane(max(max(__shfl(nj, 0 * 8), __shfl(nj, 1 * 8)), max(max(__shfl(nj, 2 * 8), __shfl(nj, 3 * 8)),
+                                                        max(max(__shfl(nj, 4 * 8), __shfl(nj, 5 * 8)), max(__shfl(nj, 6 * 8), __shfl(nj, 7 * 8))))));
+    for (uint32_t b0 = 0; b0 < nmax; b0 += 256u) {
+      uint32_t w[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const uint32_t t = b0 + 4u * (uint32_t)sub + 32u * (uint32_t)u;
+        w[u] = 0;
+        if (t + 4u <= nj) __builtin_memcpy(&w[u], sj + t, 4);
+        else if (t < nj) { for (uint32_t q = t; q < nj; ++q) w[u] |= (uint32_t)(uint8_t)sj[q] << (8u * (q - t)); }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const uint32_t t = b0 + 4u * (uint32_t)sub + 32u * (uint32_t)u;
+        if (t + 4u <= nj) __builtin_memcpy(dj + t, &w[u], 4);
+        else if (t < nj) { for (uint32_t q = t; q < nj; ++q) dj[q] = (char)(w[u] >> (8u * (q - t))); }
+      }
+    }
   }
   if (active) {
     p.cigar_off[pair] = len != 0xFFFFFFFFu ? dst : 0ull;

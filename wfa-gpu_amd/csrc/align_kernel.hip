@@ -447,12 +447,13 @@ wfa_align_kernel(const WfaAlignParams p) {
           // cell is 0 and it is stored as it is, NULL plus at most one per score, negative for every score 16 bits hold)
           constexpr uint32_t TB = 16;
           static_assert(TB >= (uint32_t)PER && (TB & (BT_M_MASK | BT_D_EXT | BT_I_EXT)) == 0, "tag base");
+          uint32_t d_pre[4] = {0, 0, 0, 0};      // (hybrid ring) D[s-e][k+1] of the four chunks of a group
           auto chunk = [&](auto uc, auto partial_tag, const unsigned long long act) {
             constexpr int O = decltype(uc)::value * NT;
             constexpr bool PARTIAL = decltype(partial_tag)::value;
             const int k = kq + O;
             const uint32_t u_ol = (uint16_t)q_mo[O], u_or = (uint16_t)q_mo[O + 2], u_ie = (uint16_t)q_ie[O],
-                           u_de = (uint16_t)q_de[O], u_x = (uint16_t)q_mx[O];
+                           u_de = HYBRID ? d_pre[decltype(uc)::value] : (uint32_t)(uint16_t)q_de[O], u_x = (uint16_t)q_mx[O];
             int ins_c = max((int)((u_ol << 16) + (0x10000u | TB | BT_M_I)), (int)((u_ie << 16) + (0x10000u | TB | BT_M_I | BT_I_EXT)));
             int del_t = max((int)((u_or << 16) | (TB | BT_M_D)), (int)((u_de << 16) | (TB | BT_M_D | BT_D_EXT)));
             const int mis_c = (int)((u_x << 16) + (0x10000u | TB | BT_M_X));
@@ -523,6 +524,12 @@ wfa_align_kernel(const WfaAlignParams p) {
             return n_act > NT;      // this wave has another chunk in the row
           };
           for (int k0 = wave_k; k0 <= hi; k0 += U * NT) {
+            if constexpr (HYBRID) {
+              // the D row of s-e lives in global memory: all four loads of the group go out before the first chunk
+              // (one per chunk, each waited for where it was issued, left a memory round trip exposed per chunk)
+#pragma unroll
+              for (int u = 0; u < U; ++u) d_pre[u] = (uint16_t)q_de[u * NT];
+            }
             if (chunk_at(std::integral_constant<int, 0>{}, k0) && chunk_at(std::integral_constant<int, 1>{}, k0) &&
                 chunk_at(std::integral_constant<int, 2>{}, k0) && chunk_at(std::integral_constant<int, 3>{}, k0)) {
               q_mx += U * NT; q_mo += U * NT; q_ie += U * NT; q_de += U * NT;

@@ -161,8 +161,8 @@ wfa_align_kernel(const WfaAlignParams p) {
   const int lane = tid & 63;
   const int dm = p.dm, de = p.de, rs = p.rs;
   constexpr int ROW_PAD = (!GLOBAL_RING && !BANDED && sizeof(OffT) == 2) ? WFA_RING_ROW_PAD : 0;     // (see wfa_device.h)
-  // the one-wavefront 16-bit LDS tier (BASELINE's short-read configs): its lean loops have a form of their own
-  constexpr bool HOT = NW == 1 && !BANDED && !GLOBAL_RING && !HYBRID && sizeof(OffT) == 2;
+  // the exact tiers with the whole ring in LDS as 16-bit offsets (0, 1, 2): their lean loops have a form of their own
+  constexpr bool HOT = !BANDED && !GLOBAL_RING && !HYBRID && sizeof(OffT) == 2;
   const int x = p.x, oe = p.oe, e = p.e;
 
   // ---- carve LDS -----------------------------------------------------------------------------
@@ -649,10 +649,10 @@ wfa_align_kernel(const WfaAlignParams p) {
       typedef __attribute__((address_space(3))) OffT* LdsRow;
       typedef __attribute__((address_space(3))) const uint32_t* LdsWords;
       typedef __attribute__((address_space(1))) uint8_t* GlobalBytes;
-      const uint32_t pw_addr = lds_addr(Pw), tw_addr = lds_addr(Tw);
-      const uint32_t a_hm = lds_addr(Mr + (dm + 2 * de) * rs + (BANDED ? 0 : kidx0));      // (HOT) diagonal 0 of the run-limit row
+      OffT* const hm_row0 = Mr + (dm + 2 * de) * rs + (BANDED ? 0 : kidx0);      // (HOT) diagonal 0 of the run-limit row
       auto hot_cells = [&](const int lo, const int wm1, GlobalBytes codes, const uint32_t a_oe, const uint32_t a_x, const uint32_t a_m,
-                           const uint32_t a_ip, const uint32_t a_ic, const uint32_t a_dp, const uint32_t a_dc, unsigned long long& touch) {
+                           const uint32_t a_ip, const uint32_t a_ic, const uint32_t a_dp, const uint32_t a_dc, const uint32_t pw_addr, const uint32_t tw_addr,
+                           const uint32_t a_hm, unsigned long long& touch) {
         constexpr int SH = RAW ? 2 : 4, PER = 1 << SH, BITS = RAW ? 3 : 1;
         // Every role tag carries TB >= PER besides its origin bits (the backtrace masks them off), so that any tagged value
         // that is valid (offset >= 0) is >= PER and v_med3(value, 0, PER) is PER for a valid cell and 0 for a NULL one.
@@ -669,7 +669,7 @@ wfa_align_kernel(const WfaAlignParams p) {
           const LdsRow r_mo = (LdsRow)q_mo, r_mx = (LdsRow)q_mx, w_m = (LdsRow)q_wm;
           const LdsRow r_i = (LdsRow)q_ri, w_i = (LdsRow)q_wi, r_d = (LdsRow)q_rd, w_d = (LdsRow)q_wd, r_hm = (LdsRow)q_hm;
           auto chunk = [&](auto uc, auto partial_tag, const unsigned long long act) {
-            constexpr int O = decltype(uc)::value * 64;
+            constexpr int O = decltype(uc)::value * NT;
             constexpr bool PARTIAL = decltype(partial_tag)::value;
             const int k = kq + O;
             const uint32_t u_ol = (uint16_t)r_mo[O], u_or = (uint16_t)r_mo[O + 2], u_ie = (uint16_t)r_i[O],
@@ -738,23 +738,30 @@ wfa_align_kernel(const WfaAlignParams p) {
           more_groups = false;
           auto from = [&](auto&& self, auto uc) -> void {
             constexpr int Uc = decltype(uc)::value;
-            const int n_act = left - Uc * 64;
+            const int n_act = left - Uc * NT;       // cells of the row from this wave's chunk on (wave-uniform)
             if (n_act >= 64) {
               chunk(uc, std::false_type{}, 0ull);
-              if constexpr (Uc < 3) { if (n_act > 64) self(self, std::integral_constant<int, Uc + 1>{}); }
-              else more_groups = n_act > 64;
-            } else {
+              if constexpr (Uc < 3) { if (n_act > NT) self(self, std::integral_constant<int, Uc + 1>{}); }
+              else more_groups = n_act > NT;
+            } else if (NW == 1 || n_act > 0) {
               chunk(uc, std::true_type{}, (1ull << n_act) - 1ull);
             }
           };
           from(from, std::integral_constant<int, 0>{});
           return more_groups;
         };
-        const uint32_t vb0 = (uint32_t)(lane + (lo - 1)) << 1;
-        if (__builtin_expect(group(vb0, lane + lo, codes, wm1 + 1), 0)) {
-          // (wider than four chunks: rare in this tier, kept out of the way of the common case)
-          uint32_t vb = vb0; int kq = lane + lo, left = wm1 + 1;
-          do { vb += 512u; kq += 256; codes += 256; left -= 256; } while (group(vb, kq, codes, left));
+        const uint32_t vb0 = (uint32_t)(tid + (lo - 1)) << 1;
+        // (several waves: each one's count of remaining cells starts at its own first diagonal)
+        const int left0 = wm1 + 1 - ((NW == 1) ? 0 : __builtin_amdgcn_readfirstlane(tid & ~63));
+        if constexpr (NW == 1) {
+          if (__builtin_expect(group(vb0, tid + lo, codes, left0), 0)) {
+            // (wider than four chunks: rare in this tier, kept out of the way of the common case)
+            uint32_t vb = vb0; int kq = tid + lo, left = left0;
+            do { vb += 8u * NT; kq += 4 * NT; codes += 4 * NT; left -= 4 * NT; } while (group(vb, kq, codes, left));
+          }
+        } else {
+          uint32_t vb = vb0; int kq = tid + lo, left = left0;
+          while (group(vb, kq, codes, left)) { vb += 8u * NT; kq += 4 * NT; codes += 4 * NT; left -= 4 * NT; }
         }
       };
       // Limits of the last score (the lean path derives the next ones from them alone).
@@ -801,23 +808,35 @@ wfa_align_kernel(const WfaAlignParams p) {
             const uint32_t a_iswap = a_ic ^ a_ip;
             uint32_t a_dc = a_ic + (uint32_t)(de * rs) * 2u, a_dp = a_ip + (uint32_t)(de * rs) * 2u;       // the D rows of those I rows
             const uint32_t a_dswap = a_dc ^ a_dp;
+            // (formed here, next to the loop that uses them in every chunk: defined further out they are the first
+            // scalars the register allocator gives up, and every chunk then fetches them back from a vector register)
+            uint32_t pw_addr = lds_addr(Pw), tw_addr = lds_addr(Tw), a_hm = lds_addr(hm_row0);
+            asm volatile("" : "+s"(pw_addr), "+s"(tw_addr), "+s"(a_hm));
             int lo = lo_in, hi = hi_in;
+            int t_lo = s_in + c_lo, t_hi = c_hi - s_in, f_lo = max(wlo, t_lo), f_hi = min(whi, t_hi);
             unsigned long long touch = 0;
             uint32_t a_last = a_m;
             // address of this lane's origin byte in the row of the current score (64-bit, bumped by the row size)
             uint64_t code_addr = 0;
             uint32_t need_prev = 0;
-            if constexpr (BT) code_addr = (uint64_t)(uintptr_t)p.arena + (uint64_t)chunk_cur * 16u + (uint32_t)lane;
+            if constexpr (BT) code_addr = (uint64_t)(uintptr_t)p.arena + (uint64_t)chunk_cur * 16u + (uint32_t)tid;
+            if constexpr (NW > 1) {
+              // "a cell touched a sequence end": one LDS word, set by the waves that see it, read after the score's barrier
+              if (tid == 0) bslot[1] = 0u;
+              __syncthreads();
+            }
             // why the loop ends: 1 = the reach interval is empty, 2 = arena exhausted, 3 = a cell touched a sequence end
             // (one exit at the bottom: several would be funnelled through a guard variable anyway)
             int why = 0;
             do {
               // (everything is updated in place -- no second set of registers to copy back at the bottom; when the loop
               // ends without having computed this score, the state of the last computed one is re-derived below)
-              ++s;
-              lo = max(lo - 1, wlo); hi = min(hi + 1, whi);
-              asm volatile("" : "+s"(lo), "+s"(hi));   // (keeps the chains off v_max3/v_min3)
-              lo = max(lo, s + c_lo); hi = min(hi, c_hi - s);
+              // (f_lo = max(wlo, s + c_lo) and f_hi = min(whi, c_hi - s), carried along: four loop constants fewer for the
+              // scalar registers, which this loop runs out of -- a spilled one comes back through the vector unit)
+              ++s; ++t_lo; --t_hi;
+              f_lo = max(f_lo, t_lo); f_hi = min(f_hi, t_hi);
+              asm volatile("" : "+s"(f_lo), "+s"(f_hi));   // (keeps the chains off v_max3/v_min3)
+              lo = max(lo - 1, f_lo); hi = min(hi + 1, f_hi);
               if (__builtin_expect(lo > hi, 0)) { why = 1; continue; }
               const int wm1 = hi - lo;            // width - 1
               uint32_t need = 0;
@@ -835,7 +854,7 @@ wfa_align_kernel(const WfaAlignParams p) {
                   }
                   base = block_bcast<NW>(base, bslot);
                   chunk_cur = base; chunk_left = (base == WFA_ROW_NONE) ? 0u : grab;
-                  code_addr = (uint64_t)(uintptr_t)cp->arena + (uint64_t)chunk_cur * 16u + (uint32_t)lane;
+                  code_addr = (uint64_t)(uintptr_t)cp->arena + (uint64_t)chunk_cur * 16u + (uint32_t)tid;
                   need_prev = 0;
                   if (chunk_left < need) { why = 2; continue; }
                 }
@@ -847,29 +866,49 @@ wfa_align_kernel(const WfaAlignParams p) {
               ncells += (uint32_t)wm1;            // (+ 1 per score when the loop is left)
               if constexpr (BT) {
                 row_s = chunk_cur; chunk_cur += need; chunk_left -= need; need_prev = need;
-                // row table, buffered by lane: a new group of 64 scores starts at every multiple of 64
-                const int sl = s & 63;
-                if (sl == 0) tab[s - 64 + lane] = make_uint2((uint32_t)tabv_row, (uint32_t)tabv_lo);
-                asm("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
-                    : "+v"(tabv_row), "+v"(tabv_lo) : "s"((int)row_s), "s"(lo), "s"(sl));      // (m0: scratch, the compiler sets it before each use of its own)
+                if constexpr (NW == 1) {
+                  // row table, buffered by lane: a new group of 64 scores starts at every multiple of 64
+                  const int sl = s & 63;
+                  if (sl == 0) tab[s - 64 + lane] = make_uint2((uint32_t)tabv_row, (uint32_t)tabv_lo);
+                  asm("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
+                      : "+v"(tabv_row), "+v"(tabv_lo) : "s"((int)row_s), "s"(lo), "s"(sl));      // (m0: scratch, the compiler sets it before each use of its own)
+                } else {
+                  if (tid == 0) tab[s] = make_uint2(row_s, (uint32_t)lo);
+                }
               }
               if (__builtin_expect(s >= s_clear, 0)) {
                 // the slots written now last held scores s-dm (M) and s-2 (I, D), whose limits lay up to dm diagonals
                 // further out: NULL the dm cells beyond each end (rows carry dm guard cells per side)
-                const int j = min(lane, 2 * dm - 1);
-                const int q = (j < dm) ? lo - 1 - j : hi + 1 - dm + j;
-                const uint32_t qa = (uint32_t)q << 1;
-                *(LdsRow)(qa + a_m) = (OffT)OffNull<OffT>::value;
-                *(LdsRow)(qa + a_ic) = (OffT)OffNull<OffT>::value;
-                *(LdsRow)(qa + a_dc) = (OffT)OffNull<OffT>::value;
+                // (lanes beyond 2 dm repeat the last of those cells: same value, same address, no exec mask)
+                auto clear_guards = [&](const int j0) {
+                  const int j = min(j0, 2 * dm - 1);
+                  const int q = (j < dm) ? lo - 1 - j : hi + 1 - dm + j;
+                  const uint32_t qa = (uint32_t)q << 1;
+                  *(LdsRow)(qa + a_m) = (OffT)OffNull<OffT>::value;
+                  *(LdsRow)(qa + a_ic) = (OffT)OffNull<OffT>::value;
+                  *(LdsRow)(qa + a_dc) = (OffT)OffNull<OffT>::value;
+                };
+                clear_guards(tid);
+                if constexpr (NW == 1) { if (__builtin_expect(2 * dm > 64, 0)) clear_guards(tid + 64); }      // (dm <= 64 in this tier)
               }
-              hot_cells(lo, wm1, (GlobalBytes)(uintptr_t)code_addr, a_oe, a_x, a_m, a_ip, a_ic, a_dp, a_dc, touch);
-              block_sync<NW>();
+              hot_cells(lo, wm1, (GlobalBytes)(uintptr_t)code_addr, a_oe, a_x, a_m, a_ip, a_ic, a_dp, a_dc, pw_addr, tw_addr, a_hm, touch);
               a_last = a_m;
               // a cell sits on a sequence end: it may be the last one (wavefront_extend.c:47-67), and from the next
               // score on values may run past the ends -- the careful path takes over
-              if (touch != 0ull) why = 3;
+              if constexpr (NW == 1) {
+                block_sync<NW>();
+                if (touch != 0ull) why = 3;
+              } else {
+                if (touch != 0ull && lane == 0) atomicOr(&bslot[1], 1u);
+                __syncthreads();
+                if (bslot[1] != 0u) why = 3;
+              }
             } while (why == 0);
+            if constexpr (NW > 1) {
+              // the reduction slots of the careful loop (it resets the one of the next score as it goes)
+              if (tid < 24) red[tid] = (tid & 7) == 6 ? 0 : (((tid & 7) & 1) ? INT_MIN : INT_MAX);
+              __syncthreads();
+            }
             const bool nomem = why == 2;
             if (why == 3) touched_ever = true;
             if (why != 3) {
@@ -1049,8 +1088,8 @@ wfa_align_kernel(const WfaAlignParams p) {
               bool my_over = false;
               unsigned long long touch_mask = 0;
               if constexpr (HOT) {
-                hot_cells(lo, hi - lo, (GlobalBytes)(uintptr_t)codes + lane, lds_addr(p_oe), lds_addr(p_x), lds_addr(out_m), lds_addr(p_ip),
-                          lds_addr(out_i), lds_addr(d_of(p_ip)), lds_addr(out_d), touch_mask);
+                hot_cells(lo, hi - lo, (GlobalBytes)(uintptr_t)codes + tid, lds_addr(p_oe), lds_addr(p_x), lds_addr(out_m), lds_addr(p_ip),
+                          lds_addr(out_i), lds_addr(d_of(p_ip)), lds_addr(out_d), lds_addr(Pw), lds_addr(Tw), lds_addr(hm_row0), touch_mask);
               } else {
                 cells_of_score(std::true_type{}, lo, hi, codes, p_x, p_oe - 1, p_ip - 1, d_of(p_ip) + 1, out_m, out_i, out_d, BandCtx{},
                                my_over, touch_mask);
@@ -1404,7 +1443,7 @@ int occ_tier_banded(int tier, size_t lds) {
 size_t wfa_align_lds_bytes(const WfaAlignParams& p, int tier) {
   size_t ring = 0;
   if (tier == 4) ring = (((size_t)(p.dm + p.de) * p.rs * sizeof(int16_t)) + 15) & ~(size_t)15;       // hybrid: M and I rings
-  else if (tier != 3) ring = (((size_t)(p.dm + 2 * p.de + ((tier == 0 && p.band_width <= 0) ? 1 : 0)) * p.rs * sizeof(int16_t)) + 15) & ~(size_t)15;     // (+ the run-limit row of the one-wavefront exact kernels)
+  else if (tier != 3) ring = (((size_t)(p.dm + 2 * p.de + ((tier <= 2 && p.band_width <= 0) ? 1 : 0)) * p.rs * sizeof(int16_t)) + 15) & ~(size_t)15;     // (+ the run-limit row of the exact LDS tiers)
   const size_t seq = (size_t)2 * p.seq_words_cap * 4;
   // reduction slots [24] + broadcast [2] + (NW > 1) row book [3][book]
   const size_t bk = (size_t)p.book_mask + 1;

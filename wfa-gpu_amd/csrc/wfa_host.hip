@@ -805,7 +805,9 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         // (leftovers of the sampled run ping-pong between list_d and list_e; list_c keeps the bucket)
         // The sample only has to yield scores: it runs without backtrace (no arena, no trace launches) and its pairs stay
         // in the bucket -- 0.4 % of the batch aligned twice is cheaper than a separate backtrace pass and a list compaction.
-        cigar_now = false;
+        // (a small sample only: one that is more than 1/64 of the batch keeps its alignments)
+        const bool sample_again = compute_cigar && (unsigned long long)n_s * 64ull <= n_pending;
+        if (sample_again) cigar_now = false;
         const int rc_s = run_list(static_cast<uint32_t*>(c->sample.p), n_s, raw, nullptr, max_error, static_cast<uint32_t*>(c->list_d.p),
                                   static_cast<uint32_t*>(c->list_e.p), /*allow_band=*/false);
         cigar_now = compute_cigar;
@@ -830,11 +832,11 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
           if (slot < 0 && c->n_saved_q < 8) slot = c->n_saved_q++;
           if (slot >= 0) c->saved_q[slot] = {bucket_hi, q, pen.x, pen.o, pen.e, max_error};
         }
-        if (compute_cigar) {
+        if (sample_again) {
           // the sampled pairs go through the bucket's run like everybody else
           LAUNCH_K(k_set_pending, dim3(cdiv(n_s, 256)), dim3(256), 0, st, static_cast<const uint32_t*>(c->sample.p), n_s, static_cast<uint32_t*>(c->status.p));
         } else {
-          // score-only call: the sampled pairs are done, drop them from the bucket's list
+          // the sampled pairs are done: drop them from the bucket's list
           uint32_t* rest = static_cast<uint32_t*>(c->list_e.p);
           if (zero_counter(c, CT_LIST)) return -1;
           LAUNCH_K(k_compact, dim3(cdiv(n_pending, 1024)), dim3(1024), 0, st, (const uint32_t*)pending, n_pending,

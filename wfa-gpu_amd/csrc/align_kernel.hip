@@ -650,7 +650,7 @@ wfa_align_kernel(const WfaAlignParams p) {
       typedef __attribute__((address_space(3))) const uint32_t* LdsWords;
       typedef __attribute__((address_space(1))) uint8_t* GlobalBytes;
       OffT* const hm_row0 = Mr + (dm + 2 * de) * rs + (BANDED ? 0 : kidx0);      // (HOT) diagonal 0 of the run-limit row
-      auto hot_cells = [&](const int lo, const int wm1, GlobalBytes codes, const uint32_t a_oe, const uint32_t a_x, const uint32_t a_m,
+      auto hot_cells = [&](const int lo, const int wm1, GlobalBytes& codes, const uint32_t a_oe, const uint32_t a_x, const uint32_t a_m,
                            const uint32_t a_ip, const uint32_t a_ic, const uint32_t a_dp, const uint32_t a_dc, const uint32_t pw_addr, const uint32_t tw_addr,
                            const uint32_t a_hm, unsigned long long& touch) {
         constexpr int SH = RAW ? 2 : 4, PER = 1 << SH, BITS = RAW ? 3 : 1;
@@ -658,10 +658,11 @@ wfa_align_kernel(const WfaAlignParams p) {
         // that is valid (offset >= 0) is >= PER and v_med3(value, 0, PER) is PER for a valid cell and 0 for a NULL one.
         constexpr uint32_t TB = 16;
         static_assert(TB >= (uint32_t)PER && (TB & (BT_M_MASK | BT_D_EXT | BT_I_EXT)) == 0, "tag base");
-        // a group of up to four chunks from lane bases vb (cell lo + lane - 1 of every row involved: all neighbours are
-        // immediates from there), kq (this lane's diagonal) and codes; returns whether the row goes on beyond the group
-        auto group = [&](const uint32_t vb, const int kq, GlobalBytes codes, const int left) -> bool {
+        // a group of up to four chunks from kq (this lane's diagonal; the lane base of every row involved is cell kq - 1:
+        // all neighbours are immediates from there) and codes; returns whether the row goes on beyond the group
+        auto group = [&](const int kq, const GlobalBytes codes, const int left) -> bool {
           bool more_groups;
+          const uint32_t vb = (uint32_t)(kq - 1) << 1;
           // (one v_add each, once per score: the empty asm keeps the compiler from re-forming them in every chunk)
           uint32_t q_mo = vb + a_oe, q_mx = vb + a_x, q_wm = vb + a_m, q_ri = vb + a_ip, q_wi = vb + a_ic;
           uint32_t q_rd = vb + a_dp, q_wd = vb + a_dc, q_hm = vb + a_hm;
@@ -750,18 +751,21 @@ wfa_align_kernel(const WfaAlignParams p) {
           from(from, std::integral_constant<int, 0>{});
           return more_groups;
         };
-        const uint32_t vb0 = (uint32_t)(tid + (lo - 1)) << 1;
         // (several waves: each one's count of remaining cells starts at its own first diagonal)
         const int left0 = wm1 + 1 - ((NW == 1) ? 0 : __builtin_amdgcn_readfirstlane(tid & ~63));
+        // (`codes` is advanced in place and put back: a second copy of the 64-bit address would not fit the registers)
+        int kq = tid + lo, left = left0;
         if constexpr (NW == 1) {
-          if (__builtin_expect(group(vb0, tid + lo, codes, left0), 0)) {
+          if (__builtin_expect(group(kq, codes, left), 0)) {
             // (wider than four chunks: rare in this tier, kept out of the way of the common case)
-            uint32_t vb = vb0; int kq = tid + lo, left = left0;
-            do { vb += 8u * NT; kq += 4 * NT; codes += 4 * NT; left -= 4 * NT; } while (group(vb, kq, codes, left));
+            uint32_t adv = 0;
+            do { kq += 4 * NT; codes += 4 * NT; adv += 4u * NT; left -= 4 * NT; } while (group(kq, codes, left));
+            codes -= adv;
           }
         } else {
-          uint32_t vb = vb0; int kq = tid + lo, left = left0;
-          while (group(vb, kq, codes, left)) { vb += 8u * NT; kq += 4 * NT; codes += 4 * NT; left -= 4 * NT; }
+          uint32_t adv = 0;
+          while (group(kq, codes, left)) { kq += 4 * NT; codes += 4 * NT; adv += 4u * NT; left -= 4 * NT; }
+          codes -= adv;
         }
       };
       // Limits of the last score (the lean path derives the next ones from them alone).
@@ -817,9 +821,9 @@ wfa_align_kernel(const WfaAlignParams p) {
             unsigned long long touch = 0;
             uint32_t a_last = a_m;
             // address of this lane's origin byte in the row of the current score (64-bit, bumped by the row size)
-            uint64_t code_addr = 0;
+            GlobalBytes code_addr = nullptr;
             uint32_t need_prev = 0;
-            if constexpr (BT) code_addr = (uint64_t)(uintptr_t)p.arena + (uint64_t)chunk_cur * 16u + (uint32_t)tid;
+            if constexpr (BT) code_addr = (GlobalBytes)(uintptr_t)p.arena + ((size_t)chunk_cur * 16u + (uint32_t)tid);
             if constexpr (NW > 1) {
               // "a cell touched a sequence end": one LDS word, set by the waves that see it, read after the score's barrier
               if (tid == 0) bslot[1] = 0u;
@@ -843,7 +847,7 @@ wfa_align_kernel(const WfaAlignParams p) {
               if constexpr (BT) {
                 // the row of origin bytes (before anything of this score is committed: a failure leaves the loop right here)
                 need = ((uint32_t)wm1 + 16u) >> 4;
-                code_addr += (uint64_t)(need_prev << 4);
+                code_addr += need_prev << 4;
                 if (__builtin_expect(need + WFA_ARENA_ROW_SLACK > chunk_left, 0)) {
                   ColdParams cp = cold_params();
                   const uint32_t grab = max(need + WFA_ARENA_ROW_SLACK, cp->chunk_units);
@@ -854,7 +858,7 @@ wfa_align_kernel(const WfaAlignParams p) {
                   }
                   base = block_bcast<NW>(base, bslot);
                   chunk_cur = base; chunk_left = (base == WFA_ROW_NONE) ? 0u : grab;
-                  code_addr = (uint64_t)(uintptr_t)cp->arena + (uint64_t)chunk_cur * 16u + (uint32_t)tid;
+                  code_addr = (GlobalBytes)(uintptr_t)cp->arena + ((size_t)chunk_cur * 16u + (uint32_t)tid);
                   need_prev = 0;
                   if (chunk_left < need) { why = 2; continue; }
                 }
@@ -891,7 +895,7 @@ wfa_align_kernel(const WfaAlignParams p) {
                 clear_guards(tid);
                 if constexpr (NW == 1) { if (__builtin_expect(2 * dm > 64, 0)) clear_guards(tid + 64); }      // (dm <= 64 in this tier)
               }
-              hot_cells(lo, wm1, (GlobalBytes)(uintptr_t)code_addr, a_oe, a_x, a_m, a_ip, a_ic, a_dp, a_dc, pw_addr, tw_addr, a_hm, touch);
+              hot_cells(lo, wm1, code_addr, a_oe, a_x, a_m, a_ip, a_ic, a_dp, a_dc, pw_addr, tw_addr, a_hm, touch);
               a_last = a_m;
               // a cell sits on a sequence end: it may be the last one (wavefront_extend.c:47-67), and from the next
               // score on values may run past the ends -- the careful path takes over
@@ -1088,7 +1092,8 @@ wfa_align_kernel(const WfaAlignParams p) {
               bool my_over = false;
               unsigned long long touch_mask = 0;
               if constexpr (HOT) {
-                hot_cells(lo, hi - lo, (GlobalBytes)(uintptr_t)codes + tid, lds_addr(p_oe), lds_addr(p_x), lds_addr(out_m), lds_addr(p_ip),
+                GlobalBytes code_lane = (GlobalBytes)(uintptr_t)codes + tid;
+                hot_cells(lo, hi - lo, code_lane, lds_addr(p_oe), lds_addr(p_x), lds_addr(out_m), lds_addr(p_ip),
                           lds_addr(out_i), lds_addr(d_of(p_ip)), lds_addr(out_d), lds_addr(Pw), lds_addr(Tw), lds_addr(hm_row0), touch_mask);
               } else {
                 cells_of_score(std::true_type{}, lo, hi, codes, p_x, p_oe - 1, p_ip - 1, d_of(p_ip) + 1, out_m, out_i, out_d, BandCtx{},

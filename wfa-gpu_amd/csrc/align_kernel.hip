@@ -161,8 +161,11 @@ wfa_align_kernel(const WfaAlignParams p) {
   const int lane = tid & 63;
   const int dm = p.dm, de = p.de, rs = p.rs;
   constexpr int ROW_PAD = (!GLOBAL_RING && !BANDED && sizeof(OffT) == 2) ? WFA_RING_ROW_PAD : 0;     // (see wfa_device.h)
-  // the exact tiers with the whole ring in LDS as 16-bit offsets (0, 1, 2): their lean loops have a form of their own
-  constexpr bool HOT = !BANDED && !GLOBAL_RING && !HYBRID && sizeof(OffT) == 2;
+  // the exact tiers with 16-bit offsets in LDS (0, 1, 2 and the hybrid ring, whose D rows live in global memory): their
+  // lean loops have a form of their own; HM_ROW: they also keep min(plen + k, tlen) per diagonal in LDS (not the hybrid
+  // tier, whose LDS is full)
+  constexpr bool HOT = !BANDED && !GLOBAL_RING && sizeof(OffT) == 2;
+  constexpr bool HM_ROW = HOT && !HYBRID;
   const int x = p.x, oe = p.oe, e = p.e;
 
   // ---- carve LDS -----------------------------------------------------------------------------
@@ -172,8 +175,8 @@ wfa_align_kernel(const WfaAlignParams p) {
     Mr = reinterpret_cast<OffT*>(static_cast<char*>(p.gring) + (size_t)blockIdx.x * p.gring_stride);
   } else {
     Mr = reinterpret_cast<OffT*>(sp);
-    // (HOT: one more row, min(plen + k, tlen) per diagonal k -- how far a run on k can go)
-    sp += (((size_t)(dm + (HYBRID ? 1 : 2) * de + (HOT ? 1 : 0)) * rs * sizeof(OffT)) + 15) & ~(size_t)15;
+    // (HM_ROW: one more row, min(plen + k, tlen) per diagonal k -- how far a run on k can go)
+    sp += (((size_t)(dm + (HYBRID ? 1 : 2) * de + (HM_ROW ? 1 : 0)) * rs * sizeof(OffT)) + 15) & ~(size_t)15;
   }
   OffT* const Dg = HYBRID ? reinterpret_cast<OffT*>(static_cast<char*>(p.gring) + (size_t)blockIdx.x * p.gring_stride) : nullptr;   // the D ring
   uint32_t* Pw = reinterpret_cast<uint32_t*>(sp);
@@ -284,7 +287,7 @@ wfa_align_kernel(const WfaAlignParams p) {
         } else {
           for (int i = tid; i < cells; i += NT) Mr[i] = (OffT)OffNull<OffT>::value;
         }
-        if constexpr (HOT) {
+        if constexpr (HM_ROW) {
           OffT* hm = Mr + cells;        // [kidx0 + k] = min(plen + k, tlen)
           for (int i = tid; i < rs; i += NT) hm[i] = (OffT)max(min(plen + (i - kidx0), tlen), 0);
         }
@@ -649,6 +652,7 @@ wfa_align_kernel(const WfaAlignParams p) {
       typedef __attribute__((address_space(3))) OffT* LdsRow;
       typedef __attribute__((address_space(3))) const uint32_t* LdsWords;
       typedef __attribute__((address_space(1))) uint8_t* GlobalBytes;
+      typedef __attribute__((address_space(1))) OffT* GlobalRow;
       OffT* const hm_row0 = Mr + (dm + 2 * de) * rs + (BANDED ? 0 : kidx0);      // (HOT) diagonal 0 of the run-limit row
       auto hot_cells = [&](const int lo, const int wm1, GlobalBytes& codes, const uint32_t a_oe, const uint32_t a_x, const uint32_t a_m,
                            const uint32_t a_ip, const uint32_t a_ic, const uint32_t a_dp, const uint32_t a_dc, const uint32_t pw_addr, const uint32_t tw_addr,
@@ -668,14 +672,21 @@ wfa_align_kernel(const WfaAlignParams p) {
           uint32_t q_rd = vb + a_dp, q_wd = vb + a_dc, q_hm = vb + a_hm;
           asm volatile("" : "+v"(q_mo), "+v"(q_mx), "+v"(q_wm), "+v"(q_ri), "+v"(q_wi), "+v"(q_rd), "+v"(q_wd), "+v"(q_hm));
           const LdsRow r_mo = (LdsRow)q_mo, r_mx = (LdsRow)q_mx, w_m = (LdsRow)q_wm;
-          const LdsRow r_i = (LdsRow)q_ri, w_i = (LdsRow)q_wi, r_d = (LdsRow)q_rd, w_d = (LdsRow)q_wd, r_hm = (LdsRow)q_hm;
+          const LdsRow r_i = (LdsRow)q_ri, w_i = (LdsRow)q_wi, r_hm = (LdsRow)q_hm;
+          // the D rows: LDS like the others, or (hybrid ring) global memory, where a_dp / a_dc are byte offsets into the ring
+          auto d_row = [&](const uint32_t q) {
+            if constexpr (HYBRID) return (GlobalRow)((GlobalBytes)(uintptr_t)d_first + (ptrdiff_t)(int32_t)q);      // (diagonals below 0: negative offsets)
+            else return (LdsRow)q;
+          };
+          const auto r_d = d_row(q_rd), w_d = d_row(q_wd);
           auto chunk = [&](auto uc, auto partial_tag, const unsigned long long act) {
             constexpr int O = decltype(uc)::value * NT;
             constexpr bool PARTIAL = decltype(partial_tag)::value;
             const int k = kq + O;
             const uint32_t u_ol = (uint16_t)r_mo[O], u_or = (uint16_t)r_mo[O + 2], u_ie = (uint16_t)r_i[O],
                            u_de = (uint16_t)r_d[O + 2], u_x = (uint16_t)r_mx[O + 1];
-            const int hmax = (int)(uint16_t)r_hm[O + 1];      // min(plen + k, tlen): how far a run on this diagonal can go
+            // min(plen + k, tlen): how far a run on this diagonal can go
+            const int hmax = HM_ROW ? (int)(uint16_t)r_hm[O + 1] : min(plen + k, tlen);
             int ins_c = max((int)((u_ol << 16) + (0x10000u | TB | BT_M_I)), (int)((u_ie << 16) + (0x10000u | TB | BT_M_I | BT_I_EXT)));
             int del_t = max((int)((u_or << 16) | (TB | BT_M_D)), (int)((u_de << 16) | (TB | BT_M_D | BT_D_EXT)));
             const int mis_c = (int)((u_x << 16) + (0x10000u | TB | BT_M_X));
@@ -810,7 +821,9 @@ wfa_align_kernel(const WfaAlignParams p) {
             uint32_t a_m = lds_addr(p_m), a_x = lds_addr(p_x), a_oe = lds_addr(p_oe);
             uint32_t a_ic = lds_addr(p_ic), a_ip = lds_addr(p_ip);
             const uint32_t a_iswap = a_ic ^ a_ip;
-            uint32_t a_dc = a_ic + (uint32_t)(de * rs) * 2u, a_dp = a_ip + (uint32_t)(de * rs) * 2u;       // the D rows of those I rows
+            // the D rows of those I rows (hybrid ring: as byte offsets into the global D ring, which is laid out like the I ring)
+            uint32_t a_dc = HYBRID ? a_ic - lds_addr(i_first) : a_ic + (uint32_t)(de * rs) * 2u,
+                     a_dp = HYBRID ? a_ip - lds_addr(i_first) : a_ip + (uint32_t)(de * rs) * 2u;
             const uint32_t a_dswap = a_dc ^ a_dp;
             // (formed here, next to the loop that uses them in every chunk: defined further out they are the first
             // scalars the register allocator gives up, and every chunk then fetches them back from a vector register)
@@ -890,7 +903,8 @@ wfa_align_kernel(const WfaAlignParams p) {
                   const uint32_t qa = (uint32_t)q << 1;
                   *(LdsRow)(qa + a_m) = (OffT)OffNull<OffT>::value;
                   *(LdsRow)(qa + a_ic) = (OffT)OffNull<OffT>::value;
-                  *(LdsRow)(qa + a_dc) = (OffT)OffNull<OffT>::value;
+                  if constexpr (HYBRID) *(GlobalRow)((GlobalBytes)(uintptr_t)d_first + (ptrdiff_t)(int32_t)(qa + a_dc)) = (OffT)OffNull<OffT>::value;
+                  else *(LdsRow)(qa + a_dc) = (OffT)OffNull<OffT>::value;
                 };
                 clear_guards(tid);
                 if constexpr (NW == 1) { if (__builtin_expect(2 * dm > 64, 0)) clear_guards(tid + 64); }      // (dm <= 64 in this tier)
@@ -1094,7 +1108,8 @@ wfa_align_kernel(const WfaAlignParams p) {
               if constexpr (HOT) {
                 GlobalBytes code_lane = (GlobalBytes)(uintptr_t)codes + tid;
                 hot_cells(lo, hi - lo, code_lane, lds_addr(p_oe), lds_addr(p_x), lds_addr(out_m), lds_addr(p_ip),
-                          lds_addr(out_i), lds_addr(d_of(p_ip)), lds_addr(out_d), lds_addr(Pw), lds_addr(Tw), lds_addr(hm_row0), touch_mask);
+                          lds_addr(out_i), HYBRID ? (uint32_t)((p_ip - i_first) * (int)sizeof(OffT)) : lds_addr(d_of(p_ip)),
+                          HYBRID ? (uint32_t)((p_ic - i_first) * (int)sizeof(OffT)) : lds_addr(out_d), lds_addr(Pw), lds_addr(Tw), lds_addr(hm_row0), touch_mask);
               } else {
                 cells_of_score(std::true_type{}, lo, hi, codes, p_x, p_oe - 1, p_ip - 1, d_of(p_ip) + 1, out_m, out_i, out_d, BandCtx{},
                                my_over, touch_mask);

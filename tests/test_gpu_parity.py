@@ -240,6 +240,20 @@ def test_score_budget_window_is_exact(aligner, pen):
         checked += 1
 
 
+@pytest.mark.parametrize("pen", [(40, 2, 1), (64, 0, 1), (33, 30, 1)])
+def test_wide_ring_penalties_keep_the_guard_cells(aligner, pen):
+    """A mismatch penalty x > 32 gives a ring of more than 32 M rows, i.e. more than 64 guard cells per score (dm on
+    each side): the one-wavefront lean loop clears them in two passes, and only while the budget's reach shrinks the
+    wavefront -- so the budgets here are tight (each pair's own score and a little more).  Byte-identical to WFA2."""
+    rng = random.Random(77 + pen[0])
+    pairs = _rand_pairs(rng, 300, 200, err=0.08) + _rand_pairs(rng, 100, 700, err=0.05)
+    buf, meta = wfagpu.layout_pairs(pairs)
+    so, co, _ = oracle_lib.oracle_batch(buf, meta, pen, cigar=True, nthreads=8)
+    for me in (int(np.percentile(so, 50)) + 1, int(so.max()) + 3, 5000):
+        s, c = _run(aligner, buf, meta, pen, max_error=me)
+        assert np.array_equal(s, so) and c == co, me
+
+
 def test_randomised_penalties_and_shapes(aligner):
     """Stress: 24 random (x,o,e) triples x ragged pair sets (similar, unrelated, one-sided gaps, very different
     lengths, homopolymers) x three max_error settings -- byte-identical scores and CIGARs vs the oracle.  Exercises the

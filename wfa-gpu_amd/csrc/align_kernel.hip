@@ -162,10 +162,10 @@ wfa_align_kernel(const WfaAlignParams p) {
   const int dm = p.dm, de = p.de, rs = p.rs;
   constexpr int ROW_PAD = (!GLOBAL_RING && !BANDED && sizeof(OffT) == 2) ? WFA_RING_ROW_PAD : 0;     // (see wfa_device.h)
   // the exact tiers with 16-bit offsets in LDS (0, 1, 2 and the hybrid ring, whose D rows live in global memory): their
-  // lean loops have a form of their own; HM_ROW: they also keep min(plen + k, tlen) per diagonal in LDS (not the hybrid
-  // tier, whose LDS is full)
+  // lean loops have a form of their own; HM_ROW: the one-wave tier also keeps min(plen + k, tlen) per diagonal in LDS (the
+  // multi-wave tiers are LDS-bound: 16k x 10 kbp, four waves: 6 rings per CU without the row, 5 with it, 16.4 vs 17.7 ms)
   constexpr bool HOT = !BANDED && !GLOBAL_RING && sizeof(OffT) == 2;
-  constexpr bool HM_ROW = HOT && !HYBRID;
+  constexpr bool HM_ROW = HOT && !HYBRID && NW == 1;
   const int x = p.x, oe = p.oe, e = p.e;
 
   // ---- carve LDS -----------------------------------------------------------------------------
@@ -1463,7 +1463,7 @@ int occ_tier_banded(int tier, size_t lds) {
 size_t wfa_align_lds_bytes(const WfaAlignParams& p, int tier) {
   size_t ring = 0;
   if (tier == 4) ring = (((size_t)(p.dm + p.de) * p.rs * sizeof(int16_t)) + 15) & ~(size_t)15;       // hybrid: M and I rings
-  else if (tier != 3) ring = (((size_t)(p.dm + 2 * p.de + ((tier <= 2 && p.band_width <= 0) ? 1 : 0)) * p.rs * sizeof(int16_t)) + 15) & ~(size_t)15;     // (+ the run-limit row of the exact LDS tiers)
+  else if (tier != 3) ring = (((size_t)(p.dm + 2 * p.de + ((tier == 0 && p.band_width <= 0) ? 1 : 0)) * p.rs * sizeof(int16_t)) + 15) & ~(size_t)15;     // (+ the run-limit row of the one-wave exact kernels)
   const size_t seq = (size_t)2 * p.seq_words_cap * 4;
   // reduction slots [24] + broadcast [2] + (NW > 1) row book [3][book]
   const size_t bk = (size_t)p.book_mask + 1;

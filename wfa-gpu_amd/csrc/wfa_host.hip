@@ -374,11 +374,12 @@ bool plan_tier(const wfagpu_amd_ctx* c, WfaAlignParams& p, int max_score, unsign
     if (t == 1 && width > 8192) continue;
     const int nb = wfa_align_max_blocks_per_cu(t, bt, raw, false, lds);
     if (nb < 1) continue;
-    // One wave per alignment needs its own ring: when LDS leaves fewer than 2 wavefronts per SIMD and the rows are wide
+    // One wave per alignment needs its own ring: when LDS leaves fewer than 2.5 wavefronts per SIMD and the rows are wide
     // enough to share, four waves per alignment (same LDS per workgroup, 4x the resident waves) win although every wave
-    // repeats the per-score bookkeeping: 16k x 10 kbp @ 3 % (24 KB rings, 6 per CU): 25.6 -> 20.3 ms; with 10 rings per CU
-    // (5 kbp @ 4 %) one wave is still the better choice (30.7 vs 38.2 ms).  WFAGPU_T0_MIN_BLOCKS: A/B.
-    static const int t0_min_blocks = getenv("WFAGPU_T0_MIN_BLOCKS") ? atoi(getenv("WFAGPU_T0_MIN_BLOCKS")) : 8;
+    // repeats the per-score bookkeeping: 16k x 10 kbp @ 3 % (24 KB rings, 6 per CU): 25.6 -> 20.3 ms (final kernels: 16.4);
+    // 5 kbp @ 4 % (9 rings per CU): 31.2 -> 29.9 ms with four waves; 3 kbp @ 5 % (12 rings): one wave, 16.1 against 19.7 ms
+    // (profiles/r02/mid_lengths.txt).  WFAGPU_T0_MIN_BLOCKS: A/B.
+    static const int t0_min_blocks = getenv("WFAGPU_T0_MIN_BLOCKS") ? atoi(getenv("WFAGPU_T0_MIN_BLOCKS")) : 10;
     if (t == 0 && !env_min && nb < t0_min_blocks && width >= 384) continue;
     *out = {t, width, max_score, lds, nb};
     return true;

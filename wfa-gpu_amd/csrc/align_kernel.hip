@@ -1051,7 +1051,136 @@ wfa_align_kernel(const WfaAlignParams p) {
         // its limits here), the reach interval moves one diagonal every e scores, and scores without any predecessor row
         // (all odd scores of an all-even penalty set) are "no wavefront" scores: their ring slots are cleared and nothing
         // is computed.
-        if constexpr (!BANDED) {
+        if constexpr (HOT) {
+          // (the same trimmed bookkeeping as the e == 1 loop above, except that the limits come from the row book)
+          if (e != 1 && !touched_ever) {
+            const int s_in = s;
+            const uint32_t rsb = (uint32_t)rs * 2u;
+            const uint32_t a_first = lds_addr(m_first), a_end = lds_addr(m_end), ai_first = lds_addr(i_first), ai_end = lds_addr(i_end);
+            uint32_t a_m = lds_addr(p_m), a_x = lds_addr(p_x), a_oe = lds_addr(p_oe), a_ic = lds_addr(p_ic), a_ip = lds_addr(p_ip);
+            // the D row of an I row: further up in LDS, or (hybrid ring) the same offset into the global D ring
+            const uint32_t d_delta = HYBRID ? 0u - ai_first : (uint32_t)(de * rs) * 2u;
+            uint32_t pw_addr = lds_addr(Pw), tw_addr = lds_addr(Tw), a_hm = lds_addr(hm_row0);
+            asm volatile("" : "+s"(pw_addr), "+s"(tw_addr), "+s"(a_hm));
+            unsigned long long touch = 0;
+            uint32_t a_last = a_m;
+            GlobalBytes code_addr = nullptr;
+            uint32_t need_prev = 0;
+            if constexpr (BT) code_addr = (GlobalBytes)(uintptr_t)p.arena + ((size_t)chunk_cur * 16u + (uint32_t)tid);
+            if constexpr (NW > 1) {
+              if (tid == 0) bslot[1] = 0u;
+              __syncthreads();
+            }
+            int lo = 0, hi = -1;
+            // why the loop ends: 1 = budget exhausted, 2 = arena exhausted, 3 = a cell touched a sequence end
+            int why = 0;
+            do {
+              const int ns = s + 1;
+              int n_rr = reach_r, n_rlo = rlo, n_rhi = rhi;
+              if (n_rr == 0) { ++n_rlo; --n_rhi; n_rr = e - 1; } else --n_rr;
+              const int b_x = book.get_a((ns - x) & bkm), b_oe = book.get_a((ns - oe) & bkm), b_e = book.get_a((ns - e) & bkm);
+              lo = min(range_lo(b_x), range_lo(b_oe) - 1); hi = max(range_hi(b_x), range_hi(b_oe) + 1);
+              if constexpr (NW == 1) asm volatile("" : "+s"(lo), "+s"(hi));
+              lo = min(lo, range_lo(b_e) - 1); hi = max(hi, range_hi(b_e) + 1);
+              if constexpr (NW == 1) asm volatile("" : "+s"(lo), "+s"(hi));
+              lo = max(lo, wlo); hi = min(hi, whi);
+              if constexpr (NW == 1) asm volatile("" : "+s"(lo), "+s"(hi));
+              lo = max(lo, n_rlo); hi = min(hi, n_rhi);
+              const bool none = lo > hi;
+              if (__builtin_expect(none && bounded && ns > budget, 0)) { why = 1; continue; }      // the careful path reports it
+              const int wm1 = hi - lo;
+              uint32_t need = 0;
+              if constexpr (BT) {
+                if (!none) {
+                  need = ((uint32_t)wm1 + 16u) >> 4;
+                  code_addr += need_prev << 4;
+                  if (__builtin_expect(need + WFA_ARENA_ROW_SLACK > chunk_left, 0)) {
+                    ColdParams cp = cold_params();
+                    const uint32_t grab = max(need + WFA_ARENA_ROW_SLACK, cp->chunk_units);
+                    uint32_t base = WFA_ROW_NONE;
+                    if (tid == 0) {
+                      const unsigned long long b = atomicAdd(cp->arena_top, (unsigned long long)grab);
+                      if (b + grab <= cp->arena_units) base = (uint32_t)b;
+                    }
+                    base = block_bcast<NW>(base, bslot);
+                    chunk_cur = base; chunk_left = (base == WFA_ROW_NONE) ? 0u : grab;
+                    code_addr = (GlobalBytes)(uintptr_t)cp->arena + ((size_t)chunk_cur * 16u + (uint32_t)tid);
+                    need_prev = 0;
+                    if (chunk_left < need) { why = 2; continue; }
+                  }
+                }
+              }
+              s = ns; rlo = n_rlo; rhi = n_rhi; reach_r = n_rr;
+              a_m += rsb;  if (a_m == a_end) a_m = a_first;
+              a_x += rsb;  if (a_x == a_end) a_x = a_first;
+              a_oe += rsb; if (a_oe == a_end) a_oe = a_first;
+              a_ic += rsb; if (a_ic == ai_end) a_ic = ai_first;
+              a_ip += rsb; if (a_ip == ai_end) a_ip = ai_first;
+              const uint32_t a_dc = a_ic + d_delta, a_dp = a_ip + d_delta;
+              auto store_null = [&](const uint32_t qa) {
+                *(LdsRow)(qa + a_m) = (OffT)OffNull<OffT>::value;
+                *(LdsRow)(qa + a_ic) = (OffT)OffNull<OffT>::value;
+                if constexpr (HYBRID) *(GlobalRow)((GlobalBytes)(uintptr_t)d_first + (ptrdiff_t)(int32_t)(qa + a_dc)) = (OffT)OffNull<OffT>::value;
+                else *(LdsRow)(qa + a_dc) = (OffT)OffNull<OffT>::value;
+              };
+              if (none) {
+                // no wavefront at this score: the slots it would have written must read as NULL everywhere
+                const int o_m = book.get_a((s - dm) & bkm), o_e = book.get_a((s - de) & bkm);
+                const int f0 = min(range_lo(o_m), range_lo(o_e)), f1 = max(range_hi(o_m), range_hi(o_e));
+                for (int q = f0 + tid; q <= f1; q += NT) store_null((uint32_t)q << 1);
+                book.set_a(s & bkm, ROW_NONE_A);
+                block_sync<NW>();
+                continue;
+              }
+              ncells += (uint32_t)wm1 + 1u;
+              if constexpr (BT) {
+                row_s = chunk_cur; chunk_cur += need; chunk_left -= need; need_prev = need;
+                tab_set(s, row_s, lo);
+              }
+              // ring invariant: the limits move by at most one diagonal per score (see the e == 1 loop): dm cells beyond each end
+              // (lanes beyond 2 dm repeat the last of those cells: same value, same address, no exec mask)
+              {
+                auto clear_guards = [&](const int j0) {
+                  const int j = min(j0, 2 * dm - 1);
+                  store_null((uint32_t)((j < dm) ? lo - 1 - j : hi + 1 - dm + j) << 1);
+                };
+                clear_guards(tid);
+                if constexpr (NW == 1) { if (__builtin_expect(2 * dm > 64, 0)) clear_guards(tid + 64); }
+              }
+              hot_cells(lo, wm1, code_addr, a_oe, a_x, a_m, a_ip, a_ic, a_dp, a_dc, pw_addr, tw_addr, a_hm, touch);
+              a_last = a_m;
+              if constexpr (NW == 1) {
+                block_sync<NW>();
+                if (touch != 0ull) why = 3;
+              } else {
+                if (touch != 0ull && lane == 0) atomicOr(&bslot[1], 1u);
+                __syncthreads();
+                if (bslot[1] != 0u) why = 3;
+              }
+              book.set_a(s & bkm, pack_range(lo, hi));
+              if constexpr (NW == 1) block_sync<NW>();
+            } while (why == 0);
+            if constexpr (NW > 1) {
+              // the reduction slots of the careful loop (it resets the one of the next score as it goes)
+              if (tid < 24) red[tid] = (tid & 7) == 6 ? 0 : (((tid & 7) & 1) ? INT_MIN : INT_MAX);
+              __syncthreads();
+            }
+            if (why == 3) {
+              // a cell sits on a sequence end: it may be the last one (wavefront_extend.c:47-67), and from the next
+              // score on values may run past the ends -- the careful path takes over
+              touched_ever = true;
+              done = ((unsigned)(kend - lo) <= (unsigned)(hi - lo)) &&
+                     __builtin_amdgcn_readfirstlane((int)*(LdsRow)(a_last + ((uint32_t)kend << 1))) >= tlen;
+            }
+            if (s != s_in) book.copy_a_to_id(tid, NT, bkm);
+            regular = 0;      // (the careful path's shortcut for runs of regular scores starts counting afresh)
+            p_m = m_first + (a_m - a_first) / 2; p_x = m_first + (a_x - a_first) / 2; p_oe = m_first + (a_oe - a_first) / 2;
+            p_ic = m_first + (a_ic - a_first) / 2; p_ip = m_first + (a_ip - a_first) / 2;
+            if (why == 2) { status = WFA_ST_NOMEM; break; }
+            if (done) break;
+          }
+        }
+        if constexpr (!BANDED && !HOT) {
           if (e != 1 && !touched_ever) {
             const int s_in = s;
             bool nomem = false;
@@ -1105,15 +1234,8 @@ wfa_align_kernel(const WfaAlignParams p) {
               }
               bool my_over = false;
               unsigned long long touch_mask = 0;
-              if constexpr (HOT) {
-                GlobalBytes code_lane = (GlobalBytes)(uintptr_t)codes + tid;
-                hot_cells(lo, hi - lo, code_lane, lds_addr(p_oe), lds_addr(p_x), lds_addr(out_m), lds_addr(p_ip),
-                          lds_addr(out_i), HYBRID ? (uint32_t)((p_ip - i_first) * (int)sizeof(OffT)) : lds_addr(d_of(p_ip)),
-                          HYBRID ? (uint32_t)((p_ic - i_first) * (int)sizeof(OffT)) : lds_addr(out_d), lds_addr(Pw), lds_addr(Tw), lds_addr(hm_row0), touch_mask);
-              } else {
-                cells_of_score(std::true_type{}, lo, hi, codes, p_x, p_oe - 1, p_ip - 1, d_of(p_ip) + 1, out_m, out_i, out_d, BandCtx{},
-                               my_over, touch_mask);
-              }
+              cells_of_score(std::true_type{}, lo, hi, codes, p_x, p_oe - 1, p_ip - 1, d_of(p_ip) + 1, out_m, out_i, out_d, BandCtx{},
+                             my_over, touch_mask);
               const bool wave_touch = touch_mask != 0ull;
               bool any_touch;
               if constexpr (NW == 1) {

@@ -288,7 +288,8 @@ def main():
         main_ms = acc["main_ms"] / steps
         alg = algorithmic_bytes(int(st.main_launch_seq_bytes), int(st.main_launch_pairs), int(st.main_launch_cells), wl["cigar"])
         achieved = alg / (main_ms * 1e-3) / 1e9 if main_ms > 0 else 0.0
-        default_cmd = not args.pairs and not args.max_error
+        # (the committed counters belong to the default command: not to other sizes, and not to runs with the A/B switches set)
+        default_cmd = not args.pairs and not args.max_error and not any(k.startswith("WFAGPU_") for k in os.environ)
         pmc, pmc_src, pmc_stale = _pmc_main_launch(args.workload, ["FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_INSTS_SALU"]) \
             if default_cmd else (None, None, None)
         # HBM bytes of the main launch: (FETCH_SIZE*2 + WRITE_SIZE) KB -- FETCH_SIZE counts half of a wide coalesced

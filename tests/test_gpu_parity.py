@@ -436,11 +436,11 @@ def _concat_layouts(parts):
 def test_auto_budget_path_on_a_heterogeneous_batch(aligner):
     """The sampled auto-budget driver (csrc/wfa_host.hip: k_sample -> sampled run -> k_ratio -> percentile -> k_budget
     -> budget round -> misses re-run with the caller's budget) only engages at >= 8192 pairs with a window > 128
-    diagonals -- the regime bench.py's cfg3 runs in.  A 1.5 % sub-population with four times the error rate sits above
-    the sampled 98th percentile, so its pairs MUST miss their budget and be re-run; lengths vary 3x inside the bucket.
+    diagonals -- the regime bench.py's cfg3 runs in.  A 0.7 % sub-population with four times the error rate sits above
+    the sampled 99th percentile, so its pairs MUST miss their budget and be re-run; lengths vary 3x inside the bucket.
     Scores and CIGARs byte-identical to the oracle on every pair."""
     parts = [wfagpu.generate_pairs(9000, 1000, 0.03, seed=101), wfagpu.generate_pairs(7000, 600, 0.04, seed=102),
-             wfagpu.generate_pairs(240, 1000, 0.13, seed=103), wfagpu.generate_pairs(300, 350, 0.02, seed=104)]
+             wfagpu.generate_pairs(110, 1000, 0.13, seed=103), wfagpu.generate_pairs(300, 350, 0.02, seed=104)]
     buf, meta = _concat_layouts(parts)
     perm = np.random.RandomState(5).permutation(len(meta))
     meta = np.ascontiguousarray(meta[perm])
@@ -449,7 +449,7 @@ def test_auto_budget_path_on_a_heterogeneous_batch(aligner):
     s, c = aligner.align(batch, (2, 3, 1), max_error=400, compute_cigar=True)
     st = aligner.stats()
     assert st.auto_budget > 0, "the auto-budget path did not engage"
-    assert st.pairs_budget_missed >= 200, st.pairs_budget_missed
+    assert st.pairs_budget_missed >= 100, st.pairs_budget_missed
     assert st.auto_budget < 400
     assert np.array_equal(s, so)
     assert c == co

@@ -189,11 +189,11 @@ __global__ void k_ratio(const uint32_t* __restrict__ list, uint32_t n, const uin
 }
 
 // per-pair budget = 1.02 * q/1024 * length + slack
-__global__ void k_budget(const WfaSeqPair* __restrict__ meta, uint32_t n, int q, int slack, int32_t* __restrict__ out) {
+__global__ void k_budget(const WfaSeqPair* __restrict__ meta, uint32_t n, int q, int slack, int margin_pct, int32_t* __restrict__ out) {
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= n) return;
   const unsigned len = max(meta[gid].pattern_len, meta[gid].text_len);
-  out[gid] = (int32_t)min(0x3FFFFFFFll, ((long long)q * len * 102 / 100) / 1024 + slack);
+  out[gid] = (int32_t)min(0x3FFFFFFFll, ((long long)q * len * margin_pct / 100) / 1024 + slack);
 }
 
 // pairs that are not DONE at the end of a call (must be none: every list is run to completion)
@@ -772,6 +772,15 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       // diamond).
       const int32_t* budgets = nullptr;
       int budget_cap = max_error;
+      // Quantile of the sampled score/length ratios, margin on it (percent) and additive slack of the per-pair budgets.
+      // A pair that misses its budget is re-run with the caller's (~3x the cells on BASELINE configs[2]), a budget that is
+      // too generous costs every pair: 1M x 1 kbp @ 5 %, (quantile, margin, slack) -> budget, misses, align ms:
+      // (0.98, 102, 8) 185, 66, 26.19; (0.99, 100, 2) 177, 3.8 k, 25.84; (0.98, 100, 2) 175, 8.6 k, 25.97;
+      // (0.95, 100, 2) 171, 27.8 k, 26.35 -- flat around the 99th percentile (a narrower diamond only pays where it
+      // saves a whole 64-lane chunk).  WFAGPU_BUDGET_{Q,MARGIN,SLACK}: A/B.
+      static const double budget_q = getenv("WFAGPU_BUDGET_Q") ? atof(getenv("WFAGPU_BUDGET_Q")) : 0.99;
+      static const int budget_margin = getenv("WFAGPU_BUDGET_MARGIN") ? atoi(getenv("WFAGPU_BUDGET_MARGIN")) : 100;
+      const int budget_slack = getenv("WFAGPU_BUDGET_SLACK") ? atoi(getenv("WFAGPU_BUDGET_SLACK")) : 2;
       // With a band requested the sample still runs (exactly): if the budgets it yields make the exact wavefronts no
       // wider than 2.5 bands, the exact search is at least as fast as the band (16k x 10 kbp @ 3 %, window 1017: 20.3 ms
       // exact against 24.8 ms with beta 512 and 18.8 ms with beta 352) and the band -- a permission to approximate, not an obligation -- is not used
@@ -790,11 +799,11 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         // a later batch of the same stream of reads: try the budgets the sample of an earlier batch gave (misses are
         // re-run with the caller's budget as always; too many of them and the next batch samples again)
         const int q = c->saved_q[saved_idx].q;
-        const int slack = pen.o + pen.e + pen.x + 2;
+        const int slack = budget_slack;
         if (c->budget.ensure((size_t)4 * n, st)) return -1;
-        LAUNCH_K(k_budget, dim3(cdiv(n, 256)), dim3(256), 0, st, ap.meta, n, q, slack, static_cast<int32_t*>(c->budget.p));
+        LAUNCH_K(k_budget, dim3(cdiv(n, 256)), dim3(256), 0, st, ap.meta, n, q, slack, budget_margin, static_cast<int32_t*>(c->budget.p));
         budgets = static_cast<const int32_t*>(c->budget.p);
-        budget_cap = (int)std::min<long long>(max_error, ((long long)q * max_len * 102 / 100) / 1024 + slack);
+        budget_cap = (int)std::min<long long>(max_error, ((long long)q * max_len * budget_margin / 100) / 1024 + slack);
         c->stats.auto_budget = budget_cap;
       } else if (try_budget) {
         const uint32_t n_s = std::min<uint32_t>(4096u, std::max<uint32_t>(512u, n_pending / 16u)), stride_s = n_pending / n_s;
@@ -821,11 +830,11 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         std::sort(hr.begin(), hr.end());
         const size_t valid = std::lower_bound(hr.begin(), hr.end(), INT_MAX) - hr.begin();
         if (valid >= n_s / 2) {
-          const int q = hr[std::min(valid - 1, (size_t)(0.98 * valid))];      // score per 1024 bases
-          const int slack = pen.o + pen.e + pen.x + 2;
-          LAUNCH_K(k_budget, dim3(cdiv(n, 256)), dim3(256), 0, st, ap.meta, n, q, slack, static_cast<int32_t*>(c->budget.p));
+          const int q = hr[std::min(valid - 1, (size_t)(budget_q * valid))];      // score per 1024 bases
+          const int slack = budget_slack;
+          LAUNCH_K(k_budget, dim3(cdiv(n, 256)), dim3(256), 0, st, ap.meta, n, q, slack, budget_margin, static_cast<int32_t*>(c->budget.p));
           budgets = static_cast<const int32_t*>(c->budget.p);
-          budget_cap = (int)std::min<long long>(max_error, ((long long)q * max_len * 102 / 100) / 1024 + slack);
+          budget_cap = (int)std::min<long long>(max_error, ((long long)q * max_len * budget_margin / 100) / 1024 + slack);
           c->stats.auto_budget = budget_cap;
           // remember it for later batches of the same stream
           int slot = -1;

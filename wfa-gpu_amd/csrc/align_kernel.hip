@@ -420,127 +420,8 @@ wfa_align_kernel(const WfaAlignParams p) {
                                 const OffT* rb_ie, const OffT* rb_de, OffT* wb_m, OffT* wb_i, OffT* wb_d, const BandCtx& bc,
                                 bool& my_over, unsigned long long& wave_touch) {
         constexpr bool LEAN = decltype(lean_tag)::value;
-        constexpr bool TAGGED = LEAN && !GLOBAL_RING && !BANDED && sizeof(OffT) == 2;     // (also the hybrid ring: its D row is read through a global pointer)
-        if constexpr (TAGGED) {
-          // ---- lean cells with 16-bit offsets in LDS.  Every row is addressed as (lane's base of this score) + a
-          // compile-time chunk offset, which the DS instructions carry as their immediate: the seven row bases are
-          // formed once per score instead of once per 64-diagonal chunk (groups of U chunks; a wavefront wider than
-          // U chunks bumps the bases once per group).  No lane is ever switched off (see `chunk`).
-          // Offsets go to the high halves, the role of each value (its origin bits, see wfa_device.h) to the low
-          // halves -- one v_lshl_add/v_lshl_or per value, which also carries the "+1" of the insertion and
-          // mismatch candidates.  A signed max then picks the larger offset and, on equal offsets, the source WFA2
-          // prefers (extension over open; mismatch, then deletion, then insertion), and the origin byte is two
-          // bit-field inserts of the winners' low bits.  (The MI355X runs with SRAM ECC on, where d16_hi loads zero
-          // the other half of their destination: the role bits cannot simply be left standing in the registers.)
-          constexpr int U = 4;
-          static_assert(U == 4, "the group below is written out for four chunks");
-          constexpr int SH = RAW ? 2 : 4, PER = 1 << SH, BITS = RAW ? 3 : 1;
-          const OffT* q_mx = rb_mx + lo + tid; const OffT* q_mo = rb_mo + lo + tid;
-          const OffT* q_ie = rb_ie + lo + tid; const OffT* q_de = rb_de + lo + tid;
-          OffT* w_m = wb_m + lo + tid; OffT* w_i = wb_i + lo + tid; OffT* w_d = wb_d + lo + tid;
-          uint8_t* q_codes = codes + tid;
-          int kq = lo + tid;
-          const int wave_k = (NW == 1) ? lo : lo + __builtin_amdgcn_readfirstlane(tid & ~63);    // first diagonal of this wave
-          // One chunk: `uc` = its compile-time position in the group, `PARTIAL` = some lanes lie beyond `hi` (mask `act`
-          // of those that do not).  Lanes beyond `hi` run along and store NULL into their cells (the rows are padded by
-          // one chunk for that, and NULL is what a cell outside a row's limits has to hold anyway) and a meaningless
-          // origin byte into the slack the arena keeps behind every row.
-          // (every role tag carries TB >= PER besides its origin bits -- the backtrace masks them off --, so a valid tagged
-          // value is >= PER and v_med3(value, 0, PER) is PER for a valid cell, 0 for a NULL one: the run length of a NULL
-          // cell is 0 and it is stored as it is, NULL plus at most one per score, negative for every score 16 bits hold)
-          constexpr uint32_t TB = 16;
-          static_assert(TB >= (uint32_t)PER && (TB & (BT_M_MASK | BT_D_EXT | BT_I_EXT)) == 0, "tag base");
-          uint32_t d_pre[4] = {0, 0, 0, 0};      // (hybrid ring) D[s-e][k+1] of the four chunks of a group
-          auto chunk = [&](auto uc, auto partial_tag, const unsigned long long act) {
-            constexpr int O = decltype(uc)::value * NT;
-            constexpr bool PARTIAL = decltype(partial_tag)::value;
-            const int k = kq + O;
-            const uint32_t u_ol = (uint16_t)q_mo[O], u_or = (uint16_t)q_mo[O + 2], u_ie = (uint16_t)q_ie[O],
-                           u_de = HYBRID ? d_pre[decltype(uc)::value] : (uint32_t)(uint16_t)q_de[O], u_x = (uint16_t)q_mx[O];
-            int ins_c = max((int)((u_ol << 16) + (0x10000u | TB | BT_M_I)), (int)((u_ie << 16) + (0x10000u | TB | BT_M_I | BT_I_EXT)));
-            int del_t = max((int)((u_or << 16) | (TB | BT_M_D)), (int)((u_de << 16) | (TB | BT_M_D | BT_D_EXT)));
-            const int mis_c = (int)((u_x << 16) + (0x10000u | TB | BT_M_X));
-            const int mv_t = max(del_t, max(mis_c, ins_c));
-            uint32_t code = 0;
-            if constexpr (BT) {
-              uint32_t c1;
-              asm("v_bfi_b32 %0, 2, %1, %2" : "=v"(c1) : "v"(del_t), "v"(mv_t));      // bit 1 from the deletion winner
-              asm("v_bfi_b32 %0, 1, %1, %2" : "=v"(code) : "v"(ins_c), "v"(c1));      // bit 0 from the insertion winner
-            }
-            const int mv0 = mv_t >> 16;
-            // No cell has touched a sequence end so far, so no candidate lies beyond one (M, I and D of the earlier
-            // scores are all < min(plen + k, tlen), and a candidate is at most one more): "not valid" just means NULL,
-            // i.e. negative.
-            int cap;
-            asm("v_med3_i32 %0, %1, 0, %2" : "=v"(cap) : "v"(mv_t), "n"(PER));
-            // extend = longest common prefix from (v,h) (wavefront_extend.c:174-199), see the notes in the general loop below
-            int h = mv0;
-            const int hmax = min(plen + k, tlen);
-            {
-              const int v = mv0 - k;
-              const int rem = hmax - h;
-              const char* pp = reinterpret_cast<const char*>(Pw + (v >> SH));
-              const char* tp = reinterpret_cast<const char*>(Tw + (h >> SH));
-              const uint32_t sa = (uint32_t)v << BITS, sb = (uint32_t)h << BITS;
-              uint32_t fb;
-              {
-                const uint32_t* pw = reinterpret_cast<const uint32_t*>(pp);
-                const uint32_t* tw = reinterpret_cast<const uint32_t*>(tp);
-                const uint32_t d0w = __builtin_amdgcn_alignbit(pw[1], pw[0], sa) ^ __builtin_amdgcn_alignbit(tw[1], tw[0], sb);
-                asm("v_ffbl_b32 %0, %1" : "=v"(fb) : "v"(d0w));
-              }
-              int adv;
-              asm("v_min3_i32 %0, %1, %2, %3" : "=v"(adv) : "v"((int)(fb >> BITS)), "v"(rem), "v"(cap));
-              h += adv;
-              const bool more = adv == PER;       // a whole word matched (a valid cell with at least a word to go)
-              if (__builtin_amdgcn_ballot_w64(more) != 0ull) {
-                int left = more ? max(rem - PER, 0) : 0;
-                while (__builtin_amdgcn_ballot_w64(left > 0) != 0ull) {
-                  pp += 4; tp += 4;
-                  const uint32_t* pw = reinterpret_cast<const uint32_t*>(pp);
-                  const uint32_t* tw = reinterpret_cast<const uint32_t*>(tp);
-                  const uint32_t d = __builtin_amdgcn_alignbit(pw[1], pw[0], sa) ^ __builtin_amdgcn_alignbit(tw[1], tw[0], sb);
-                  asm("v_ffbl_b32 %0, %1" : "=v"(fb) : "v"(d));
-                  const int nn = min(min((int)(fb >> BITS), PER), left);
-                  h += nn;
-                  left = (nn == PER) ? left - PER : 0;
-                }
-              }
-            }
-            int mv = h;
-            if constexpr (PARTIAL) {
-              const bool active = __builtin_amdgcn_inverse_ballot_w64(act);
-              mv = active ? h : OffNull<OffT>::value;
-              ins_c = active ? ins_c : (int)0x80000000u; del_t = active ? del_t : (int)0x80000000u;
-            }
-            wave_touch |= __builtin_amdgcn_ballot_w64(mv == hmax);      // (a NULL never equals it)
-            w_m[O] = (OffT)mv;
-            w_i[O] = (OffT)(ins_c >> 16);     // (high halves: ds_write_b16_d16_hi, no unpacking)
-            w_d[O] = (OffT)(del_t >> 16);
-            if constexpr (BT) q_codes[O] = (uint8_t)code;
-          };
-          auto chunk_at = [&](auto uc, const int k0) -> bool {
-            const int n_act = hi - (k0 + decltype(uc)::value * NT) + 1;     // lanes of this chunk that carry a cell (wave-uniform)
-            if (n_act <= 0) return false;
-            if (n_act >= 64) chunk(uc, std::false_type{}, 0ull);
-            else chunk(uc, std::true_type{}, (1ull << n_act) - 1ull);
-            return n_act > NT;      // this wave has another chunk in the row
-          };
-          for (int k0 = wave_k; k0 <= hi; k0 += U * NT) {
-            if constexpr (HYBRID) {
-              // the D row of s-e lives in global memory: all four loads of the group go out before the first chunk
-              // (one per chunk, each waited for where it was issued, left a memory round trip exposed per chunk)
-#pragma unroll
-              for (int u = 0; u < U; ++u) d_pre[u] = (uint16_t)q_de[u * NT];
-            }
-            if (chunk_at(std::integral_constant<int, 0>{}, k0) && chunk_at(std::integral_constant<int, 1>{}, k0) &&
-                chunk_at(std::integral_constant<int, 2>{}, k0) && chunk_at(std::integral_constant<int, 3>{}, k0)) {
-              q_mx += U * NT; q_mo += U * NT; q_ie += U * NT; q_de += U * NT;
-              w_m += U * NT; w_i += U * NT; w_d += U * NT; q_codes += U * NT; kq += U * NT;
-            } else break;
-          }
-          return;
-        }
+        // (the 16-bit LDS tiers never get here with LEAN set: their lean loops call hot_cells below)
+        static_assert(!(LEAN && HOT), "lean cells of the LDS tiers live in hot_cells");
         for (int k0 = lo; k0 <= hi; k0 += NT) {
           const int k = min(k0 + tid, hi);
           // recurrences (wavefront_compute_affine.c:66-84)

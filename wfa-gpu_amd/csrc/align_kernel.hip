@@ -24,15 +24,17 @@
 //     and the D ring in HBM; the last resort keeps the whole ring (16- or 32-bit) in HBM/L2.
 //   * Ring invariant: a row holds NULL everywhere outside the limits it was last written with (set up
 //     once per alignment, kept by clearing what a slot's previous occupant had beyond the new limits),
-//     so the five reads per cell need no range predicate, and lanes past the end of a row recompute its
-//     last cell, so no store needs an exec mask: the per-cell code is straight-line.
+//     so the five reads per cell need no range predicate.  No lane is switched off: in the careful loop lanes past
+//     the end of a row recompute its last cell, in the lean loops they store NULL into the padding behind the row.
 //   * Two score loops.  The CAREFUL one is WFA2 to the letter (limits from the trimmed limits of the input
 //     rows, "no wavefront" scores, trimming of values past a sequence end, termination read per score).  The
 //     LEAN one runs until an M cell first touches a sequence end -- before that no value can run past an
-//     end, nothing is trimmed and no cell can be the last one -- with limits from the previous score(s)
-//     alone, constant-size ring clearing, tie-breaks from one signed max over (offset << 16 | origin bits),
-//     an extend without exec mask whose first 16-base step is straight-line code, and a row table buffered
-//     in VGPR lanes.  Instruction issue (vector pipe 100 % busy on the headline workload) is what this
+//     end, nothing is trimmed and no cell can be the last one.  Its cells (hot_cells) address every row as one
+//     lane base + immediates (bases formed once per score), break ties with one signed max over
+//     (offset << 16 | origin bits), give NULL cells a run length of 0 through v_med3 instead of selecting, extend
+//     without exec mask (first 16-base step straight-line) and take the run limit from an LDS row; its per-score part
+//     has closed-form limits (e == 1), in-place state, one loop exit, and touches the row book only when it leaves.
+//     Instruction issue (vector pipe 89 % busy on the headline workload, scalar pipe 71 %) is what this
 //     kernel is bound by; the lean loop exists to issue fewer instructions per cell and per score.
 //   * NW == 1: no barrier anywhere in the score loop (LDS operations of one wavefront execute in
 //     order) and the per-score bookkeeping lives in three VGPRs indexed by lane (v_readlane), not in

@@ -254,7 +254,8 @@ int run_shard(const CallArgs& a, Shard& sh) {
   bs = std::max<size_t>(1, bs);
   // a single huge batch is cut in eight so that the stages have something to overlap (1M x 1 kbp pairs, two slices:
   // 66 ms host to host with four batches per slice, 59 ms with eight)
-  if (bs == n_all && n_all >= ((size_t)1 << 17)) bs = (n_all + 7) / 8;
+  static const size_t cut = getenv("WFAGPU_SLICE_BATCHES") ? (size_t)std::max(1, atoi(getenv("WFAGPU_SLICE_BATCHES"))) : 8;
+  if (bs == n_all && n_all >= ((size_t)1 << 17)) bs = (n_all + cut - 1) / cut;
   std::vector<BatchPlan> plan;
   for (size_t from = sh.from; from < sh.to; from += bs) { BatchPlan b{}; b.from = from; b.to = std::min(sh.to, from + bs); plan.push_back(b); }
   const int nb = (int)plan.size();

@@ -579,7 +579,8 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       }
       if (round == 0) { c->stats.lds_bytes_tier0 = tp.lds; c->stats.blocks_per_cu_tier0 = tp.blocks_per_cu; }
       ap.work = cur; ap.n_work = n_cur;
-      const int grid = (int)std::min<uint32_t>(std::min<uint32_t>(n_cur, grid_cap), (uint32_t)(c->num_cus * tp.blocks_per_cu));
+      static const int bpc_cap = getenv("WFAGPU_MAX_BLOCKS_PER_CU") ? atoi(getenv("WFAGPU_MAX_BLOCKS_PER_CU")) : 1 << 20;     // (occupancy experiments)
+      const int grid = (int)std::min<uint32_t>(std::min<uint32_t>(n_cur, grid_cap), (uint32_t)(c->num_cus * std::min(tp.blocks_per_cu, bpc_cap)));
       // arena refill size: as large as lets every workgroup hold a few chunks -- each refill is a
       // returning atomic on ONE word (~88 per microsecond on this chip), which at 4 KiB refills
       // was the whole kernel time

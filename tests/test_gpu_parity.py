@@ -145,14 +145,19 @@ def test_non_acgt_pairs_use_byte_compare_kernels(aligner, pen):
         assert np.array_equal(s2, so)
 
 
-def test_small_arena_forces_multiple_passes(golden_dir):
-    """Backtrace arena smaller than the batch needs: pairs are re-queued for a further pass, results identical."""
+@pytest.mark.parametrize("min_tier,pen", [(0, (2, 3, 1)), (1, (2, 3, 1)), (4, (2, 3, 1)), (0, (5, 3, 2)), (2, (5, 3, 2))])
+def test_small_arena_forces_multiple_passes(golden_dir, min_tier, pen, monkeypatch):
+    """Backtrace arena smaller than the batch needs: pairs are re-queued for a further pass, results identical -- in the
+    one-wave, the multi-wave and the hybrid tier, for gap extension 1 and beyond (each has its own lean loop, and each of
+    those claims its arena row before it commits a score)."""
+    if min_tier:
+        monkeypatch.setenv("WFAGPU_MIN_TIER", str(min_tier))
     al = wfagpu.DeviceAligner(0, arena_bytes=8 << 20)
     try:
-        buf, meta = wfagpu.generate_pairs(3000, 1000, 0.05, 11)
-        so, co, _ = oracle_lib.oracle_batch(buf, meta, (2, 3, 1), cigar=True, nthreads=8)
+        buf, meta = wfagpu.generate_pairs(3000 if min_tier == 0 else 1200, 1000, 0.05, 11)
+        so, co, _ = oracle_lib.oracle_batch(buf, meta, pen, cigar=True, nthreads=8)
         batch = al.upload(buf, meta)
-        s, c = al.align(batch, (2, 3, 1), max_error=300, compute_cigar=True)
+        s, c = al.align(batch, pen, max_error=300 * max(1, pen[0] // 2), compute_cigar=True)
         assert al.stats().sub_batches > 1
         assert np.array_equal(s, so)
         assert c == co
@@ -293,7 +298,7 @@ def test_every_tier_gives_the_same_answers(min_tier, monkeypatch):
     pairs = _rand_pairs(rng, 96, 400, err=0.08)
     pairs += [(b"ACGT" * 50, b"ACGT" * 20), (b"", b"ACGTAC"), (b"GATTACA", b""), (b"A" * 300, b"A" * 299 + b"C")]
     buf, meta = wfagpu.layout_pairs(pairs)
-    for pen in ((2, 3, 1), (4, 6, 2)):
+    for pen in ((2, 3, 1), (4, 6, 2), (5, 3, 2)):
         so, co, _ = oracle_lib.oracle_batch(buf, meta, pen, cigar=True, nthreads=8)
         al = wfagpu.DeviceAligner(0)
         try:

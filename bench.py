@@ -137,11 +137,13 @@ def cpu_baseline(buf, meta, compute_cigar, budget_pairs):
     return res
 
 
-def host_to_host(buf, meta, wl, max_error, n_devices=1, reps=5, registered=True):
+def host_to_host(buf, meta, wl, max_error, n_devices=1, reps=8, registered=False, tuning=None):
     """The metric as SURVEY.md section 8(d) defines it: N / wall of launch_alignments*() -- pageable host buffers in,
     host results (CIGAR strings scattered into the caller's wfa_alignment_result_t records) out, PCIe both ways.
-    First call = cold (context, allocations), later calls = warm (per-device state cached by the library; the arena
-    cap doubles after multi-pass calls, so the best of several warm calls is the steady state)."""
+    First call = cold (contexts, allocations), later calls = warm (per-device state cached by the library; the arena
+    cap grows after multi-pass calls, so the steady state is reached after a call or two): `warm` is the MEDIAN of the
+    warm calls after the first two, `best` their minimum.  `stages_ms`: the library's own stage clock of the median-most
+    call (wfagpu_amd_last_launch_stats; stages overlap)."""
     import ctypes as C
     import wfagpu
     lib = wfagpu.load()
@@ -154,7 +156,7 @@ def host_to_host(buf, meta, wl, max_error, n_devices=1, reps=5, registered=True)
                          band=band[0] if band else -1, batch_size=n, num_alignments=n,
                          penalties=wfagpu.Penalties(*PEN), compute_cigar=wl["cigar"])
     fn = lib.launch_alignments if wl["cigar"] else lib.launch_alignments_distance
-    lib.wfagpu_amd_set_num_devices(n_devices)
+    wfagpu.configure_launch(num_devices=n_devices, tuning=tuning or {})
     meta = meta.copy()
 
     def timed(k):
@@ -162,16 +164,22 @@ def host_to_host(buf, meta, wl, max_error, n_devices=1, reps=5, registered=True)
         for _ in range(k):
             t0 = time.perf_counter()
             fn(buf.ctypes.data, buf.nbytes, meta.ctypes.data, res, opt, False)
-            out.append((time.perf_counter() - t0) * 1e3)
+            out.append(((time.perf_counter() - t0) * 1e3, wfagpu.last_launch_stats()))
         return out
 
     lib.wfagpu_amd_release_cache()
-    ms = timed(1 + reps)
+    calls = timed(3 + reps)
+    ms = [c[0] for c in calls]
+    steady = sorted(calls[3:], key=lambda c: c[0])
+    med_ms, med_stats = steady[len(steady) // 2]
     out = {"unit": "alignments/s", "pairs": n, "devices": n_devices,
            "what": "wall of launch_alignments%s(): pageable host buffer -> device -> host results%s" %
                    ("" if wl["cigar"] else "_distance", " with CIGAR strings" if wl["cigar"] else ""),
-           "pageable": {"cold_ms": round(ms[0], 2), "warm_ms": round(min(ms[1:]), 2),
-                        "cold": round(n / ms[0] * 1e3, 1), "warm": round(n / min(ms[1:]) * 1e3, 1)}}
+           "pageable": {"cold_ms": round(ms[0], 2), "warm_ms": round(med_ms, 2), "best_ms": round(steady[0][0], 2),
+                        "cold": round(n / ms[0] * 1e3, 1), "warm": round(n / med_ms * 1e3, 1),
+                        "best": round(n / steady[0][0] * 1e3, 1), "calls_ms": [round(m, 2) for m in ms]},
+           "stages_ms": {k: (round(v, 2) if isinstance(v, float) else v) for k, v in med_stats.items()},
+           "input_bytes": int(buf.nbytes)}
     if registered:
         hip = wfagpu._hiprt()
         hip.hipHostRegister.argtypes = [C.c_void_p, C.c_size_t, C.c_uint]
@@ -180,12 +188,13 @@ def host_to_host(buf, meta, wl, max_error, n_devices=1, reps=5, registered=True)
         rc = hip.hipHostRegister(buf.ctypes.data, buf.nbytes, 0)
         reg_ms = (time.perf_counter() - t0) * 1e3
         if rc == 0:
-            ms = timed(reps)
+            ms = [c[0] for c in timed(reps)]
             hip.hipHostUnregister(buf.ctypes.data)
             out["registered"] = {"register_ms": round(reg_ms, 2), "warm_ms": round(min(ms), 2),
                                  "warm": round(n / min(ms) * 1e3, 1)}
     out["first_result"] = int(res[0].error)
     lib.destroy_wfa_results(res, n)
+    wfagpu.configure_launch()
     return out
 
 
@@ -215,6 +224,9 @@ def main():
     ap.add_argument("--mode", default="ranks", choices=["ranks", "library"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-to-host", action="store_true")
+    ap.add_argument("--force-band", action="store_true", help="banded workloads: always run the banded kernels (tuning.force_band)")
+    ap.add_argument("--virtual-devices", type=int, default=0,
+                    help="--mode library: shard the call over this many device slots mapped onto the visible GPUs")
     ap.add_argument("--cpu-harness", action="store_true",
                     help="CPU-only check of the rank/timing harness (gloo; the step is the ORACLE, nothing is measured)")
     args = ap.parse_args()
@@ -251,7 +263,8 @@ def main():
     # synthetic data (seeded; every rank its own shard), resident in HBM before the clock starts
     buf, meta = wfagpu.generate_pairs(n_pairs, wl["length"], wl["error"], seed=shardlib.shard_seed(1000, rank),
                                       nthreads=min(16, usable_cores()))
-    al = wfagpu.DeviceAligner(local_rank)
+    tuning = {"force_band": 1} if args.force_band else {}
+    al = wfagpu.DeviceAligner(local_rank, **tuning)
     batch = al.upload(buf, meta)
     dptt = int((meta["pattern_len"].astype(np.int64) * meta["text_len"].astype(np.int64)).sum())
     acc = {"align_ms": 0.0, "pack_ms": 0.0, "trace_ms": 0.0, "launches": 0, "main_ms": 0.0}
@@ -289,7 +302,7 @@ def main():
         alg = algorithmic_bytes(int(st.main_launch_seq_bytes), int(st.main_launch_pairs), int(st.main_launch_cells), wl["cigar"])
         achieved = alg / (main_ms * 1e-3) / 1e9 if main_ms > 0 else 0.0
         # (the committed counters belong to the default command: not to other sizes, and not to runs with the A/B switches set)
-        default_cmd = not args.pairs and not args.max_error and not any(k.startswith("WFAGPU_") for k in os.environ)
+        default_cmd = not args.pairs and not args.max_error and not args.force_band
         pmc, pmc_src, pmc_stale = _pmc_main_launch(args.workload, ["FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_INSTS_SALU"]) \
             if default_cmd else (None, None, None)
         # HBM bytes of the main launch: (FETCH_SIZE*2 + WRITE_SIZE) KB -- FETCH_SIZE counts half of a wide coalesced
@@ -325,7 +338,7 @@ def main():
             "config": {"workload": f"{args.workload}: {wl['desc']}", "pairs_per_gpu_per_step": n_pairs, "length": wl["length"],
                        "error": wl["error"], "penalties": "x=2,o=3,e=1", "max_error": max_error,
                        "compute_cigar": wl["cigar"],
-                       "band": {"period": band[0], "width": band[1], "forced": bool(os.environ.get("WFAGPU_FORCE_BAND")),
+                       "band": {"period": band[0], "width": band[1], "forced": bool(args.force_band),
                                 "policy": "the band is used only where the sampled score budgets leave the exact wavefronts wider "
                                           "than 2.5 bands (tiers.pairs_banded counts the pairs it finished)"} if band else None,
                        "sharding": f"batch-sharded x{world}, no collective", "mode": "ranks"},
@@ -366,7 +379,11 @@ def main():
     if rank == 0 and world == 1:
         if not args.no_host_to_host:
             try:
-                out["host_to_host"] = host_to_host(buf, meta, wl, max_error)
+                h2h = host_to_host(buf, meta, wl, max_error, tuning=tuning)
+                out["host_to_host"] = h2h
+                # the reference's own metric (tools/aligner.c:450-474), PCIe inclusive, next to `value` (resident batch)
+                out["host_to_host_value"] = h2h["pageable"]["warm"]
+                out["host_to_host_ms_per_call"] = h2h["pageable"]["warm_ms"]
             except Exception as ex:
                 out["host_to_host"] = {"error": str(ex)}
         if not args.no_cpu_baseline:
@@ -396,7 +413,8 @@ def library_mode(args, wl, n_pairs, max_error, steps):
                          band=band[0] if band else -1, batch_size=n, num_alignments=n,
                          penalties=wfagpu.Penalties(*PEN), compute_cigar=wl["cigar"])
     fn = lib.launch_alignments if wl["cigar"] else lib.launch_alignments_distance
-    lib.wfagpu_amd_set_num_devices(args.gpus)
+    wfagpu.configure_launch(num_devices=args.gpus, virtual_devices=args.virtual_devices,
+                            tuning={"force_band": 1} if args.force_band else {})
     nd = C.c_int(0)
     lib.get_num_cuda_devices(C.byref(nd))
     if nd.value < args.gpus:
@@ -408,6 +426,7 @@ def library_mode(args, wl, n_pairs, max_error, steps):
     for _ in range(steps):
         fn(buf.ctypes.data, buf.nbytes, meta.ctypes.data, res, opt, False)
     elapsed = time.perf_counter() - t0
+    stages = wfagpu.last_launch_stats()
     dptt = int((meta["pattern_len"].astype(np.int64) * meta["text_len"].astype(np.int64)).sum())
     out = {"metric": "alignments_per_sec", "value": round(n * steps / elapsed, 1), "unit": "alignments/s",
            "n_gpus": args.gpus, "steps": steps, "warmup": max(1, args.warmup), "ms_per_step": round(elapsed / steps * 1e3, 3),
@@ -416,7 +435,9 @@ def library_mode(args, wl, n_pairs, max_error, steps):
                       "error": wl["error"], "penalties": "x=2,o=3,e=1", "max_error": max_error, "compute_cigar": wl["cigar"],
                       "sharding": f"one launch_alignments() call sharded in-library over {args.gpus} devices, no collective",
                       "mode": "library (host buffer -> host results, PCIe inclusive)"},
-           "gcups": round(dptt * steps / elapsed / 1e9, 2), "first_result": int(res[0].error)}
+           "gcups": round(dptt * steps / elapsed / 1e9, 2), "first_result": int(res[0].error),
+           "virtual_devices": args.virtual_devices,
+           "stages_ms_last_call": {k: (round(v, 2) if isinstance(v, float) else v) for k, v in stages.items()}}
     lib.destroy_wfa_results(res, n)
     print(json.dumps(out))
 

@@ -21,6 +21,20 @@ extern "C" {
 
 typedef struct wfagpu_amd_ctx wfagpu_amd_ctx_t;
 
+/* Tuning switches and test hooks of a context.  All zero = the defaults (what every product path uses); they are
+ * plain configuration, set by the caller -- the library reads no environment variables. */
+typedef struct {
+    int min_tier;          /* test hook: skip the wavefront-kernel tiers below this one so that the rarely needed ones run
+                              (1: 4 waves, 2: 16 waves, 3: ring in HBM, 4: hybrid ring)                                  */
+    int careful_only;      /* diagnostics: keep every score on the careful (WFA2-to-the-letter) loop                     */
+    int force_band;        /* with a band requested: always run the banded kernels (default: only where they pay)        */
+    int no_auto_budget;    /* never tune per-pair score budgets from a sample                                            */
+    int max_blocks_per_cu; /* occupancy experiments: cap on resident workgroups per CU (0: none)                         */
+    int t0_min_blocks;     /* one-wave tier only while LDS leaves at least this many rings per CU (0: default, 10)       */
+    int trace_mode;        /* 0: automatic; 1: lane-per-alignment walk + windowed emit whatever the length (the fallback
+                              of the wave-per-alignment kernel); 2: never several alignments per wavefront               */
+} wfagpu_amd_tuning_t;
+
 typedef struct {
     int device;            /* HIP device ordinal                                         */
     void* stream;          /* hipStream_t to run on; NULL: the context creates its own   */
@@ -31,6 +45,7 @@ typedef struct {
     size_t arena_limit_max_bytes; /* > arena_limit_bytes: the cap doubles, up to this value, after every call that
                               needed several passes -- a one-shot call touches little fresh device memory (first touch
                               costs ~33 ms per GiB), a long-lived process ends up with the arena its batches need */
+    wfagpu_amd_tuning_t tuning;
 } wfagpu_amd_config_t;
 
 typedef struct {
@@ -70,11 +85,19 @@ typedef struct {
     unsigned int main_launch_pairs;
     unsigned long long main_launch_cells;
     unsigned long long main_launch_seq_bytes;   /* packed sequence bytes its pairs read */
+    /* work of auto-budget samples whose pairs were aligned again with the batch (score-only launches on <= 4096 pairs):
+     * not part of cells / align_launches / sub_batches / pairs_tier above */
+    unsigned long long sample_cells;
+    int sample_launches;
+    unsigned int sample_passes;
 } wfagpu_amd_stats_t;
 
 /* 0 on success, negative on error (message on stderr). */
 int wfagpu_amd_create(wfagpu_amd_ctx_t** ctx, const wfagpu_amd_config_t* cfg);
 void wfagpu_amd_destroy(wfagpu_amd_ctx_t* ctx);
+
+/* Replaces the tuning switches of a live context (between calls).  NULL: the defaults. */
+void wfagpu_amd_set_tuning(wfagpu_amd_ctx_t* ctx, const wfagpu_amd_tuning_t* tuning);
 
 /* Host helper: assigns text_offset_packed / pattern_offset_packed for n
  * records (what lib/align.cu:103-115 does inline) and returns the number of
@@ -110,8 +133,44 @@ void wfagpu_amd_last_stats(const wfagpu_amd_ctx_t* ctx, wfagpu_amd_stats_t* out)
  * 5 % do makes the next one sample again).  on = 0 forgets what was learnt. */
 void wfagpu_amd_hint_same_stream(wfagpu_amd_ctx_t* ctx, int on);
 
-/* Number of devices launch_alignments* shard a call over (default: all
- * visible).  Results stay in input order. */
+/* How launch_alignments* run a call.  All zero = automatic.  Set between calls (not while one is running). */
+typedef struct {
+    int num_devices;          /* devices a call is sharded over (0: all visible)                                         */
+    int virtual_devices;      /* tests: this many shards -- own threads, contexts, streams -- mapped round-robin onto the
+                                 physical devices: exercises the multi-device path on one GPU                            */
+    int lanes_per_device;     /* contexts per device working on alternate batches (0: 2 for big calls, else 1)           */
+    int batches_per_device;   /* a single huge batch is cut into this many so that the stages overlap (0: 16)            */
+    size_t arena_limit_bytes; /* fixed backtrace-arena cap per lane (0: 4 GiB, growing with use)                         */
+    size_t input_pool_bytes;  /* device memory for resident input per device (0: a quarter of the free memory, <= 24 GiB) */
+    int numa_pin;             /* 0: pin a device's host threads to its NUMA node when several devices are used,
+                                 1: always (test hook for one-GPU boxes), -1: never                                      */
+    int timing;               /* 1: print the stage times of every device on stderr                                      */
+    wfagpu_amd_tuning_t tuning;   /* handed to every context the calls create                                            */
+} wfagpu_amd_launch_config_t;
+
+/* NULL: back to the defaults.  Changing `tuning` or `arena_limit_bytes` drops the cached per-device state. */
+void wfagpu_amd_configure_launch(const wfagpu_amd_launch_config_t* cfg);
+
+/* Stage times of the last launch_alignments* call, milliseconds of wall clock.  The per-stage figures are sums over
+ * the batches of the busiest device (stages overlap: they do not add up to `total_ms`). */
+typedef struct {
+    double total_ms;        /* the whole call                                                         */
+    double plan_ms;         /* sharding + batch planning before any device work                       */
+    double acquire_ms;      /* contexts, streams, cached buffers (cold calls)                         */
+    double prep_ms;         /* spans, packed offsets (host)                                           */
+    double upload_ms;       /* H2D of sequences and metadata                                          */
+    double upload_wait_ms;  /* uploader waiting for a free input slot                                 */
+    double device_ms;       /* wfagpu_amd_align_device, all lanes                                     */
+    double device_wait_ms;  /* lanes waiting for their batch to arrive                                */
+    double d2h_ms;          /* results to pinned staging                                              */
+    double scatter_ms;      /* staging -> the caller's records                                        */
+    double check_ms;        /* -c                                                                     */
+    int devices, lanes, batches;
+    unsigned host_threads;  /* host cores the call could use (affinity mask capped by the cgroup CPU quota) */
+} wfagpu_amd_launch_stats_t;
+void wfagpu_amd_last_launch_stats(wfagpu_amd_launch_stats_t* out);
+
+/* Shorthand for wfagpu_amd_launch_config_t::num_devices. */
 void wfagpu_amd_set_num_devices(int n);
 
 /* Pairs that failed the check_correctness (-c) verification in the last launch_alignments* call (the "Incorrect=" counts

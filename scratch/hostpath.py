@@ -15,6 +15,10 @@ cigar = (sys.argv[4] != "score") if len(sys.argv) > 4 else True
 reps = int(sys.argv[5]) if len(sys.argv) > 5 else 2
 batch = int(sys.argv[6]) if len(sys.argv) > 6 else n
 lib = wfagpu.load()
+lanes = int(sys.argv[7]) if len(sys.argv) > 7 else 0
+nbatch = int(sys.argv[8]) if len(sys.argv) > 8 else 0
+bpc = int(sys.argv[9]) if len(sys.argv) > 9 else 0
+wfagpu.configure_launch(timing=0, lanes_per_device=lanes, batches_per_device=nbatch, tuning={"max_blocks_per_cu": bpc})
 buf, meta = wfagpu.generate_pairs(n, length, err, seed=7, nthreads=16)
 res = C.POINTER(wfagpu.AlignmentResult)()
 assert lib.initialize_wfa_results(C.byref(res), n, 256)
@@ -26,4 +30,6 @@ for r in range(reps):
     fn(buf.ctypes.data, buf.nbytes, meta.ctypes.data, res, opt, False)
     dt = time.perf_counter() - t0
     print(f"call {r}: {dt*1e3:.1f} ms  {n/dt/1e6:.2f} M alignments/s  ({'CIGAR' if cigar else 'score'})", flush=True)
+    st = wfagpu.last_launch_stats()
+    print("   ", " ".join(f"{k}={v:.1f}" if isinstance(v, float) else f"{k}={v}" for k, v in st.items()), flush=True)
 print("first:", res[0].error, C.string_at(res[0].cigar.buffer)[:60] if cigar and res[0].cigar.buffer else "")

@@ -51,16 +51,15 @@ for it in range(iters):
         pairs += [(bytes(rng.choice(b"ACGTN") for _ in range(rng.randint(1, 200))), bytes(rng.choice(b"ACGTNacgt") for _ in range(rng.randint(1, 200)))) for _ in range(20)]
     buf, meta = wfagpu.layout_pairs(pairs)
     so, co, _ = oracle_lib.oracle_batch(buf, meta, pen, cigar=True, nthreads=16)
-    os.environ.pop("WFAGPU_MIN_TIER", None)
-    if rng.random() < 0.25:
-        os.environ["WFAGPU_MIN_TIER"] = str(rng.randint(1, 4))
+    min_tier = rng.randint(1, 4) if rng.random() < 0.25 else 0
+    al.set_tuning(min_tier=min_tier)
     batch = al.upload(buf, meta)
     for max_error in (rng.choice([1, 5, 20]), rng.choice([60, 200, 1000]), 20000):
         s, c = al.align(batch, pen, max_error=max_error, compute_cigar=True)
         if not np.array_equal(s, so) or c != co:
             bad += 1
             k = next(i for i in range(len(pairs)) if s[i] != so[i] or c[i] != co[i])
-            print("MISMATCH it", it, "pen", pen, "max_error", max_error, "tier", os.environ.get("WFAGPU_MIN_TIER"), "pair", k, pairs[k], s[k], so[k], c[k], co[k], flush=True)
+            print("MISMATCH it", it, "pen", pen, "max_error", max_error, "tier", min_tier, "pair", k, pairs[k], s[k], so[k], c[k], co[k], flush=True)
     s2, _ = al.align(batch, pen, max_error=rng.choice([3, 50, 3000]), compute_cigar=False)
     if not np.array_equal(s2, so):
         bad += 1

@@ -1,4 +1,4 @@
-"""One-wave vs four-wave tier against ring size: exact + CIGAR on pairs of several lengths (WFAGPU_T0_MIN_BLOCKS=0 keeps tier 0)."""
+"""One-wave vs four-wave tier against ring size: exact + CIGAR on pairs of several lengths (DeviceAligner(t0_min_blocks=1) keeps tier 0)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "wfa-gpu_amd", "bindings")); sys.path.insert(0, os.path.join(ROOT, "tests"))

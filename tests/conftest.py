@@ -27,3 +27,14 @@ def _build_checkers():
     if not os.path.exists(oracle_lib.ORACLE_SO):
         oracle_lib.build()
     yield
+
+
+@pytest.fixture(autouse=True)
+def _default_launch_config(request):
+    """GPU tests may reconfigure launch_alignments* (virtual devices, tuning hooks): back to the defaults afterwards,
+    whatever the test's outcome."""
+    yield
+    if request.node.get_closest_marker("gpu") is not None:
+        import wfagpu
+        if wfagpu._lib is not None:
+            wfagpu.configure_launch()

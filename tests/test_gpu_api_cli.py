@@ -174,14 +174,13 @@ def test_cached_device_state_survives_mode_and_size_changes(golden_dir):
 
 
 @pytest.mark.parametrize("shards,batch", [(2, None), (3, 50), (8, 7)])
-def test_call_sharded_over_several_device_slots(golden_dir, monkeypatch, shards, batch):
+def test_call_sharded_over_several_device_slots(golden_dir, shards, batch):
     """launch_alignments* cut a call into contiguous per-device slices, one host thread +
-    context + streams each, results in input order.  WFAGPU_VIRTUAL_DEVICES runs that path with several
-    slices on the one GPU of the test box."""
+    context + streams each, results in input order.  wfagpu_amd_launch_config_t::virtual_devices runs that path with
+    several slices on the one GPU of the test box."""
     lib = wfagpu.load()
     lib.wfagpu_amd_release_cache.restype = None
-    monkeypatch.setenv("WFAGPU_VIRTUAL_DEVICES", str(shards))
-    monkeypatch.setenv("WFAGPU_FORCE_NUMA_PIN", "1")     # slice threads move to the cores of their GPU's NUMA node (best effort)
+    wfagpu.configure_launch(virtual_devices=shards, numa_pin=1)     # (numa_pin: slice threads move to the cores of their GPU's NUMA node, best effort)
     pairs = wfagpu.read_seq_file(os.path.join(golden_dir, "seq1k.seq"))[:301]
     buf, meta = wfagpu.layout_pairs(pairs)
     so, co, _ = oracle_lib.oracle_batch(buf, meta, (2, 3, 1), cigar=True, nthreads=8)
@@ -190,6 +189,7 @@ def test_call_sharded_over_several_device_slots(golden_dir, monkeypatch, shards,
         assert np.array_equal(s, np.asarray(so))
         if cigar:
             assert c == co
+    wfagpu.configure_launch()
     lib.wfagpu_amd_release_cache()
 
 
@@ -310,18 +310,19 @@ def test_cli_full_size_cfg3_with_check(tmp_path):
     os.remove(out)
 
 
-def test_ragged_call_is_cut_by_work_not_by_count(monkeypatch):
+def test_ragged_call_is_cut_by_work_not_by_count():
     """launch_alignments* cut a call into per-device slices of equal P x T work: a batch whose long pairs all sit at the end
-    must still come back complete and in input order from 3 slices (WFAGPU_VIRTUAL_DEVICES), CIGARs included."""
+    must still come back complete and in input order from 3 slices (virtual devices), CIGARs included."""
     import random
     lib = wfagpu.load()
-    monkeypatch.setenv("WFAGPU_VIRTUAL_DEVICES", "3")
+    wfagpu.configure_launch(virtual_devices=3)
     rng = random.Random(77)
     from test_oracle import _rand_pairs
     pairs = _rand_pairs(rng, 600, 100, err=0.05) + _rand_pairs(rng, 40, 3000, err=0.05)
     buf, meta = wfagpu.layout_pairs(pairs)
     so, co, _ = oracle_lib.oracle_batch(buf, meta, (2, 3, 1), cigar=True, nthreads=8)
     s, c = _api_align(pairs, (2, 3, 1), cigar=True, max_error=400)
+    wfagpu.configure_launch()
     assert np.array_equal(s, np.asarray(so)) and c == co
     lib.wfagpu_amd_release_cache()
 

@@ -146,13 +146,11 @@ def test_non_acgt_pairs_use_byte_compare_kernels(aligner, pen):
 
 
 @pytest.mark.parametrize("min_tier,pen", [(0, (2, 3, 1)), (1, (2, 3, 1)), (4, (2, 3, 1)), (0, (5, 3, 2)), (2, (5, 3, 2))])
-def test_small_arena_forces_multiple_passes(golden_dir, min_tier, pen, monkeypatch):
+def test_small_arena_forces_multiple_passes(golden_dir, min_tier, pen):
     """Backtrace arena smaller than the batch needs: pairs are re-queued for a further pass, results identical -- in the
     one-wave, the multi-wave and the hybrid tier, for gap extension 1 and beyond (each has its own lean loop, and each of
     those claims its arena row before it commits a score)."""
-    if min_tier:
-        monkeypatch.setenv("WFAGPU_MIN_TIER", str(min_tier))
-    al = wfagpu.DeviceAligner(0, arena_bytes=8 << 20)
+    al = wfagpu.DeviceAligner(0, arena_bytes=8 << 20, min_tier=min_tier)
     try:
         buf, meta = wfagpu.generate_pairs(3000 if min_tier == 0 else 1200, 1000, 0.05, 11)
         so, co, _ = oracle_lib.oracle_batch(buf, meta, pen, cigar=True, nthreads=8)
@@ -289,18 +287,17 @@ def test_randomised_penalties_and_shapes(aligner):
 
 
 @pytest.mark.parametrize("min_tier", [1, 2, 3, 4])
-def test_every_tier_gives_the_same_answers(min_tier, monkeypatch):
+def test_every_tier_gives_the_same_answers(min_tier):
     """The 4-wave, 16-wave, HBM-ring (16-bit offsets) and hybrid-ring (tier 4: M and I rings in LDS, D ring in HBM)
-    instantiations on a ragged set that the one-wave tier normally takes: WFAGPU_MIN_TIER makes the planner skip the
-    smaller tiers."""
-    monkeypatch.setenv("WFAGPU_MIN_TIER", str(min_tier))
+    instantiations on a ragged set that the one-wave tier normally takes: wfagpu_amd_tuning_t::min_tier makes the planner
+    skip the smaller tiers."""
     rng = random.Random(1234 + min_tier)
     pairs = _rand_pairs(rng, 96, 400, err=0.08)
     pairs += [(b"ACGT" * 50, b"ACGT" * 20), (b"", b"ACGTAC"), (b"GATTACA", b""), (b"A" * 300, b"A" * 299 + b"C")]
     buf, meta = wfagpu.layout_pairs(pairs)
     for pen in ((2, 3, 1), (4, 6, 2), (5, 3, 2)):
         so, co, _ = oracle_lib.oracle_batch(buf, meta, pen, cigar=True, nthreads=8)
-        al = wfagpu.DeviceAligner(0)
+        al = wfagpu.DeviceAligner(0, min_tier=min_tier)
         try:
             s, c = _run(al, buf, meta, pen, max_error=600)
             st = al.stats()
@@ -588,17 +585,15 @@ def test_penalty_sets_at_scale(aligner, pen, max_error):
     assert np.array_equal(s2, so)
 
 
-def test_band_is_only_used_where_it_pays(monkeypatch):
+def test_band_is_only_used_where_it_pays():
     """-B on a big batch: the sample that tunes the score budgets runs exactly; when the budgets leave the exact wavefronts
     no wider than 2.5 bands the exact kernels are at least as fast as the band and are used instead (optimal results, no
-    pair counted as banded); WFAGPU_FORCE_BAND=1 keeps the band.  Both ways: valid alignments, cost == score >= optimum."""
+    pair counted as banded); wfagpu_amd_tuning_t::force_band keeps the band.  Both ways: valid alignments, cost == score >= optimum."""
     buf, meta = wfagpu.generate_pairs(9000, 1500, 0.04, seed=401)
     so, co, _ = oracle_lib.oracle_batch(buf, meta, (2, 3, 1), cigar=True, nthreads=16)
     pairs = wfagpu.pairs_from_layout(buf, meta)
     for force in (False, True):
-        if force:
-            monkeypatch.setenv("WFAGPU_FORCE_BAND", "1")
-        al = wfagpu.DeviceAligner(0)
+        al = wfagpu.DeviceAligner(0, force_band=1 if force else 0)
         try:
             batch = al.upload(buf, meta)
             s, c = al.align(batch, (2, 3, 1), max_error=450, compute_cigar=True, band=25, band_width=128)

@@ -45,9 +45,26 @@ class Aligner(C.Structure):  # wfagpu_aligner_t
                 ("last_sequence_pair_idx", C.c_int64), ("alignment_options", Options)]
 
 
+class Tuning(C.Structure):  # wfagpu_amd_tuning_t: all zero = the defaults
+    _fields_ = [("min_tier", C.c_int), ("careful_only", C.c_int), ("force_band", C.c_int), ("no_auto_budget", C.c_int),
+                ("max_blocks_per_cu", C.c_int), ("t0_min_blocks", C.c_int), ("trace_mode", C.c_int)]
+
+
 class Config(C.Structure):  # wfagpu_amd_config_t
     _fields_ = [("device", C.c_int), ("stream", C.c_void_p), ("arena_bytes", C.c_size_t), ("text_bytes", C.c_size_t),
-                ("arena_limit_bytes", C.c_size_t), ("arena_limit_max_bytes", C.c_size_t)]
+                ("arena_limit_bytes", C.c_size_t), ("arena_limit_max_bytes", C.c_size_t), ("tuning", Tuning)]
+
+
+class LaunchConfig(C.Structure):  # wfagpu_amd_launch_config_t: all zero = automatic
+    _fields_ = [("num_devices", C.c_int), ("virtual_devices", C.c_int), ("lanes_per_device", C.c_int),
+                ("batches_per_device", C.c_int), ("arena_limit_bytes", C.c_size_t), ("input_pool_bytes", C.c_size_t),
+                ("numa_pin", C.c_int), ("timing", C.c_int), ("tuning", Tuning)]
+
+
+class LaunchStats(C.Structure):  # wfagpu_amd_launch_stats_t
+    _fields_ = [(k, C.c_double) for k in ("total_ms", "plan_ms", "acquire_ms", "prep_ms", "upload_ms", "upload_wait_ms",
+                                          "device_ms", "device_wait_ms", "d2h_ms", "scatter_ms", "check_ms")] + \
+               [("devices", C.c_int), ("lanes", C.c_int), ("batches", C.c_int), ("host_threads", C.c_uint)]
 
 
 class Batch(C.Structure):  # wfagpu_amd_batch_t
@@ -61,7 +78,8 @@ class Stats(C.Structure):  # wfagpu_amd_stats_t
                 ("text_bytes", C.c_ulonglong), ("pairs_tier", C.c_uint * 5), ("pairs_retried", C.c_uint), ("pairs_raw", C.c_uint), ("pairs_banded", C.c_uint), ("pairs_budget_missed", C.c_uint), ("auto_budget", C.c_int),
                 ("sub_batches", C.c_uint), ("lds_bytes_tier0", C.c_size_t), ("blocks_per_cu_tier0", C.c_int),
                 ("main_launch_ms", C.c_float), ("main_launch_tier", C.c_int), ("main_launch_pairs", C.c_uint),
-                ("main_launch_cells", C.c_ulonglong), ("main_launch_seq_bytes", C.c_ulonglong)]
+                ("main_launch_cells", C.c_ulonglong), ("main_launch_seq_bytes", C.c_ulonglong),
+                ("sample_cells", C.c_ulonglong), ("sample_launches", C.c_int), ("sample_passes", C.c_uint)]
 
 
 ABI_SYMBOLS = [
@@ -73,7 +91,8 @@ ABI_SYMBOLS = [
     # include/wfa_gpu_device.h
     "wfagpu_amd_create", "wfagpu_amd_destroy", "wfagpu_amd_fill_packed_offsets", "wfagpu_amd_pack_device",
     "wfagpu_amd_align_device", "wfagpu_amd_last_stats", "wfagpu_amd_set_num_devices", "wfagpu_amd_release_cache",
-    "wfagpu_amd_check_failures", "wfagpu_amd_hint_same_stream",
+    "wfagpu_amd_check_failures", "wfagpu_amd_hint_same_stream", "wfagpu_amd_configure_launch",
+    "wfagpu_amd_last_launch_stats", "wfagpu_amd_set_tuning",
 ]
 
 _lib = None
@@ -109,6 +128,12 @@ def load():
     lib.wfagpu_amd_last_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
     lib.wfagpu_amd_last_stats.restype = None
     lib.wfagpu_amd_set_num_devices.argtypes = [C.c_int]
+    lib.wfagpu_amd_set_tuning.argtypes = [C.c_void_p, C.POINTER(Tuning)]
+    lib.wfagpu_amd_set_tuning.restype = None
+    lib.wfagpu_amd_configure_launch.argtypes = [C.POINTER(LaunchConfig)]
+    lib.wfagpu_amd_configure_launch.restype = None
+    lib.wfagpu_amd_last_launch_stats.argtypes = [C.POINTER(LaunchStats)]
+    lib.wfagpu_amd_last_launch_stats.restype = None
     lib.wfagpu_amd_check_failures.argtypes = []
     lib.wfagpu_amd_check_failures.restype = C.c_long
     lib.wfagpu_amd_release_cache.argtypes = []
@@ -140,6 +165,24 @@ def load():
     lib.get_cuda_dev_name.restype = C.c_void_p
     _lib = lib
     return lib
+
+
+def configure_launch(**kw):
+    """wfagpu_amd_configure_launch; keyword arguments are fields of wfagpu_amd_launch_config_t, `tuning` a dict of
+    wfagpu_amd_tuning_t fields.  No arguments: back to the defaults."""
+    lib = load()
+    if not kw:
+        lib.wfagpu_amd_configure_launch(None)
+        return
+    tuning = Tuning(**kw.pop("tuning", {}))
+    cfg = LaunchConfig(tuning=tuning, **kw)
+    lib.wfagpu_amd_configure_launch(C.byref(cfg))
+
+
+def last_launch_stats():
+    st = LaunchStats()
+    load().wfagpu_amd_last_launch_stats(C.byref(st))
+    return {k: getattr(st, k) for k, _ in LaunchStats._fields_}
 
 
 def load_gen():
@@ -258,19 +301,25 @@ def read_seq_file(path, limit=None):
 class DeviceAligner:
     """Owns a wfagpu_amd context on one GPU and runs resident batches through the C-ABI."""
 
-    def __init__(self, device=0, arena_bytes=0, text_bytes=0, use_torch_stream=True, arena_limit_bytes=0):
+    def __init__(self, device=0, arena_bytes=0, text_bytes=0, use_torch_stream=True, arena_limit_bytes=0, **tuning):
+        """tuning: fields of wfagpu_amd_tuning_t (min_tier=2, force_band=1, ...)."""
         import torch
         self.torch = torch
         self.lib = load()
         self.device = device
         torch.cuda.set_device(device)
         cfg = Config(device=device, stream=None, arena_bytes=arena_bytes, text_bytes=text_bytes,
-                     arena_limit_bytes=arena_limit_bytes)
+                     arena_limit_bytes=arena_limit_bytes, tuning=Tuning(**tuning))
         if use_torch_stream:
             cfg.stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
         self.ctx = C.c_void_p()
         if self.lib.wfagpu_amd_create(C.byref(self.ctx), C.byref(cfg)) != 0:
             raise RuntimeError("wfagpu_amd_create failed")
+
+    def set_tuning(self, **tuning):
+        """Replace the context's tuning switches (no arguments: the defaults)."""
+        t = Tuning(**tuning)
+        self.lib.wfagpu_amd_set_tuning(self.ctx, C.byref(t))
 
     def close(self):
         if self.ctx:

@@ -95,7 +95,8 @@ __device__ __forceinline__ unsigned long long wave_alloc(unsigned long long* top
 }
 
 __device__ __forceinline__ int dec_digits(uint32_t n) {
-  return n < 10 ? 1 : n < 100 ? 2 : n < 1000 ? 3 : n < 10000 ? 4 : n < 100000 ? 5 : 6;
+  return n < 10 ? 1 : n < 100 ? 2 : n < 1000 ? 3 : n < 10000 ? 4 : n < 100000 ? 5 : n < 1000000 ? 6 : n < 10000000 ? 7 :
+         n < 100000000 ? 8 : n < 1000000000 ? 9 : 10;
 }
 
 struct RleSink {
@@ -385,9 +386,9 @@ __global__ void __launch_bounds__(TRACE_THREADS) wfa_emit_kernel(const WfaTraceP
   }
   if (p.text_scratch) {
     // single replay: the text goes to this lane's slot of the scratch (sized by the same bound the host sizes the arenas
-    // with: at most score / min(x, e) operations, each with a match run, 6 characters per item); wfa_text_compact_kernel
+    // with: at most score / min(x, e) operations, each with a match run, item_chars characters per item); wfa_text_compact_kernel
     // moves it to its place in the dense arena
-    const uint32_t bound = (active && !fail) ? 6u * (2u * ((uint32_t)p.score[pair] / (uint32_t)p.min_op_cost) + 1u) + 1u : 0u;
+    const uint32_t bound = (active && !fail) ? (uint32_t)p.item_chars * (2u * ((uint32_t)p.score[pair] / (uint32_t)p.min_op_cost) + 1u) + 1u : 0u;
     const unsigned long long s_off = wave_alloc(p.scratch_top, bound, lane);
     if (active && !fail && s_off + bound > p.text_scratch_cap) fail = true;
     if (active) {
@@ -799,8 +800,7 @@ void wfa_launch_trace(const WfaTraceParams& p, hipStream_t stream) {
   }
   const uint32_t grid = (p.n_work + TRACE_THREADS - 1) / TRACE_THREADS;
   hipLaunchKernelGGL(wfa_walk_kernel, dim3(grid), dim3(TRACE_THREADS), 0, stream, p);
-  static const bool use_window = getenv("WFAGPU_EMIT_WINDOW") != nullptr;     // (A/B switch: 8-word LDS windows instead of whole sequences)
-  if (use_window || p.seq_lds_stride == 0) {
+  if (p.seq_lds_stride == 0) {      // (sequences too long to stage 64 pairs, or tuning.trace_mode 1: 8-word LDS windows)
     hipLaunchKernelGGL(wfa_emit_win_kernel, dim3(grid), dim3(TRACE_THREADS), 0, stream, p);
     return;
   }

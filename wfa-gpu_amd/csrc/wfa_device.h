@@ -122,6 +122,7 @@ struct WfaTraceParams {
   unsigned long long text_scratch_cap;
   unsigned long long* scratch_top;
   int min_op_cost;               // min(x, e): an alignment of score s has at most s / min_op_cost operations
+  int item_chars;                // widest RLE item (digits of the longest sequence + 1): sizes the upper-bound text slots
   unsigned long long* cigar_off; // [pair] out: byte offset of the CIGAR in `text`
   uint32_t* cigar_len;           // [pair] out: strlen; 0xFFFFFFFF if it did not fit
 };

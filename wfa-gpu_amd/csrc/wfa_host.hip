@@ -136,7 +136,7 @@ __global__ void k_flag_alphabet(const uint8_t* __restrict__ flags, uint32_t n, u
 // bounds for the trace scratch: sum over finished pairs of the op-list and
 // text sizes; also the total of computed cells.  Grid-stride, one atomic triple per block.
 __global__ void __launch_bounds__(256) k_trace_bounds(const uint32_t* __restrict__ work, uint32_t n, const uint32_t* __restrict__ status,
-                               const int32_t* __restrict__ score, const uint32_t* __restrict__ cells, int min_op_cost,
+                               const int32_t* __restrict__ score, const uint32_t* __restrict__ cells, int min_op_cost, int item_chars,
                                unsigned long long* __restrict__ ct) {
   __shared__ unsigned long long part[3][4];
   unsigned long long ops = 0, txt = 0, cl = 0;
@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(256) k_trace_bounds(const uint32_t* __restrict
       smax = max(smax, s);
       ops += (s + 3u) & ~3u;
       const uint32_t m = s / (uint32_t)min_op_cost;
-      txt += 6ull * (2ull * m + 1ull) + 1ull;
+      txt += (unsigned long long)item_chars * (2ull * m + 1ull) + 1ull;
     }
     if (cells && status[pair] != WFA_ST_PENDING) cl += cells[pair];
   }
@@ -226,6 +226,7 @@ struct wfagpu_amd_ctx {
   int num_cus = 0;
   size_t lds_per_block_max = 0;
   size_t arena_cfg = 0, text_cfg = 0, arena_limit = 0, arena_limit_max = 0;
+  wfagpu_amd_tuning_t tuning{};
   DevBuf packed, flags, status, cells, bt_final, list_a, list_b, list_c, list_d, list_e, work_ctr, sample, ratio, budget, counters, arena, ops, text, text_scratch, cig_off, cig_len, gring;
   unsigned long long* h_counters = nullptr;  // pinned
   hipEvent_t ev_start = nullptr, ev_pack = nullptr, ev_a0 = nullptr, ev_a1 = nullptr, ev_t0 = nullptr, ev_t1 = nullptr, ev_end = nullptr;
@@ -266,6 +267,7 @@ int wfagpu_amd_create(wfagpu_amd_ctx_t** out, const wfagpu_amd_config_t* cfg) {
     c->text_cfg = cfg ? cfg->text_bytes : 0;
     c->arena_limit = cfg ? cfg->arena_limit_bytes : 0;
     c->arena_limit_max = cfg ? cfg->arena_limit_max_bytes : 0;
+    if (cfg) c->tuning = cfg->tuning;
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_counters), CT_N * sizeof(unsigned long long), hipHostMallocDefault));
     HIP_TRY(hipEventCreate(&c->ev_start)); HIP_TRY(hipEventCreate(&c->ev_pack));
     HIP_TRY(hipEventCreate(&c->ev_a0)); HIP_TRY(hipEventCreate(&c->ev_a1));
@@ -315,6 +317,10 @@ int wfagpu_amd_pack_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_batch_t* b, voi
   return 0;
 }
 
+void wfagpu_amd_set_tuning(wfagpu_amd_ctx_t* c, const wfagpu_amd_tuning_t* tuning) {
+  if (c) c->tuning = tuning ? *tuning : wfagpu_amd_tuning_t{};
+}
+
 void wfagpu_amd_hint_same_stream(wfagpu_amd_ctx_t* c, int on) {
   if (!c) return;
   c->same_stream = on != 0;
@@ -348,8 +354,8 @@ bool plan_tier(const wfagpu_amd_ctx* c, WfaAlignParams& p, int max_score, unsign
     // (the single-wavefront kernels keep the row book in VGPR lanes: at most 64 ring rows)
     // One wavefront per alignment up to 512 diagonals (beta 352: 26.8 -> 18.4 ms per 16k 10 kbp pairs, 512: 26.4 -> 24.8,
     // 1024: 33 -> 55, so not beyond): the banded kernels spend most of their
-    // instructions on per-score scalar bookkeeping, which every wave of a workgroup repeats.  WFAGPU_BAND_TIER0_MAX: A/B.
-    static const int t0_max = getenv("WFAGPU_BAND_TIER0_MAX") ? atoi(getenv("WFAGPU_BAND_TIER0_MAX")) : 512;
+    // instructions on per-score scalar bookkeeping, which every wave of a workgroup repeats.
+    constexpr int t0_max = 512;
     const int t = (p.band_width <= t0_max && p.dm <= 64) ? 0 : (p.band_width <= 1024 ? 1 : 2);
     const size_t lds = wfa_align_lds_bytes(p, t);
     if (lds > c->lds_per_block_max || max_seq_len > 32766u || max_score > 30000) return false;
@@ -364,9 +370,9 @@ bool plan_tier(const wfagpu_amd_ctx* c, WfaAlignParams& p, int max_score, unsign
   p.rs = rs_plain + WFA_RING_ROW_PAD;
   const bool i16_ok = max_seq_len <= 32766u && max_score <= 30000;
   const size_t budget[3] = {40u << 10, 80u << 10, c->lds_per_block_max};
-  // WFAGPU_MIN_TIER (tests): skip the smaller tiers so that the rarely needed ones get exercised
-  const char* env_min = getenv("WFAGPU_MIN_TIER");
-  for (int t = env_min ? atoi(env_min) : 0; t < 3 && i16_ok; ++t) {
+  // tuning.min_tier (tests): skip the smaller tiers so that the rarely needed ones get exercised
+  const int min_tier = c->tuning.min_tier;
+  for (int t = min_tier; t < 3 && i16_ok; ++t) {
     const size_t lds = wfa_align_lds_bytes(p, t);
     if (lds > budget[t]) continue;
     // a single wavefront sweeps up to ~16 chunks per score before more waves pay off
@@ -378,14 +384,14 @@ bool plan_tier(const wfagpu_amd_ctx* c, WfaAlignParams& p, int max_score, unsign
     // enough to share, four waves per alignment (same LDS per workgroup, 4x the resident waves) win although every wave
     // repeats the per-score bookkeeping: 16k x 10 kbp @ 3 % (24 KB rings, 6 per CU): 25.6 -> 20.3 ms (final kernels: 16.4);
     // 5 kbp @ 4 % (9 rings per CU): 31.2 -> 29.9 ms with four waves; 3 kbp @ 5 % (12 rings): one wave, 16.1 against 19.7 ms
-    // (profiles/r02/mid_lengths.txt).  WFAGPU_T0_MIN_BLOCKS: A/B.
-    static const int t0_min_blocks = getenv("WFAGPU_T0_MIN_BLOCKS") ? atoi(getenv("WFAGPU_T0_MIN_BLOCKS")) : 10;
-    if (t == 0 && !env_min && nb < t0_min_blocks && width >= 384) continue;
+    // (profiles/r02/mid_lengths.txt).  tuning.t0_min_blocks: A/B.
+    const int t0_min_blocks = c->tuning.t0_min_blocks > 0 ? c->tuning.t0_min_blocks : 10;
+    if (t == 0 && !min_tier && nb < t0_min_blocks && width >= 384) continue;
     *out = {t, width, max_score, lds, nb};
     return true;
   }
   // hybrid ring: everything but the D rows in LDS (one workgroup of 16 waves per CU)
-  if (i16_ok && !raw && !getenv("WFAGPU_NO_HYBRID") && !(env_min && atoi(env_min) == 3)) {
+  if (i16_ok && !raw && min_tier != 3) {
     const size_t lds_h = wfa_align_lds_bytes(p, 4);
     if (lds_h <= c->lds_per_block_max) {
       const int nb = wfa_align_max_blocks_per_cu(4, bt, raw, false, lds_h);
@@ -464,6 +470,10 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   const unsigned batch_max_len = std::max(1u, b->max_seq_len);
   unsigned max_len = batch_max_len;    // of the pairs being run: the whole batch, or one length bucket of it
   const int oe = pen.o + pen.e;
+  // widest RLE item of a CIGAR of this batch: the digits of the longest possible run + the operation
+  int item_chars = 2;
+  for (unsigned v = batch_max_len; v >= 10; v /= 10) ++item_chars;
+  item_chars = std::max(item_chars, 6);      // (the emit kernels' one-word fast path writes 4 bytes per item)
 
   WfaAlignParams ap{};
   ap.packed = static_cast<const uint32_t*>(c->packed.p);
@@ -479,10 +489,8 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   ap.work_counter = static_cast<unsigned int*>(c->work_ctr.p);
   ap.arena_top = ct + CT_ARENA;
   ap.launch_cells = ct + CT_LCELLS;
-  ap.no_lean = getenv("WFAGPU_NO_LEAN") ? 1 : 0;
+  ap.no_lean = c->tuning.careful_only ? 1 : 0;
   ap.chunk_units = 256;   // 4 KiB refills
-  // tuning knob for experiments (not part of the interface)
-  const char* env_chunk = getenv("WFAGPU_CHUNK_UNITS");
   ap.bt_final_row = static_cast<uint32_t*>(c->bt_final.p);
 
   // Expected backtrace bytes per pair: a quarter of the score-budget square of origin bytes plus row
@@ -526,6 +534,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   bool cigar_now = compute_cigar;   // (false while the sample of the auto-budget step runs: scores only)
   unsigned long long arena_units_call = 0;
   unsigned long long text_used = 0;
+  unsigned long long sample_cells_call = 0;    // cells of auto-budget samples whose pairs were aligned again
   int rc = 0;
 
   // Runs one list of pairs to completion: passes bounded by the arena, tier escalation inside a pass,
@@ -579,13 +588,13 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       }
       if (round == 0) { c->stats.lds_bytes_tier0 = tp.lds; c->stats.blocks_per_cu_tier0 = tp.blocks_per_cu; }
       ap.work = cur; ap.n_work = n_cur;
-      static const int bpc_cap = getenv("WFAGPU_MAX_BLOCKS_PER_CU") ? atoi(getenv("WFAGPU_MAX_BLOCKS_PER_CU")) : 1 << 20;     // (occupancy experiments)
+      const int bpc_cap = c->tuning.max_blocks_per_cu > 0 ? c->tuning.max_blocks_per_cu : 1 << 20;     // (occupancy experiments)
       const int grid = (int)std::min<uint32_t>(std::min<uint32_t>(n_cur, grid_cap), (uint32_t)(c->num_cus * std::min(tp.blocks_per_cu, bpc_cap)));
       // arena refill size: as large as lets every workgroup hold a few chunks -- each refill is a
       // returning atomic on ONE word (~88 per microsecond on this chip), which at 4 KiB refills
       // was the whole kernel time
-      if (cigar_now) ap.chunk_units = (uint32_t)std::min<unsigned long long>(env_chunk ? (unsigned)atoi(env_chunk) : 4096u, std::max<unsigned long long>(256, ap.arena_units / (4ull * (unsigned)grid)));
-      { const char* es = getenv("WFAGPU_SHARDS"); ap.work_shards = es ? (uint32_t)atoi(es) : 8u; }
+      if (cigar_now) ap.chunk_units = (uint32_t)std::min<unsigned long long>(4096u, std::max<unsigned long long>(256, ap.arena_units / (4ull * (unsigned)grid)));
+      ap.work_shards = 8u;
       if (zero_counter(c, CT_LCELLS, 2)) return -1;   // CT_LCELLS and CT_LIST
       HIP_TRY(hipMemsetAsync(c->work_ctr.p, 0, 8 * 64, st));
       HIP_TRY(hipEventRecord(c->ev_a0, st));
@@ -627,7 +636,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
     if (zero_counter(c, CT_MAX_SCORE)) return -1;
     LAUNCH_K(k_trace_bounds, dim3(std::min<uint32_t>(cdiv(n_pass, 256), 1024u)), dim3(256), 0, st, (const uint32_t*)pending, n_pass,
                        static_cast<const uint32_t*>(c->status.p), (const int32_t*)d_scores,
-                       static_cast<const uint32_t*>(c->cells.p), std::min(pen.x, pen.e), ct);
+                       static_cast<const uint32_t*>(c->cells.p), std::min(pen.x, pen.e), item_chars, ct);
     if (cigar_now) {
       if (read_counters(c)) return -1;       // (score-only calls need none of these sums before the end of the call)
       const unsigned long long ops_need = c->h_counters[CT_SUM_OPS] + 256;
@@ -640,10 +649,13 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         // both sequences of a pair, as words, per lane; staged in LDS when 64 lanes fit 48 KiB
         const unsigned per_seq = raw ? (max_len + 3) / 4 + 1 : (max_len + 15) / 16 + 1;
         const unsigned stride = (2 * per_seq) | 1u;
-        tp.seq_lds_stride = ((size_t)64 * stride * 4 <= (48u << 10)) ? (int)stride : 0;
+        tp.seq_lds_stride = ((size_t)64 * stride * 4 <= (48u << 10) && c->tuning.trace_mode != 1) ? (int)stride : 0;
         // sequences too long to stage 64 pairs per wavefront: one wavefront per alignment (sequences of ONE pair in LDS)
         tp.seq_words_cap = (int)per_seq + 1;
-        tp.wave_kernel = (tp.seq_lds_stride == 0 && !getenv("WFAGPU_NO_WAVE_TRACE")) ? 1 : 0;
+        // (it needs both sequences of a pair plus ~1 KiB in LDS; sequences at the very edge of what the align tiers stage do
+        // not leave that: the lane-per-alignment walk + windowed emit take any length)
+        tp.wave_kernel = (tp.seq_lds_stride == 0 && c->tuning.trace_mode != 1 &&
+                          (size_t)2 * tp.seq_words_cap * 4 + 64 * 16 + 64 <= c->lds_per_block_max) ? 1 : 0;
         // op list (one byte per score point of the largest score of the pass) and CIGAR text of one alignment in LDS,
         // within 40 KiB per wavefront so that at least four of them fit a CU
         {
@@ -658,7 +670,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
           // the wavefront per alignment wins again (16k x 10 kbp: 2.7 ms against 4.0 ms with G = 4).
           const size_t share = seq_b - 1024 + (size_t)tp.ops_lds_bytes + (size_t)tp.text_lds_bytes;
           tp.group = 1;
-          if (!getenv("WFAGPU_NO_GROUP_TRACE") && tp.ops_lds_bytes > 0 && smax <= 512)
+          if (c->tuning.trace_mode == 0 && tp.ops_lds_bytes > 0 && smax <= 512)
             for (int g = 8; g >= 2; g >>= 1)
               if ((share + (size_t)(64 / g) * 16 + 16) * g <= (40u << 10) && n_pass >= (uint32_t)g * 1024u) { tp.group = g; break; }
         }
@@ -671,9 +683,10 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       tp.ops = static_cast<uint8_t*>(c->ops.p); tp.ops_cap = c->ops.cap; tp.ops_top = ct + CT_OPS;
       tp.text = static_cast<char*>(c->text.p); tp.text_cap = c->text.cap; tp.text_top = ct + CT_TEXT;
       tp.min_op_cost = std::min(pen.x, pen.e);
+      tp.item_chars = item_chars;
       // lane-per-alignment emit with whole sequences staged: one replay into a scratch + compaction (big passes only: the
       // scratch holds the upper bounds, ~3x the text)
-      if (!tp.wave_kernel && tp.seq_lds_stride > 0 && n_pass >= 8192u && !getenv("WFAGPU_EMIT_TWO_PASS")) {
+      if (!tp.wave_kernel && tp.seq_lds_stride > 0 && n_pass >= 8192u) {
         if (c->text_scratch.ensure(c->h_counters[CT_SUM_TEXT] + 4096, st)) return -1;
         if (zero_counter(c, CT_SCRATCH)) return -1;
         tp.text_scratch = static_cast<char*>(c->text_scratch.p); tp.text_scratch_cap = c->text_scratch.cap; tp.scratch_top = ct + CT_SCRATCH;
@@ -778,16 +791,15 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       // too generous costs every pair: 1M x 1 kbp @ 5 %, (quantile, margin, slack) -> budget, misses, align ms:
       // (0.98, 102, 8) 185, 66, 26.19; (0.99, 100, 2) 177, 3.8 k, 25.84; (0.98, 100, 2) 175, 8.6 k, 25.97;
       // (0.95, 100, 2) 171, 27.8 k, 26.35 -- flat around the 99th percentile (a narrower diamond only pays where it
-      // saves a whole 64-lane chunk).  WFAGPU_BUDGET_{Q,MARGIN,SLACK}: A/B.
-      static const double budget_q = getenv("WFAGPU_BUDGET_Q") ? atof(getenv("WFAGPU_BUDGET_Q")) : 0.99;
-      static const int budget_margin = getenv("WFAGPU_BUDGET_MARGIN") ? atoi(getenv("WFAGPU_BUDGET_MARGIN")) : 100;
-      const int budget_slack = getenv("WFAGPU_BUDGET_SLACK") ? atoi(getenv("WFAGPU_BUDGET_SLACK")) : 2;
+      // saves a whole 64-lane chunk).
+      constexpr double budget_q = 0.99;
+      constexpr int budget_margin = 100, budget_slack = 2;
       // With a band requested the sample still runs (exactly): if the budgets it yields make the exact wavefronts no
       // wider than 2.5 bands, the exact search is at least as fast as the band (16k x 10 kbp @ 3 %, window 1017: 20.3 ms
       // exact against 24.8 ms with beta 512 and 18.8 ms with beta 352) and the band -- a permission to approximate, not an obligation -- is not used
-      // for this bucket; WFAGPU_FORCE_BAND=1 keeps it.
-      const bool band_optional = want_band && !getenv("WFAGPU_FORCE_BAND");
-      const bool try_budget = !raw && (!want_band || band_optional) && n_pending >= 8192 && !getenv("WFAGPU_NO_AUTOBUDGET") &&
+      // for this bucket; tuning.force_band keeps it.
+      const bool band_optional = want_band && !c->tuning.force_band;
+      const bool try_budget = !raw && (!want_band || band_optional) && n_pending >= 8192 && !c->tuning.no_auto_budget &&
                               window_width(max_error, pen.o, pen.e, max_len) > 128;
       int saved_idx = -1;
       if (try_budget && c->same_stream) {
@@ -818,7 +830,15 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         // in the bucket -- 0.4 % of the batch aligned twice is cheaper than a separate backtrace pass and a list compaction.
         // (a small sample only: one that is more than 1/64 of the batch keeps its alignments)
         const bool sample_again = compute_cigar && (unsigned long long)n_s * 64ull <= n_pending;
-        if (sample_again) cigar_now = false;
+        // (what a sample that is aligned again adds to the work accounting is reported on its own: stats.sample_*)
+        wfagpu_amd_stats_t stats_before{};
+        unsigned long long cells_before = 0;
+        if (sample_again) {
+          cigar_now = false;
+          if (read_counters(c)) return -1;
+          cells_before = c->h_counters[CT_CELLS];
+          stats_before = c->stats;
+        }
         const int rc_s = run_list(static_cast<uint32_t*>(c->sample.p), n_s, raw, nullptr, max_error, static_cast<uint32_t*>(c->list_d.p),
                                   static_cast<uint32_t*>(c->list_e.p), /*allow_band=*/false);
         cigar_now = compute_cigar;
@@ -828,6 +848,16 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         std::vector<int32_t> hr(n_s);
         HIP_TRY(hipMemcpyAsync(hr.data(), c->ratio.p, (size_t)4 * n_s, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        if (sample_again) {
+          if (read_counters(c)) return -1;
+          const int launches = c->stats.align_launches - stats_before.align_launches;
+          const unsigned passes = c->stats.sub_batches - stats_before.sub_batches;
+          c->stats = stats_before;
+          c->stats.sample_launches += launches;
+          c->stats.sample_passes += passes;
+          c->stats.sample_cells += c->h_counters[CT_CELLS] - cells_before;
+          sample_cells_call += c->h_counters[CT_CELLS] - cells_before;
+        }
         std::sort(hr.begin(), hr.end());
         const size_t valid = std::lower_bound(hr.begin(), hr.end(), INT_MAX) - hr.begin();
         if (valid >= n_s / 2) {
@@ -883,7 +913,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
     fprintf(stderr, "[!] ERROR: %llu of %u alignments were left unfinished\n", c->h_counters[CT_LIST], n);
     return -1;
   }
-  c->stats.cells = c->h_counters[CT_CELLS];
+  c->stats.cells = c->h_counters[CT_CELLS] - sample_cells_call;
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, c->ev_start, c->ev_pack)); c->stats.pack_ms = ms;
   HIP_TRY(hipEventElapsedTime(&ms, c->ev_start, c->ev_end)); c->stats.total_ms = ms;

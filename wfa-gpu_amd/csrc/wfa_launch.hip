@@ -4,19 +4,33 @@
 // (utils/device_query.cu:27-54).
 //
 // Host buffers in, host results out, blocking, results in input order.  The
-// pairs of a call are sharded in contiguous slices over the visible GPUs
-// (one host thread + one context + one stream per device, no collective:
-// pairs are independent); inside a device the slice is cut into batches of
-// options.batch_size like the reference does.
+// pairs of a call are sharded in contiguous slices of equal work over the
+// visible GPUs (no collective: pairs are independent); a device's slice is cut
+// into batches of options.batch_size like the reference does and runs as a
+// pipeline whose stages never wait for each other's buffers:
+//
+//   prep thread      spans + packed offsets of every batch (host only, runs ahead)
+//   upload thread    ONE stream of back-to-back H2D copies into a pool of input slots -- with 288 GB of HBM the
+//                    whole slice stays resident (1M x 1 kbp pairs: 2 GB), so the copy engine never idles while a
+//                    batch computes: the call is bound by PCIe (2 GB at ~56 GB/s = 36 ms) or by the kernels,
+//                    whichever is longer, plus the tail of the last batch
+//   K compute lanes  contexts (stream, backtrace arena, scratch) that take alternate batches: the host round trips,
+//                    backtrace kernels and result copies of one lane are filled by the wavefront kernels of the other
+//   K scatter lanes  pinned staging -> the caller's wfa_alignment_result_t records (+ the -c check)
+//
+// The reference overlaps the same phases by hand with two streams and double buffers (lib/align.cu:63-68,177-385).
+// The library reads no environment variables: see wfagpu_amd_launch_config_t.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <atomic>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <chrono>
 #include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -29,23 +43,55 @@
 
 namespace {
 
-std::atomic<int> g_num_devices{0};   // 0: all visible
+constexpr int MAX_DEV = 64;     // device slots (physical devices, or virtual ones in tests)
+constexpr int MAX_LANES = 4;    // compute lanes per device
+
+std::mutex g_cfg_mu;
+wfagpu_amd_launch_config_t g_cfg{};
+wfagpu_amd_launch_stats_t g_last_stats{};
 std::atomic<long> g_check_failures{0};   // pairs that failed the -c check in the last launch_alignments* call
 
-// Host cores this process may use (affinity mask), the budget the slices of a call share.
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// Host cores this process may really use: the affinity mask capped by the cgroup CPU quota (a container with 16 cores'
+// worth of quota on a 256-thread host sees 256 in its mask; 256 busy threads would only be throttled).  The budget the
+// devices of a call share for their scatter and -c workers.
 unsigned usable_host_threads() {
+  unsigned n = std::max(1u, std::thread::hardware_concurrency());
   cpu_set_t set;
   CPU_ZERO(&set);
-  if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int n = CPU_COUNT(&set); if (n > 0) return (unsigned)n; }
-  return std::max(1u, std::thread::hardware_concurrency());
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) n = (unsigned)c; }
+  auto cap = [&](long long quota, long long period) {
+    if (quota > 0 && period > 0) n = (unsigned)std::max<long long>(1, std::min<long long>(n, (quota + period / 2) / period));
+  };
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {            // cgroup v2: "<quota|max> <period>"
+    char q[32] = {0};
+    long long period = 0;
+    if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0) cap(atoll(q), period);
+    fclose(f);
+  } else {
+    long long quota = -1, period = 0;                               // cgroup v1
+    if (FILE* fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(fq, "%lld", &quota) != 1) quota = -1; fclose(fq); }
+    if (FILE* fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(fp, "%lld", &period) != 1) period = 0; fclose(fp); }
+    cap(quota, period);
+  }
+  return n;
 }
 
-// Best effort: run a slice's host threads (this one and the ones it starts: they inherit the mask) on the cores of the
-// NUMA node its GPU hangs off, so that the staging copies and the scatter of eight slices do not all cross the socket
+// fn(t) for t in [0, nt) on nt threads (the caller's included)
+void parallel_for(unsigned nt, const std::function<void(unsigned)>& fn) {
+  if (nt <= 1) { fn(0); return; }
+  std::vector<std::thread> pool;
+  for (unsigned t = 1; t < nt; ++t) pool.emplace_back(fn, t);
+  fn(0);
+  for (auto& t : pool) t.join();
+}
+
+// Best effort: run a device's host threads (this one and the ones it starts: they inherit the mask) on the cores of the
+// NUMA node its GPU hangs off, so that the staging copies and the scatter of eight devices do not all cross the socket
 // interconnect.  Intersected with the mask the process already has; any failure leaves things as
-// they are.  WFAGPU_NO_NUMA_PIN=1 disables it.
+// they are.
 void pin_to_device_node(int device) {
-  if (getenv("WFAGPU_NO_NUMA_PIN")) return;
   char bdf[64] = {0};
   if (hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf) - 1, device) != hipSuccess) return;
   for (char* p = bdf; *p; ++p) if (*p >= 'A' && *p <= 'F') *p = (char)(*p - 'A' + 'a');    // sysfs spells it in lower case
@@ -82,10 +128,12 @@ void pin_to_device_node(int device) {
 
 struct Shard {
   int device;        // physical device
-  int slot;          // index of the cached per-device state (== device unless WFAGPU_VIRTUAL_DEVICES is set)
+  int slot;          // index of the cached per-device state (== device unless virtual devices are configured)
+  int sharers = 1;   // slots that share this physical device (their arenas share its memory)
   size_t from, to;   // [from, to)
-  unsigned host_threads = 1;   // this slice's share of the host cores (scatter and -c workers): SURVEY.md section 8(e)
+  unsigned host_threads = 1;   // this device's share of the host cores (scatter and -c workers): SURVEY.md section 8(e)
   int rc = 0;
+  wfagpu_amd_launch_stats_t st{};
 };
 
 struct CallArgs {
@@ -96,6 +144,7 @@ struct CallArgs {
   wfa_alignment_options_t opt;
   bool check;
   bool cigar;
+  wfagpu_amd_launch_config_t cfg;
 };
 
 #define HIP_OK(expr)                                                                         \
@@ -112,7 +161,8 @@ int check_batch(const CallArgs& a, size_t from, size_t to, int batch_idx, unsign
   std::atomic<long> correct{0}, incorrect{0};
   std::atomic<long long> sum{0};
   std::atomic<long> next{(long)from};
-  auto worker = [&] {
+  auto worker = [&](unsigned) {
+    verification_scratch_t scratch = {nullptr, 0};     // this worker's, for all its pairs; freed below
     for (;;) {
       const long i0 = next.fetch_add(16);
       if (i0 >= (long)to) break;
@@ -131,38 +181,34 @@ int check_batch(const CallArgs& a, size_t from, size_t to, int batch_idx, unsign
           if (!c1) LOG_ERROR("Incorrect cigar (%ld). Distance: %d. CIGAR: %s", i, dist, cg);
           ok = c1 && c2;
         }
-        const int cpu = verification_cpu_score(pattern, text, m.pattern_len, m.text_len, a.opt.penalties.x,
-                                               a.opt.penalties.o, a.opt.penalties.e);
+        const int cpu = verification_cpu_score_scratch(pattern, text, m.pattern_len, m.text_len, a.opt.penalties.x,
+                                                       a.opt.penalties.o, a.opt.penalties.e, &scratch);
         if (cpu != dist) { LOG_ERROR("Incorrect distance (%ld). GPU=%d, CPU=%d", i, dist, cpu); ok = false; }
         sum += dist;
         if (ok) ++correct; else ++incorrect;
       }
     }
+    verification_scratch_free(&scratch);
   };
-  // (each slice has its share of the host cores: with 8 devices x 2 slices a pool of hardware_concurrency() threads per
-  // batch and slice would oversubscribe the host 16-fold and starve the upload and scatter threads)
-  unsigned nt = std::max(1u, max_threads);
+  // (each device has its share of the host cores: with 8 devices a pool of every hardware thread per batch and lane
+  // would oversubscribe the host many times over and starve the upload and scatter threads)
+  unsigned nt = std::max(1u, std::min(64u, max_threads));
   nt = (unsigned)std::min<size_t>(nt, (to - from + 15) / 16);
-  std::vector<std::thread> pool;
-  for (unsigned t = 1; t < nt; ++t) pool.emplace_back(worker);
-  worker();
-  for (auto& t : pool) t.join();
+  parallel_for(nt, worker);
   fprintf(stderr, "(Batch %d) correct=%ld Incorrect=%ld Average score=%f\n", batch_idx, correct.load(), incorrect.load(),
           (to > from) ? (double)sum.load() / (double)(to - from) : 0.0);
   g_check_failures += incorrect.load();
   return incorrect.load() ? 1 : 0;
 }
 
-// Per-device state that outlives a call: the context (stream, arena, scratch), two input buffers,
-// two sets of pinned result staging.  Allocating them is most of the cost of a cold call (device memory
-// ~33 ms per GiB, pinned host memory similar), so they are kept for the next call of the process and
-// freed by wfagpu_amd_release_cache() or at exit by the OS.  Calls are single-threaded by contract
-// (lib/aligner.h of the reference is not re-entrant); a mutex guards the cache anyway.
-struct DevState {
-  int device = -1;
+// Per-device state that outlives a call: the compute lanes (context = stream + backtrace arena + scratch, score buffer,
+// two sets of pinned result staging each), the pool of input slots and the upload stream.  Allocating them is most of
+// the cost of a cold call (pinned host memory ~0.25 ms per MiB, device memory ~33 ms per GiB at first touch), so they
+// are kept for the next call of the process and freed by wfagpu_amd_release_cache() or at exit by the OS.  Calls are
+// single-threaded by contract (lib/aligner.h of the reference is not re-entrant); a mutex per slot guards the cache anyway.
+struct Lane {
   wfagpu_amd_ctx_t* ctx = nullptr;
-  hipStream_t up = nullptr, down = nullptr;   // copy streams (H2D of the next batch, D2H of the last)
-  struct In { char* d_seq = nullptr; size_t seq_cap = 0; sequence_pair_t* d_meta = nullptr; size_t meta_cap = 0; } in[2];
+  hipStream_t down = nullptr;                  // D2H of this lane's results
   int32_t* d_scores = nullptr; size_t scores_cap = 0;
   struct Out {
     char* text = nullptr; size_t text_cap = 0;
@@ -170,50 +216,79 @@ struct DevState {
     int32_t* score = nullptr; size_t n_cap = 0;
   } out[2];
 };
-constexpr int MAX_DEV = 64;
+struct InSlot { char* d_seq = nullptr; size_t seq_cap = 0; sequence_pair_t* d_meta = nullptr; size_t meta_cap = 0; };
+struct DevState {
+  int device = -1;
+  hipStream_t up = nullptr;                    // H2D of the batches, in order
+  std::vector<hipEvent_t> up_done;             // one per batch of a call: "its copies have landed"
+  std::vector<InSlot> in;
+  Lane lane[MAX_LANES];
+  wfagpu_amd_tuning_t tuning{};                // what the contexts were created with
+  size_t arena_limit_cfg = 0;
+};
 DevState g_dev[MAX_DEV];
-std::mutex g_dev_mu[MAX_DEV];   // one per device: the shards of a call run concurrently
+std::mutex g_dev_mu[MAX_DEV];   // one per slot: the devices of a call run concurrently
 
 void release_dev(DevState& d) {
   if (d.device < 0) return;
   (void)hipSetDevice(d.device);
-  for (auto& in : d.in) { if (in.d_seq) (void)hipFree(in.d_seq); if (in.d_meta) (void)hipFree(in.d_meta); in = {}; }
-  if (d.d_scores) (void)hipFree(d.d_scores);
-  for (auto& o : d.out) {
-    if (o.text) (void)hipHostFree(o.text);
-    if (o.off) (void)hipHostFree(o.off);
-    if (o.len) (void)hipHostFree(o.len);
-    if (o.score) (void)hipHostFree(o.score);
-    o = {};
+  for (auto& in : d.in) { if (in.d_seq) (void)hipFree(in.d_seq); if (in.d_meta) (void)hipFree(in.d_meta); }
+  d.in.clear();
+  for (auto& e : d.up_done) (void)hipEventDestroy(e);
+  d.up_done.clear();
+  for (auto& l : d.lane) {
+    if (l.d_scores) (void)hipFree(l.d_scores);
+    for (auto& o : l.out) {
+      if (o.text) (void)hipHostFree(o.text);
+      if (o.off) (void)hipHostFree(o.off);
+      if (o.len) (void)hipHostFree(o.len);
+      if (o.score) (void)hipHostFree(o.score);
+    }
+    if (l.down) (void)hipStreamDestroy(l.down);
+    if (l.ctx) wfagpu_amd_destroy(l.ctx);
+    l = Lane{};
   }
   if (d.up) (void)hipStreamDestroy(d.up);
-  if (d.down) (void)hipStreamDestroy(d.down);
-  if (d.ctx) wfagpu_amd_destroy(d.ctx);
-  d.device = -1; d.ctx = nullptr; d.up = d.down = nullptr; d.d_scores = nullptr; d.scores_cap = 0;
+  d.up = nullptr;
+  d.device = -1;
 }
 
-int acquire_dev(int slot, int device, DevState** out) {
+// The cached state of `slot`, with at least `lanes` compute lanes, for `device`.
+int acquire_dev(int slot, int device, int lanes, int sharers, const wfagpu_amd_launch_config_t& cfg, DevState** out) {
   if (slot < 0 || slot >= MAX_DEV) return -1;
   DevState& d = g_dev[slot];
-  if (d.device == device && d.ctx) { *out = &d; return 0; }
+  if (d.device >= 0 && (d.device != device || memcmp(&d.tuning, &cfg.tuning, sizeof(d.tuning)) != 0 || d.arena_limit_cfg != cfg.arena_limit_bytes))
+    release_dev(d);
   HIP_OK(hipSetDevice(device));
-  wfagpu_amd_config_t cfg{};
-  cfg.device = device;
-  // The backtrace arena is kept between calls.  Its cap starts at 4 GiB -- fresh device memory costs ~33 ms per GiB at
-  // first touch, and a batch that needs more simply runs in several passes (1M x 1 kbp pairs: 18 GB of origin bytes,
-  // 5 passes, 130 ms cold instead of 1.2 s) -- and doubles after every call that needed several passes, up to a quarter
-  // of the free device memory or 32 GiB: a long-lived process ends up with one pass per call.
-  cfg.arena_limit_bytes = (size_t)4 << 30;
-  {
+  if (d.device < 0) {
+    d.device = device;
+    d.tuning = cfg.tuning;
+    d.arena_limit_cfg = cfg.arena_limit_bytes;
+    HIP_OK(hipStreamCreateWithFlags(&d.up, hipStreamNonBlocking));
+  }
+  for (int k = 0; k < lanes; ++k) {
+    Lane& l = d.lane[k];
+    if (l.ctx) continue;
+    wfagpu_amd_config_t c{};
+    c.device = device;
+    c.tuning = cfg.tuning;
+    // The backtrace arena is kept between calls.  Its cap starts at 4 GiB -- fresh device memory costs ~33 ms per GiB at
+    // first touch, and a batch that needs more simply runs in several passes -- and grows after every call that needed
+    // several passes (a long-lived process ends up with one pass per call).  All lanes of all slots of a device
+    // together never claim more than half of the memory that is free when they are created.
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)16 << 30;
-    cfg.arena_limit_max_bytes = std::max<size_t>(cfg.arena_limit_bytes, std::min<size_t>((size_t)32 << 30, free_b / 4));
+    const size_t share = free_b / 2 / (size_t)std::max(1, sharers * lanes);
+    if (cfg.arena_limit_bytes) {
+      c.arena_limit_bytes = cfg.arena_limit_bytes;      // fixed cap
+      c.arena_limit_max_bytes = 0;
+    } else {
+      c.arena_limit_bytes = std::min<size_t>((size_t)4 << 30, std::max<size_t>(share, (size_t)64 << 20));
+      c.arena_limit_max_bytes = std::max<size_t>(c.arena_limit_bytes, std::min<size_t>((size_t)32 << 30, share));
+    }
+    if (wfagpu_amd_create(&l.ctx, &c)) return -1;
+    HIP_OK(hipStreamCreateWithFlags(&l.down, hipStreamNonBlocking));
   }
-  if (const char* e = getenv("WFAGPU_ARENA_LIMIT_MB")) { cfg.arena_limit_bytes = (size_t)atol(e) << 20; cfg.arena_limit_max_bytes = 0; }
-  if (wfagpu_amd_create(&d.ctx, &cfg)) return -1;
-  d.device = device;
-  HIP_OK(hipStreamCreateWithFlags(&d.up, hipStreamNonBlocking));
-  HIP_OK(hipStreamCreateWithFlags(&d.down, hipStreamNonBlocking));
   *out = &d;
   return 0;
 }
@@ -226,60 +301,102 @@ template <typename T> int grow_pinned(T** p, size_t want_elems) {
 }
 
 struct BatchPlan {
-  size_t from, to, lo, span, packed_bytes;
-  unsigned max_len;
-  unsigned long long text_bytes = 0;
+  size_t from, to;          // pairs
+  size_t lo = 0, span = 0;  // bytes of the caller's sequence buffer the batch covers: [lo, lo + span)
+  size_t packed_bytes = 0;
+  unsigned max_len = 0;
 };
 
-// One device's slice of a call as a three-stage pipeline over its batches (the reference overlaps the
-// same phases by hand with two streams, lib/align.cu:63-68,177-385):
-//   uploader thread : packed offsets + metadata rebasing + H2D into input buffer i % 2
-//   this thread     : wfagpu_amd_align_device (all kernels), then D2H into pinned staging i % 2
-//   scatter thread  : staging -> the caller's wfa_alignment_result_t records (+ the -c check)
-int run_shard(const CallArgs& a, Shard& sh) {
+// One mutex + condition variable for all the per-batch stage flags of a device's pipeline.
+struct Flags {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::atomic<int> rc{0};
+  void set(std::vector<char>& f, int i) { { std::lock_guard<std::mutex> l(mu); f[i] = 1; } cv.notify_all(); }
+  // false: the pipeline has failed (the flag changes under the mutex the waiters test it under: no wake-up can be lost)
+  bool wait(const std::vector<char>& f, int i) {
+    if (i < 0) return rc.load() == 0;
+    std::unique_lock<std::mutex> l(mu);
+    cv.wait(l, [&] { return f[i] != 0 || rc.load() != 0; });
+    return rc.load() == 0;
+  }
+  void fail(int code) { { std::lock_guard<std::mutex> l(mu); if (rc.load() == 0) rc.store(code); } cv.notify_all(); }
+};
+
+// One device's slice of a call.
+int run_device(const CallArgs& a, Shard& sh) {
   if (sh.from >= sh.to) return 0;
-  const bool timing = getenv("WFAGPU_TIMING") != nullptr;
-  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  const double t_begin = now();
+  const double t_begin = now_ms();
   if (sh.slot < 0 || sh.slot >= MAX_DEV) return -1;
   std::lock_guard<std::mutex> guard(g_dev_mu[sh.slot]);
-  DevState* dp = nullptr;
-  if (acquire_dev(sh.slot, sh.device, &dp)) return -1;
-  DevState& d = *dp;
-  HIP_OK(hipSetDevice(sh.device));
-  const double t_created = now();
 
+  // ---- batches -------------------------------------------------------------------------------------------------------
   const size_t n_all = sh.to - sh.from;
   size_t bs = a.opt.batch_size ? std::min<size_t>(a.opt.batch_size, n_all) : n_all;
   bs = std::max<size_t>(1, bs);
-  // a single huge batch is cut in eight so that the stages have something to overlap (1M x 1 kbp pairs, two slices:
-  // 66 ms host to host with four batches per slice, 59 ms with eight)
-  static const size_t cut = getenv("WFAGPU_SLICE_BATCHES") ? (size_t)std::max(1, atoi(getenv("WFAGPU_SLICE_BATCHES"))) : 8;
-  if (bs == n_all && n_all >= ((size_t)1 << 17)) bs = (n_all + cut - 1) / cut;
+  // a single huge batch is cut so that the stages have something to overlap: the call ends one batch's compute + copy +
+  // scatter after the last byte has crossed PCIe, so smaller batches shorten the tail -- and add per-batch overhead on
+  // the device (measured, 1M x 1 kbp pairs, two lanes: 16 batches 43.8 ms, 24: 48.5; tapering the last two: 45.4)
   std::vector<BatchPlan> plan;
-  for (size_t from = sh.from; from < sh.to; from += bs) { BatchPlan b{}; b.from = from; b.to = std::min(sh.to, from + bs); plan.push_back(b); }
-  const int nb = (int)plan.size();
-
-  std::mutex mu;
-  std::condition_variable cv;
-  int uploaded = 0, computed = 0, scattered = 0;   // batches that finished each stage
-  std::atomic<int> rc{0};
-  double t_up = 0, t_dev = 0, t_d2h = 0, t_scatter = 0;
-  auto advance = [&](int& counter) { { std::lock_guard<std::mutex> l(mu); ++counter; } cv.notify_all(); };
-  auto wait_for = [&](const int& counter, int at_least) {
-    std::unique_lock<std::mutex> l(mu);
-    cv.wait(l, [&] { return counter >= at_least || rc.load() != 0; });
-    return rc.load() == 0;
+  auto add_batches = [&](size_t from, size_t to, size_t step) {
+    for (; from < to; from += step) { BatchPlan b{}; b.from = from; b.to = std::min(to, from + step); plan.push_back(b); }
   };
-  // (the flag changes under the mutex the waiters test it under: no wake-up can fall between their test and their block)
-  auto fail = [&](int code) { { std::lock_guard<std::mutex> l(mu); rc.store(code); } cv.notify_all(); };
+  if (bs == n_all && n_all >= ((size_t)1 << 17)) {
+    const size_t cut = a.cfg.batches_per_device > 0 ? (size_t)a.cfg.batches_per_device : 16;
+    bs = (n_all + cut - 1) / cut;
+    add_batches(sh.from, sh.to, bs);
+  } else {
+    add_batches(sh.from, sh.to, bs);
+  }
+  const int nb = (int)plan.size();
+  // Two lanes for big calls: the kernels of one fill the gaps (host round trips between kernel tiers, backtrace tails,
+  // result copies) of the other.
+  int K = a.cfg.lanes_per_device > 0 ? a.cfg.lanes_per_device : (n_all >= ((size_t)1 << 18) ? 2 : 1);
+  K = std::max(1, std::min({K, MAX_LANES, nb}));
 
-  std::thread uploader([&] {
-    if (hipSetDevice(sh.device) != hipSuccess) { fail(-1); return; }
-    std::vector<sequence_pair_t> hm;
+  DevState* dp = nullptr;
+  if (acquire_dev(sh.slot, sh.device, K, sh.sharers, a.cfg, &dp)) return -1;
+  DevState& d = *dp;
+  HIP_OK(hipSetDevice(sh.device));
+  const double t_created = now_ms();
+
+  // ---- input slots ---------------------------------------------------------------------------------------------------
+  // As many as the batches when the device has the room (then no upload ever waits for a computation), else a ring.
+  int R = nb;
+  {
+    size_t pool = a.cfg.input_pool_bytes;
+    if (!pool) {
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
+      size_t have = 0;
+      for (const auto& s : d.in) have += s.seq_cap + s.meta_cap * sizeof(sequence_pair_t);
+      pool = std::min<size_t>((size_t)24 << 30, (free_b + have) / 4 / (size_t)std::max(1, sh.sharers));
+    }
+    // (estimate from the first batch: the pairs of a call are of similar size; the slots grow on demand anyway)
+    const sequence_pair_t& m0 = a.meta[plan[0].from];
+    const sequence_pair_t& m1 = a.meta[plan[0].to - 1];
+    const size_t lo0 = std::min(m0.pattern_offset, m0.text_offset), hi0 = std::max(m1.pattern_offset + m1.pattern_len, m1.text_offset + m1.text_len);
+    const size_t per_batch = (hi0 > lo0 ? hi0 - lo0 : 0) + (plan[0].to - plan[0].from) * sizeof(sequence_pair_t) + 4096;
+    R = (int)std::max<size_t>((size_t)std::min(nb, K + 2), std::min<size_t>((size_t)nb, pool / std::max<size_t>(1, per_batch)));
+  }
+  if ((int)d.in.size() < R) d.in.resize(R);
+  while ((int)d.up_done.size() < nb) {
+    hipEvent_t e = nullptr;
+    HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    d.up_done.push_back(e);
+  }
+
+  Flags fl;
+  std::vector<char> prepped(nb, 0), uploaded(nb, 0), computed(nb, 0), scattered(nb, 0);
+  struct StageTimes { double prep = 0, up = 0, up_wait = 0, dev = 0, dev_wait = 0, d2h = 0, scatter = 0, check = 0; };
+  StageTimes t_prep_thread, t_up_thread;
+  std::vector<StageTimes> t_lane(K), t_scat(K);
+
+  // ---- stage 0: spans and packed offsets (host only) -----------------------------------------------------------------
+  std::thread prepper([&] {
     for (int i = 0; i < nb; ++i) {
-      if (!wait_for(computed, i - 1)) return;           // input buffer i % 2 is free once batch i-2 has been computed
-      const double t0 = now();
+      if (fl.rc.load()) return;
+      const double t0 = now_ms();
       BatchPlan& b = plan[i];
       const size_t n = b.to - b.from;
       // span of the batch inside the caller's buffer (lib/align.cu:80-93 takes it from the first/last
@@ -294,14 +411,27 @@ int run_shard(const CallArgs& a, Shard& sh) {
       }
       lo &= ~(size_t)3;
       hi = std::min(a.seq_bytes, (hi + 4) & ~(size_t)3);
-      b.lo = lo; b.span = hi - lo; b.max_len = max_len;
+      b.lo = lo; b.span = hi > lo ? hi - lo : 0; b.max_len = max_len;
       // packed offsets: written into the caller's metadata like the reference
       // (lib/align.cu:103-115,363-377), relative to the batch
       b.packed_bytes = wfagpu_amd_fill_packed_offsets(a.meta + b.from, n);
-      hm.assign(a.meta + b.from, a.meta + b.to);
-      for (auto& m : hm) { m.pattern_offset -= lo; m.text_offset -= lo; }
-      DevState::In& in = d.in[i & 1];
-      auto ok = [&](hipError_t e, const char* what) { if (e != hipSuccess) { LOG_ERROR("HIP call %s failed: %s", what, hipGetErrorString(e)); fail(-1); return false; } return true; };
+      t_prep_thread.prep += now_ms() - t0;
+      fl.set(prepped, i);
+    }
+  });
+
+  // ---- stage 1: H2D, one batch after the other -------------------------------------------------------------------------
+  std::thread uploader([&] {
+    if (hipSetDevice(sh.device) != hipSuccess) { fl.fail(-1); return; }
+    auto ok = [&](hipError_t e, const char* what) { if (e != hipSuccess) { LOG_ERROR("HIP call %s failed: %s", what, hipGetErrorString(e)); fl.fail(-1); return false; } return true; };
+    for (int i = 0; i < nb; ++i) {
+      double t0 = now_ms();
+      if (!fl.wait(prepped, i)) return;
+      if (!fl.wait(computed, i - R)) return;          // (a ring of slots: the one of batch i - R must have been consumed)
+      t_up_thread.up_wait += now_ms() - t0; t0 = now_ms();
+      const BatchPlan& b = plan[i];
+      const size_t n = b.to - b.from;
+      InSlot& in = d.in[i % R];
       if (b.span + 16 > in.seq_cap) {
         if (in.d_seq) (void)hipFree(in.d_seq);
         in.d_seq = nullptr; in.seq_cap = b.span + b.span / 8 + 16;
@@ -312,77 +442,92 @@ int run_shard(const CallArgs& a, Shard& sh) {
         in.d_meta = nullptr; in.meta_cap = n + n / 8;
         if (!ok(hipMalloc(&in.d_meta, in.meta_cap * sizeof(sequence_pair_t)), "hipMalloc(metadata)")) return;
       }
-      if (!ok(hipMemcpyAsync(in.d_seq, a.seq + lo, b.span, hipMemcpyHostToDevice, d.up), "H2D sequences")) return;
-      if (!ok(hipMemcpyAsync(in.d_meta, hm.data(), n * sizeof(sequence_pair_t), hipMemcpyHostToDevice, d.up), "H2D metadata")) return;
-      if (!ok(hipStreamSynchronize(d.up), "H2D sync")) return;
-      t_up += now() - t0;
-      advance(uploaded);
+      // (the records go up as they are: the kernels see the sequences through a base pointer moved back by b.lo, so the
+      // caller's offsets need no rebasing and no host copy)
+      if (b.span && !ok(hipMemcpyAsync(in.d_seq, a.seq + b.lo, b.span, hipMemcpyHostToDevice, d.up), "H2D sequences")) return;
+      if (!ok(hipMemcpyAsync(in.d_meta, a.meta + b.from, n * sizeof(sequence_pair_t), hipMemcpyHostToDevice, d.up), "H2D metadata")) return;
+      // (no synchronisation here: the copies of the next batch follow back to back; the lane that takes this batch
+      // waits for the event)
+      if (!ok(hipEventRecord(d.up_done[i], d.up), "H2D event")) return;
+      t_up_thread.up += now_ms() - t0;
+      fl.set(uploaded, i);
     }
   });
 
-  std::thread scatterer([&] {
-    for (int i = 0; i < nb; ++i) {
-      if (!wait_for(computed, i + 1)) return;
-      const double t0 = now();
+  // ---- stage 3: staging -> the caller's records (+ -c), one thread per lane --------------------------------------------
+  const unsigned lane_threads = std::max(1u, sh.host_threads / (unsigned)K);
+  auto scatter_lane = [&](int k) {
+    int j = 0;
+    for (int i = k; i < nb; i += K, ++j) {
+      if (!fl.wait(computed, i)) return;
+      const double t0 = now_ms();
       const BatchPlan& b = plan[i];
       const size_t n = b.to - b.from;
-      const DevState::Out& o = d.out[i & 1];
+      const Lane::Out& o = d.lane[k].out[j & 1];
       std::atomic<int> bad{0};
+      // Every cigar.buffer stays the caller's own, individually free()-able allocation (the ABI: lib/alignment_results.c).
+      // One that is too small grows to the longest text of the batch, so that the following calls of a process (same
+      // reads, similar CIGARs) find every buffer big enough: no realloc in the steady state.
+      unsigned max_len = 0;
+      if (a.cigar) for (size_t q = 0; q < n; ++q) if (o.len[q] != 0xFFFFFFFFu) max_len = std::max(max_len, o.len[q]);
+      const size_t grow_to = (size_t)max_len + 1;
       auto work = [&](size_t j0, size_t j1) {
-        for (size_t j = j0; j < j1; ++j) {
-          wfa_alignment_result_t& r = a.results[b.from + j];
-          r.error = (unsigned int)o.score[j];
+        for (size_t q = j0; q < j1; ++q) {
+          wfa_alignment_result_t& r = a.results[b.from + q];
+          r.error = (unsigned int)o.score[q];
           if (!a.cigar) continue;
-          if (o.len[j] == 0xFFFFFFFFu) { LOG_ERROR("CIGAR recovery failed for pair %zu", b.from + j); bad.store(1); continue; }
+          if (o.len[q] == 0xFFFFFFFFu) { LOG_ERROR("CIGAR recovery failed for pair %zu", b.from + q); bad.store(1); continue; }
           wfa_cigar_t& cg = r.cigar;
-          const size_t need = (size_t)o.len[j] + 1;
+          const size_t need = (size_t)o.len[q] + 1;
           if (need > cg.buffer_size || !cg.buffer) {
-            char* nbuf = static_cast<char*>(realloc(cg.buffer, need));
+            char* nbuf = static_cast<char*>(realloc(cg.buffer, grow_to));
             if (!nbuf) { LOG_ERROR("Can not realloc CIGAR buffer"); exit(-1); }   // utils/wfa_cpu.c:77-80
-            cg.buffer = nbuf; cg.buffer_size = need;
+            cg.buffer = nbuf; cg.buffer_size = grow_to;
           }
-          memcpy(cg.buffer, o.text + o.off[j], need);
-          cg.last_free_position = o.len[j];
+          memcpy(cg.buffer, o.text + o.off[q], need);
+          cg.last_free_position = o.len[q];
         }
       };
-      const unsigned nt = a.cigar ? (unsigned)std::min<size_t>(std::max(1u, std::min(8u, sh.host_threads)), (n + 8191) / 8192) : 1u;
-      if (nt <= 1) work(0, n);
-      else {
-        std::vector<std::thread> pool;
-        for (unsigned t = 1; t < nt; ++t) pool.emplace_back(work, n * t / nt, n * (t + 1) / nt);
-        work(0, n / nt);
-        for (auto& t : pool) t.join();
-      }
-      if (bad.load()) { fail(-1); return; }
-      if (a.check) check_batch(a, b.from, b.to, i, sh.host_threads);
-      t_scatter += now() - t0;
-      advance(scattered);
+      // strips of consecutive pairs per thread
+      const unsigned nt = a.cigar ? (unsigned)std::min<size_t>(std::min(8u, lane_threads), (n + 8191) / 8192) : 1u;
+      parallel_for(std::max(1u, nt), [&](unsigned t) { work(n * t / std::max(1u, nt), n * (t + 1) / std::max(1u, nt)); });
+      t_scat[k].scatter += now_ms() - t0;
+      if (bad.load()) { fl.fail(-1); return; }
+      if (a.check) { const double t1 = now_ms(); check_batch(a, b.from, b.to, i, lane_threads); t_scat[k].check += now_ms() - t1; }
+      fl.set(scattered, i);
     }
-  });
+  };
 
-  auto compute = [&]() -> int {
-    for (int i = 0; i < nb; ++i) {
-      if (!wait_for(uploaded, i + 1)) return rc.load();
-      double t0 = now();
-      BatchPlan& b = plan[i];
+  // ---- stage 2: the kernels + D2H, K lanes on alternate batches ----------------------------------------------------------
+  auto compute_lane = [&](int k) -> int {
+    HIP_OK(hipSetDevice(sh.device));
+    Lane& L = d.lane[k];
+    int j = 0;
+    for (int i = k; i < nb; i += K, ++j) {
+      double t0 = now_ms();
+      if (!fl.wait(uploaded, i)) return fl.rc.load();
+      HIP_OK(hipEventSynchronize(d.up_done[i]));
+      t_lane[k].dev_wait += now_ms() - t0; t0 = now_ms();
+      const BatchPlan& b = plan[i];
       const size_t n = b.to - b.from;
-      DevState::In& in = d.in[i & 1];
-      if (n > d.scores_cap) {
-        if (d.d_scores) (void)hipFree(d.d_scores);
-        d.d_scores = nullptr; d.scores_cap = n + n / 8;
-        HIP_OK(hipMalloc(&d.d_scores, d.scores_cap * sizeof(int32_t)));
+      const InSlot& in = d.in[i % R];
+      if (n > L.scores_cap) {
+        if (L.d_scores) (void)hipFree(L.d_scores);
+        L.d_scores = nullptr; L.scores_cap = n + n / 8;
+        HIP_OK(hipMalloc(&L.d_scores, L.scores_cap * sizeof(int32_t)));
       }
       wfagpu_amd_batch_t wb{};
-      wb.d_sequences = in.d_seq; wb.sequences_bytes = b.span; wb.d_metadata = in.d_meta; wb.num_pairs = n;
+      wb.d_sequences = reinterpret_cast<const char*>(reinterpret_cast<uintptr_t>(in.d_seq) - b.lo);     // [offset of the caller's buffer]
+      wb.sequences_bytes = b.lo + b.span; wb.d_metadata = in.d_meta; wb.num_pairs = n;
       wb.packed_bytes = b.packed_bytes; wb.max_seq_len = b.max_len;
       const char* d_text = nullptr; const unsigned long long* d_off = nullptr; const unsigned int* d_len = nullptr;
-      wfagpu_amd_hint_same_stream(d.ctx, i > 0 ? 1 : 0);     // the batches of a call come from one stream of reads
-      const int arc = wfagpu_amd_align_device(d.ctx, &wb, a.opt.penalties, a.opt.max_error, a.opt.band, a.opt.threads_per_block, a.cigar,
-                                              d.d_scores, &d_text, &d_off, &d_len);
+      wfagpu_amd_hint_same_stream(L.ctx, j > 0 ? 1 : 0);     // the batches of a call come from one stream of reads
+      const int arc = wfagpu_amd_align_device(L.ctx, &wb, a.opt.penalties, a.opt.max_error, a.opt.band, a.opt.threads_per_block, a.cigar,
+                                              L.d_scores, &d_text, &d_off, &d_len);
       if (arc) return arc;
-      t_dev += now() - t0; t0 = now();
-      if (!wait_for(scattered, i - 1)) return rc.load();   // staging i % 2 is free once batch i-2 has been scattered
-      DevState::Out& o = d.out[i & 1];
+      t_lane[k].dev += now_ms() - t0; t0 = now_ms();
+      if (!fl.wait(scattered, i - 2 * K)) return fl.rc.load();   // staging j % 2 is free once this lane's batch j-2 has been scattered
+      Lane::Out& o = L.out[j & 1];
       if (n > o.n_cap) {
         const size_t cap = n + n / 8;
         if (grow_pinned(&o.score, cap)) return -1;
@@ -393,33 +538,49 @@ int run_shard(const CallArgs& a, Shard& sh) {
         if (grow_pinned(&o.off, cap) || grow_pinned(&o.len, cap)) return -1;
         o.cig_cap = cap;
       }
-      HIP_OK(hipMemcpyAsync(o.score, d.d_scores, n * sizeof(int32_t), hipMemcpyDeviceToHost, d.down));
+      HIP_OK(hipMemcpyAsync(o.score, L.d_scores, n * sizeof(int32_t), hipMemcpyDeviceToHost, L.down));
       if (a.cigar) {
-        wfagpu_amd_stats_t stt; wfagpu_amd_last_stats(d.ctx, &stt);
-        b.text_bytes = stt.text_bytes;
+        wfagpu_amd_stats_t stt; wfagpu_amd_last_stats(L.ctx, &stt);
         if (stt.text_bytes + 1 > o.text_cap) {
           const size_t cap = (size_t)stt.text_bytes + (size_t)stt.text_bytes / 8 + 4096;
           if (grow_pinned(&o.text, cap)) return -1;
           o.text_cap = cap;
         }
-        HIP_OK(hipMemcpyAsync(o.off, d_off, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, d.down));
-        HIP_OK(hipMemcpyAsync(o.len, d_len, n * sizeof(unsigned int), hipMemcpyDeviceToHost, d.down));
-        if (stt.text_bytes) HIP_OK(hipMemcpyAsync(o.text, d_text, stt.text_bytes, hipMemcpyDeviceToHost, d.down));
+        HIP_OK(hipMemcpyAsync(o.off, d_off, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, L.down));
+        HIP_OK(hipMemcpyAsync(o.len, d_len, n * sizeof(unsigned int), hipMemcpyDeviceToHost, L.down));
+        if (stt.text_bytes) HIP_OK(hipMemcpyAsync(o.text, d_text, stt.text_bytes, hipMemcpyDeviceToHost, L.down));
       }
-      HIP_OK(hipStreamSynchronize(d.down));
-      t_d2h += now() - t0;
-      advance(computed);
+      HIP_OK(hipStreamSynchronize(L.down));
+      t_lane[k].d2h += now_ms() - t0;
+      fl.set(computed, i);
     }
     return 0;
   };
-  const int crc = compute();
-  if (crc) fail(crc);
+
+  std::vector<std::thread> scat, comp;
+  for (int k = 0; k < K; ++k) scat.emplace_back(scatter_lane, k);
+  for (int k = 1; k < K; ++k) comp.emplace_back([&, k] { const int c = compute_lane(k); if (c) fl.fail(c); });
+  { const int c = compute_lane(0); if (c) fl.fail(c); }
+  for (auto& t : comp) t.join();
+  prepper.join();
   uploader.join();
-  scatterer.join();
-  if (timing)
-    fprintf(stderr, "[wfagpu timing] device %d: %d batches, acquire %.1f ms, upload %.1f, device %.1f, d2h %.1f, scatter %.1f (overlapped), total %.1f\n",
-            sh.device, nb, t_created - t_begin, t_up, t_dev, t_d2h, t_scatter, now() - t_begin);
-  return rc.load();
+  for (auto& t : scat) t.join();
+
+  wfagpu_amd_launch_stats_t& st = sh.st;
+  st.total_ms = now_ms() - t_begin;
+  st.acquire_ms = t_created - t_begin;
+  st.prep_ms = t_prep_thread.prep; st.upload_ms = t_up_thread.up; st.upload_wait_ms = t_up_thread.up_wait;
+  for (int k = 0; k < K; ++k) {
+    st.device_ms += t_lane[k].dev; st.device_wait_ms += t_lane[k].dev_wait; st.d2h_ms += t_lane[k].d2h;
+    st.scatter_ms += t_scat[k].scatter; st.check_ms += t_scat[k].check;
+  }
+  st.lanes = K; st.batches = nb;
+  if (a.cfg.timing)
+    fprintf(stderr, "[wfagpu timing] device %d (slot %d): %d batches, %d lanes, %d input slots; acquire %.1f ms, prep %.1f, upload %.1f (+%.1f waiting), "
+            "device %.1f (+%.1f waiting), d2h %.1f, scatter %.1f, check %.1f; total %.1f\n",
+            sh.device, sh.slot, nb, K, R, st.acquire_ms, st.prep_ms, st.upload_ms, st.upload_wait_ms, st.device_ms, st.device_wait_ms,
+            st.d2h_ms, st.scatter_ms, st.check_ms, st.total_ms);
+  return fl.rc.load();
 }
 
 void launch_impl(char* seq, size_t seq_bytes, sequence_pair_t* meta, wfa_alignment_result_t* results,
@@ -427,67 +588,98 @@ void launch_impl(char* seq, size_t seq_bytes, sequence_pair_t* meta, wfa_alignme
   if (!seq || !meta || !results) { LOG_ERROR("Invalid buffers."); return; }
   const size_t n = opt.num_alignments;
   if (n == 0) return;
+  const double t_begin = now_ms();
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
     LOG_ERROR("No HIP device available.");
     exit(-1);   // utils/cuda_utils.cuh:28-35: device errors are fatal
   }
-  const int want = g_num_devices.load();
-  if (want > 0) ndev = std::min(ndev, want);
-  // WFAGPU_VIRTUAL_DEVICES=k (tests): k shards with their own threads, contexts and streams, mapped round-robin
+  CallArgs a{seq, seq_bytes, meta, results, opt, check, cigar, {}};
+  { std::lock_guard<std::mutex> l(g_cfg_mu); a.cfg = g_cfg; }
+  if (a.cfg.num_devices > 0) ndev = std::min(ndev, a.cfg.num_devices);
+  // virtual devices (tests): that many shards with their own threads, contexts and streams, mapped round-robin
   // onto the physical devices -- exercises the multi-device path on a single GPU
   const int physical = ndev;
-  // Two slices per device for big calls: the kernels of one slice fill the gaps (host round trips, backtrace
-  // tails, copies) of the other -- 1M 1 kbp pairs with CIGARs: 81 -> 73 ms host to host, same cold-call time.
-  if (n / (size_t)physical >= ((size_t)1 << 18)) ndev = std::min(MAX_DEV, 2 * physical);
-  if (const char* e = getenv("WFAGPU_VIRTUAL_DEVICES")) ndev = std::max(1, std::min(MAX_DEV, atoi(e)));
-  ndev = (int)std::min<size_t>((size_t)ndev, n);
-  CallArgs a{seq, seq_bytes, meta, results, opt, check, cigar};
+  if (a.cfg.virtual_devices > 0) ndev = std::min(MAX_DEV, a.cfg.virtual_devices);
+  ndev = (int)std::min<size_t>((size_t)std::min(ndev, MAX_DEV), n);
   g_check_failures.store(0);
+  const unsigned host_threads = usable_host_threads();
   std::vector<Shard> shards(ndev);
   // Contiguous slices of equal WORK, not of equal count: the wavefront work of a pair grows with P x T (score^2 at a
-  // given error rate), so a ragged batch cut by count would leave devices idle.  One pass over the records.
+  // given error rate), so a ragged batch cut by count would leave devices idle.  Partial sums per strip in parallel,
+  // then one scan over the strip that holds each cut.
   std::vector<size_t> cut(ndev + 1, n);
   cut[0] = 0;
   if (ndev > 1) {
-    long double total = 0;
-    for (size_t i = 0; i < n; ++i) total += (long double)meta[i].pattern_len * meta[i].text_len + 1024.0L;   // (+ a per-pair constant)
-    long double acc = 0;
-    int d = 1;
-    for (size_t i = 0; i < n && d < ndev; ++i) {
-      acc += (long double)meta[i].pattern_len * meta[i].text_len + 1024.0L;
-      while (d < ndev && acc >= total * d / ndev) cut[d++] = i + 1;
+    auto work_of = [&](size_t i) { return (double)meta[i].pattern_len * (double)meta[i].text_len + 1024.0; };   // (+ a per-pair constant)
+    const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(16u, host_threads), n / 65536));
+    std::vector<double> part(nt, 0.0);
+    parallel_for(nt, [&](unsigned t) { double s = 0; for (size_t i = n * t / nt; i < n * (t + 1) / nt; ++i) s += work_of(i); part[t] = s; });
+    double total = 0;
+    for (double p : part) total += p;
+    double acc = 0;
+    int dcut = 1;
+    for (unsigned t = 0; t < nt && dcut < ndev; ++t) {
+      if (acc + part[t] < total * dcut / ndev) { acc += part[t]; continue; }
+      for (size_t i = n * t / nt; i < n * (t + 1) / nt && dcut < ndev; ++i) {
+        acc += work_of(i);
+        while (dcut < ndev && acc >= total * dcut / ndev) cut[dcut++] = i + 1;
+      }
     }
   }
-  const unsigned host_threads = usable_host_threads();
   for (int d = 0; d < ndev; ++d) {
     shards[d].device = d % physical;
     shards[d].slot = d;
+    shards[d].sharers = (ndev - 1 - (d % physical)) / physical + 1;      // slots mapped onto the same physical device
     shards[d].from = cut[d];
     shards[d].to = cut[d + 1];
     shards[d].host_threads = std::max(1u, std::min(64u, host_threads / (unsigned)ndev));
   }
+  const double t_planned = now_ms();
   if (ndev == 1) {
-    shards[0].rc = run_shard(a, shards[0]);
+    shards[0].rc = run_device(a, shards[0]);
   } else {
     std::vector<std::thread> th;
-    // (own threads, one per slice: each may be moved to the cores next to its GPU; the caller's thread is never touched)
+    // (own threads, one per device: each may be moved to the cores next to its GPU; the caller's thread is never touched)
+    const bool pin = a.cfg.numa_pin > 0 || (a.cfg.numa_pin == 0 && physical > 1);
     for (int d = 0; d < ndev; ++d)
-      th.emplace_back([&a, &shards, d, physical] {
-        if (physical > 1 || getenv("WFAGPU_FORCE_NUMA_PIN")) pin_to_device_node(shards[d].device);    // (the variable: test hook for one-GPU boxes)
-        shards[d].rc = run_shard(a, shards[d]);
+      th.emplace_back([&a, &shards, d, pin] {
+        if (pin) pin_to_device_node(shards[d].device);
+        shards[d].rc = run_device(a, shards[d]);
       });
     for (auto& t : th) t.join();
   }
   for (auto& s : shards)
     if (s.rc) { LOG_ERROR("Alignment failed on device %d (code %d).", s.device, s.rc); exit(-1); }
+  // stage times of the busiest device
+  wfagpu_amd_launch_stats_t st{};
+  for (auto& s : shards) if (s.st.total_ms >= st.total_ms) st = s.st;
+  st.plan_ms = t_planned - t_begin;
+  st.devices = ndev;
+  st.host_threads = host_threads;
+  st.total_ms = now_ms() - t_begin;
+  { std::lock_guard<std::mutex> l(g_cfg_mu); g_last_stats = st; }
 }
 
 }  // namespace
 
 extern "C" {
 
-void wfagpu_amd_set_num_devices(int n) { g_num_devices.store(n < 0 ? 0 : n); }
+void wfagpu_amd_configure_launch(const wfagpu_amd_launch_config_t* cfg) {
+  std::lock_guard<std::mutex> l(g_cfg_mu);
+  g_cfg = cfg ? *cfg : wfagpu_amd_launch_config_t{};
+}
+
+void wfagpu_amd_last_launch_stats(wfagpu_amd_launch_stats_t* out) {
+  if (!out) return;
+  std::lock_guard<std::mutex> l(g_cfg_mu);
+  *out = g_last_stats;
+}
+
+void wfagpu_amd_set_num_devices(int n) {
+  std::lock_guard<std::mutex> l(g_cfg_mu);
+  g_cfg.num_devices = n < 0 ? 0 : n;
+}
 
 long wfagpu_amd_check_failures(void) { return g_check_failures.load(); }
 

@@ -54,29 +54,40 @@ bool check_affine_distance(const char* text, const char* pattern, size_t tlen, s
 
 /* Furthest-reaching points per (score, diagonal): the plain textbook formulation (the span grows by one diagonal per
  * side and score, nothing is trimmed, three score-indexed tables) so that it shares nothing with the kernels it
- * checks.  Storage is a ring of depth max(x, o+e)+1 rows per table over columns k + plen + 1, kept in a per-thread
- * scratch that is grown, never freed per pair, and never bulk-filled: spans only grow, so a ring slot is always
+ * checks.  Storage is a ring of depth max(x, o+e)+1 rows per table over columns k + plen + 1, kept in a scratch the
+ * caller owns (one per worker) that is grown, never freed per pair, and never bulk-filled: spans only grow, so a ring slot is always
  * reused by a WIDER row, and the only cells a read can reach that the slot's current row has not written are columns
  * that entered the span after the slot's previous (narrower) row was written -- those are set to NONE in every slot
  * of the ring at the moment they enter (two columns per score). */
-static __thread int* vs_buf = NULL;
-static __thread size_t vs_cap = 0;
+void verification_scratch_free(verification_scratch_t* sc) {
+    if (!sc) return;
+    free(sc->buf);
+    sc->buf = NULL; sc->cap = 0;
+}
 
-int verification_cpu_score(const char* pattern, const char* text, size_t plen_, size_t tlen_,
-                           int x, int o, int e) {
+int verification_cpu_score(const char* pattern, const char* text, size_t plen, size_t tlen, int x, int o, int e) {
+    verification_scratch_t sc = {NULL, 0};
+    const int s = verification_cpu_score_scratch(pattern, text, plen, tlen, x, o, e, &sc);
+    verification_scratch_free(&sc);
+    return s;
+}
+
+int verification_cpu_score_scratch(const char* pattern, const char* text, size_t plen_, size_t tlen_,
+                                   int x, int o, int e, verification_scratch_t* sc) {
     const int plen = (int)plen_, tlen = (int)tlen_;
     const int W = plen + tlen + 5, K0 = plen + 2;
     const int NONE = -(1 << 28);
     const int oe = o + e;
     const int depth = (x > oe ? x : oe) + 1;
     const size_t need = (size_t)W * 3 * (size_t)depth;
-    if (need > vs_cap) {
-        free(vs_buf);
-        vs_cap = need + need / 4;
-        vs_buf = (int*)malloc(sizeof(int) * vs_cap);
-        if (!vs_buf) { vs_cap = 0; return -1; }
+    if (!sc) return -1;
+    if (need > sc->cap) {
+        free(sc->buf);
+        sc->cap = need + need / 4;
+        sc->buf = (int*)malloc(sizeof(int) * sc->cap);
+        if (!sc->buf) { sc->cap = 0; return -1; }
     }
-    int* M = vs_buf; int* I = M + (size_t)W * depth; int* D = I + (size_t)W * depth;
+    int* M = sc->buf; int* I = M + (size_t)W * depth; int* D = I + (size_t)W * depth;
     const int kend = tlen - plen;
     /* columns -1, 0, 1 of every slot: the span of score 0 and its guards */
     for (int r = 0; r < depth; ++r)

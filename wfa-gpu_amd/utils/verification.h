@@ -22,7 +22,16 @@ bool check_affine_distance(const char* text, const char* pattern, size_t tlen, s
                            int distance, int x, int o, int e, const char* cigar);
 
 /* Optimal gap-affine score by a scalar dynamic program over (score,
- * diagonal); O(score * width) time.  Independent of the GPU kernels. */
+ * diagonal); O(score * width) time.  Independent of the GPU kernels.
+ * The working memory belongs to the caller: one zero-initialised
+ * verification_scratch_t per worker thread, reused across pairs (it only
+ * grows) and released with verification_scratch_free -- nothing is kept in
+ * thread-local storage, so short-lived worker threads leak nothing. */
+typedef struct { int* buf; size_t cap; } verification_scratch_t;
+int verification_cpu_score_scratch(const char* pattern, const char* text, size_t plen, size_t tlen,
+                                   int x, int o, int e, verification_scratch_t* scratch);
+void verification_scratch_free(verification_scratch_t* scratch);
+/* One-off form: allocates and frees its own scratch. */
 int verification_cpu_score(const char* pattern, const char* text, size_t plen, size_t tlen,
                            int x, int o, int e);
 

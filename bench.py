@@ -179,6 +179,7 @@ def host_to_host(buf, meta, wl, max_error, n_devices=1, reps=8, registered=False
                         "cold": round(n / ms[0] * 1e3, 1), "warm": round(n / med_ms * 1e3, 1),
                         "best": round(n / steady[0][0] * 1e3, 1), "calls_ms": [round(m, 2) for m in ms]},
            "stages_ms": {k: (round(v, 2) if isinstance(v, float) else v) for k, v in med_stats.items()},
+           "cold_stages_ms": {k: (round(v, 2) if isinstance(v, float) else v) for k, v in calls[0][1].items()},
            "input_bytes": int(buf.nbytes)}
     if registered:
         hip = wfagpu._hiprt()

@@ -203,7 +203,9 @@ wfa_align_kernel(const WfaAlignParams p) {
     uint32_t w = 0xFFFFFFFFu;
     {
       ColdParams cp = cold_params();
-      const uint32_t nsh = cp->work_shards, n_work = cp->n_work;
+      const uint32_t nsh = cp->work_shards;
+      uint32_t n_work = cp->n_work;
+      { const unsigned long long* nd = cp->n_work_dev; if (nd) n_work = min(n_work, (uint32_t)*nd); }      // (list length still on the device)
       while (shards_left) {
         const uint32_t lo_w = (uint32_t)(((unsigned long long)n_work * shard) / nsh);
         const uint32_t hi_w = (uint32_t)(((unsigned long long)n_work * (shard + 1)) / nsh);
@@ -218,6 +220,7 @@ wfa_align_kernel(const WfaAlignParams p) {
     const uint32_t* work = cold_params()->work;
     // (every thread loads the same words; readfirstlane tells the compiler so)
     const uint32_t pair = __builtin_amdgcn_readfirstlane(work ? work[w] : w);
+    if (cold_params()->only_pending && __builtin_amdgcn_readfirstlane(cold_params()->status[pair]) != WFA_ST_PENDING) continue;   // (uniform)
     const WfaSeqPair mp = cold_params()->meta[pair];
     const int plen = __builtin_amdgcn_readfirstlane((int)mp.pattern_len), tlen = __builtin_amdgcn_readfirstlane((int)mp.text_len);
     const int kend = tlen - plen;

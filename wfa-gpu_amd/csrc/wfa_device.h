@@ -61,6 +61,9 @@ struct WfaAlignParams {
   const WfaSeqPair* meta;
   const uint32_t* work;          // pair indices to process (NULL: identity)
   uint32_t n_work;
+  const unsigned long long* n_work_dev;   // optional: the list's real length lives on the device (a list compacted by the launch
+                                          // before, not read back by the host yet); n_work is then an upper bound
+  int only_pending;              // 1: skip pairs whose status is not PENDING (an unfiltered list: pairs flagged for the byte-compare class)
   unsigned int* work_counter;    // dynamic work distribution: 8 counters, 64 bytes apart (zeroed before launch)
   uint32_t work_shards;          // 1 or 8 of them in use
   int x, oe, e;                  // penalties: mismatch, open+extend, extend

@@ -80,7 +80,10 @@ struct DevBuf {
 };
 
 // device counters (u64 slots)
-enum { CT_ARENA = 0, CT_OPS = 1, CT_TEXT = 2, CT_LCELLS = 3, CT_LIST = 4, CT_SUM_OPS = 5, CT_SUM_TEXT = 6, CT_CELLS = 7, CT_MAX_SCORE = 8, CT_NRAW = 9, CT_SCRATCH = 10, CT_N = 11 };
+// (CT_LCELLS/CT_LIST and CT_LCELLS2/CT_LIST2: cell count and failure-list length of the first and second wavefront launch of
+// a chain, zeroed in pairs; CT_NOMEM: length of the list of pairs that ran out of arena in the current pass)
+enum { CT_ARENA = 0, CT_OPS = 1, CT_TEXT = 2, CT_LCELLS = 3, CT_LIST = 4, CT_SUM_OPS = 5, CT_SUM_TEXT = 6, CT_CELLS = 7, CT_MAX_SCORE = 8, CT_NRAW = 9, CT_SCRATCH = 10,
+       CT_LCELLS2 = 11, CT_LIST2 = 12, CT_NOMEM = 13, CT_N = 14 };
 
 constexpr uint32_t MASK(uint32_t st) { return 1u << st; }
 
@@ -102,10 +105,13 @@ __device__ __forceinline__ void block_append(bool take, uint32_t value, uint32_t
   if (take) out[block_base + wave_n[wave] + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = value;
 }
 
-// pairs of `work` whose status is in `mask` -> out list
-__global__ void __launch_bounds__(1024) k_compact(const uint32_t* __restrict__ work, uint32_t n, const uint32_t* __restrict__ status,
+// pairs of `work` whose status is in `mask` -> out list (appended at *out_count).  n_dev (optional): the real length of
+// `work` where only the device knows it yet; n is then an upper bound.
+__global__ void __launch_bounds__(1024) k_compact(const uint32_t* __restrict__ work, uint32_t n, const unsigned long long* __restrict__ n_dev,
+                          const uint32_t* __restrict__ status,
                           uint32_t mask, uint32_t* __restrict__ out, unsigned long long* __restrict__ out_count) {
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n_dev) n = min(n, (uint32_t)*n_dev);
   bool take = false; uint32_t pair = 0;
   if (gid < n) { pair = work ? work[gid] : gid; take = (mask >> status[pair]) & 1u; }
   block_append(take, pair, out, out_count);
@@ -149,8 +155,8 @@ __global__ void __launch_bounds__(256) k_trace_bounds(const uint32_t* __restrict
       ops += (s + 3u) & ~3u;
       const uint32_t m = s / (uint32_t)min_op_cost;
       txt += (unsigned long long)item_chars * (2ull * m + 1ull) + 1ull;
+      if (cells) cl += cells[pair];       // (of the launch that finished the pair)
     }
-    if (cells && status[pair] != WFA_ST_PENDING) cl += cells[pair];
   }
   for (int d = 32; d > 0; d >>= 1) {
     ops += __shfl_down((unsigned long long)ops, d);
@@ -210,12 +216,22 @@ __global__ void k_scale_scores(int32_t* __restrict__ score, uint32_t n, int g) {
   if (gid < n && score[gid] > 0) score[gid] *= g;
 }
 
+__global__ void k_iota(uint32_t* __restrict__ out, uint32_t first, uint32_t n) {
+  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid < n) out[gid] = first + gid;
+}
+
 __global__ void k_set_pending(const uint32_t* __restrict__ work, uint32_t n, uint32_t* __restrict__ status) {
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
   if (gid < n) status[work ? work[gid] : gid] = WFA_ST_PENDING;
 }
 
 inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+// Workgroup size of a list compaction.  Big lists: 1024 threads, one atomic per workgroup.  Lists of a batch of a
+// pipelined call: one wavefront per workgroup, which finds a free wave slot next to the persistent wavefront kernel of
+// the device's other lane (a 16-wave workgroup waits until a whole CU drains: measured 1.7 ms for a 5 us kernel).
+inline uint32_t compact_block(uint32_t n) { return n <= (1u << 18) ? 64u : 1024u; }
 
 }  // namespace
 
@@ -229,7 +245,7 @@ struct wfagpu_amd_ctx {
   wfagpu_amd_tuning_t tuning{};
   DevBuf packed, flags, status, cells, bt_final, list_a, list_b, list_c, list_d, list_e, work_ctr, sample, ratio, budget, counters, arena, ops, text, text_scratch, cig_off, cig_len, gring;
   unsigned long long* h_counters = nullptr;  // pinned
-  hipEvent_t ev_start = nullptr, ev_pack = nullptr, ev_a0 = nullptr, ev_a1 = nullptr, ev_t0 = nullptr, ev_t1 = nullptr, ev_end = nullptr;
+  hipEvent_t ev_start = nullptr, ev_pack = nullptr, ev_a0 = nullptr, ev_a1 = nullptr, ev_b0 = nullptr, ev_b1 = nullptr, ev_t0 = nullptr, ev_t1 = nullptr, ev_end = nullptr;
   wfagpu_amd_stats_t stats{};
   // budgets learnt from the sample of an earlier batch of the same stream (wfagpu_amd_hint_same_stream)
   bool same_stream = false;
@@ -271,6 +287,7 @@ int wfagpu_amd_create(wfagpu_amd_ctx_t** out, const wfagpu_amd_config_t* cfg) {
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_counters), CT_N * sizeof(unsigned long long), hipHostMallocDefault));
     HIP_TRY(hipEventCreate(&c->ev_start)); HIP_TRY(hipEventCreate(&c->ev_pack));
     HIP_TRY(hipEventCreate(&c->ev_a0)); HIP_TRY(hipEventCreate(&c->ev_a1));
+    HIP_TRY(hipEventCreate(&c->ev_b0)); HIP_TRY(hipEventCreate(&c->ev_b1));
     HIP_TRY(hipEventCreate(&c->ev_t0)); HIP_TRY(hipEventCreate(&c->ev_t1));
     HIP_TRY(hipEventCreate(&c->ev_end));
     if (c->counters.ensure(CT_N * sizeof(unsigned long long), c->stream)) return -1;
@@ -290,7 +307,7 @@ void wfagpu_amd_destroy(wfagpu_amd_ctx_t* c) {
                     &c->counters, &c->arena, &c->ops, &c->text, &c->text_scratch, &c->cig_off, &c->cig_len, &c->gring})
     b->release();
   if (c->h_counters) hipHostFree(c->h_counters);
-  for (hipEvent_t ev : {c->ev_start, c->ev_pack, c->ev_a0, c->ev_a1, c->ev_t0, c->ev_t1, c->ev_end})
+  for (hipEvent_t ev : {c->ev_start, c->ev_pack, c->ev_a0, c->ev_a1, c->ev_b0, c->ev_b1, c->ev_t0, c->ev_t1, c->ev_end})
     if (ev) hipEventDestroy(ev);
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
   delete c;
@@ -500,11 +517,15 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
                           16.0 * std::min<unsigned>(max_error, 2 * max_len) + 4096.0;
   if (compute_cigar) {
     // arena: expected need, bounded by configuration / free memory / 32-bit unit addressing
-    size_t free_b = 0, total_b = 0;
-    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     size_t want = c->arena_cfg;
     if (!want) {
-      want = (size_t)std::min<double>(est_pair_bytes * 1.1 * n, 0.45 * (double)(free_b + c->arena.cap));
+      want = (size_t)(est_pair_bytes * 1.1 * n);
+      if (want > c->arena.cap) {
+        // (the driver is only asked when the arena has to grow: the query costs as much as a kernel launch or two)
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        want = (size_t)std::min<double>((double)want, 0.45 * (double)(free_b + c->arena.cap));
+      }
       want = std::max<size_t>(want, (size_t)64 << 20);
       if (c->arena_limit) {
         // (the starting cap keeps first calls cheap; it gives way, up to the maximum, when it could not even hold the
@@ -542,9 +563,18 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   // `alt0`/`alt1`: the two lists the passes ping-pong between for what is left over (NOMEM pairs + pairs not launched
   // yet).  The caller picks them so that neither is a list it still needs (the sampled run of the auto-budget step
   // must not touch the bucket's own list).
+  // `pending` == nullptr: the identity list 0..n_pending-1, UNFILTERED -- it may hold pairs flagged for the byte-compare
+  // class; the first launch over such a list skips whatever is not PENDING.
+  //
+  // A pass is a sequence of CHAINS, each enqueued without a host round trip: wavefront kernel -> compaction of its
+  // failures [-> the re-run of the pairs that missed their auto-tuned budget, its length read on the device ->
+  // compaction] -> backtrace + CIGAR text of what finished -> compaction of the pairs that ran out of arena -> ONE
+  // synchronisation.  Further chains (wider tiers) follow only for pairs that are still unfinished then.  (Six round
+  // trips per batch before: with two lanes per device the lanes fell into lockstep, both waiting on the host at once.)
   auto run_list = [&](uint32_t* pending, uint32_t n_pending, const bool raw, const int32_t* budgets, const int budget_cap,
                       uint32_t* alt0, uint32_t* alt1, const bool allow_band = true) -> int {
   grid_cap = UINT32_MAX;
+  const bool unfiltered = pending == nullptr;
   if (budgets) {
     // tight budgets make the wavefront a diamond: at most half the budget square of origin bytes
     const double B = budget_cap;
@@ -558,94 +588,96 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       const double fit = (double)c->arena.cap / std::max(1.0, est_pair_bytes);
       n_pass = (uint32_t)std::min<double>(n_pending, std::max<double>(fit, 4.0 * c->num_cus));
     }
-    // ---- forward pass with tier escalation ----------------------------------
     if (zero_counter(c, CT_ARENA)) return -1;
+    if (zero_counter(c, CT_NOMEM)) return -1;
+    uint32_t* nxt_pending = (pending == alt0) ? alt1 : alt0;
     uint32_t* cur = pending;
     uint32_t n_cur = n_pass;
     uint32_t* spare[2] = {static_cast<uint32_t*>(c->list_a.p), static_cast<uint32_t*>(c->list_b.p)};
     int flip = 0;
     int max_score = budgets ? std::min(budget_cap, max_error) : max_error;
     bool budget_round = budgets != nullptr;
-    for (int round = 0; n_cur > 0; ++round) {
-      TierPlan tp;
-      ap.budget = budget_round ? budgets : nullptr;
-      // banded first attempt (packed class only); whatever it cannot finish goes to the exact tiers
-      ap.band_width = (want_band && allow_band && !raw && round == 0 && !budgets) ? band_width : 0;
-      ap.band_period = band;
-      if (ap.band_width > 0 && !plan_tier(c, ap, std::min(max_score, 30000), max_len, cigar_now, raw, &tp)) ap.band_width = 0;
-      if (ap.band_width > 0) c->stats.pairs_banded += n_cur;
-      if (ap.band_width == 0 && !plan_tier(c, ap, max_score, max_len, cigar_now, raw, &tp)) {
-        fprintf(stderr, "[!] ERROR: sequences of %u bases do not fit the LDS staging area\n", max_len);
-        return -1;
+    int round = 0;
+    while (n_cur > 0) {
+      // ---- one chain ------------------------------------------------------------------------------------------------
+      uint32_t* const chain_list = cur;
+      const uint32_t n_chain = n_cur;
+      struct Link { int tier; int ct_list; int ct_cells; hipEvent_t e0, e1; bool banded; bool budgeted; bool first_round; uint32_t n_in; } link[2];
+      int n_links = 0;
+      long long s_hi = 0;                       // no pair of this chain finishes with a larger score
+      const unsigned long long* cur_len_dev = nullptr;
+      for (;;) {
+        Link& L = link[n_links];
+        L = {0, n_links ? CT_LIST2 : CT_LIST, n_links ? CT_LCELLS2 : CT_LCELLS, n_links ? c->ev_b0 : c->ev_a0, n_links ? c->ev_b1 : c->ev_a1,
+             false, budget_round, round == 0, n_cur};
+        TierPlan tp;
+        ap.budget = budget_round ? budgets : nullptr;
+        // banded first attempt (packed class only); whatever it cannot finish goes to the exact tiers
+        ap.band_width = (want_band && allow_band && !raw && round == 0 && !budgets) ? band_width : 0;
+        ap.band_period = band;
+        if (ap.band_width > 0 && !plan_tier(c, ap, std::min(max_score, 30000), max_len, cigar_now, raw, &tp)) ap.band_width = 0;
+        L.banded = ap.band_width > 0;
+        if (ap.band_width == 0 && !plan_tier(c, ap, max_score, max_len, cigar_now, raw, &tp)) {
+          fprintf(stderr, "[!] ERROR: sequences of %u bases do not fit the LDS staging area\n", max_len);
+          return -1;
+        }
+        L.tier = tp.tier;
+        if (tp.tier == 3 || tp.tier == 4) {
+          ap.ring16 = max_len <= 32766u ? 1 : 0;
+          const size_t stride = tp.tier == 4 ? ((((size_t)ap.de * ap.rs * 2) + 255) & ~(size_t)255)     // hybrid: the D ring only
+                                             : ((((size_t)(ap.dm + 2 * ap.de) * ap.rs * (ap.ring16 ? 2 : 4)) + 255) & ~(size_t)255);
+          const int g = (int)std::min<uint32_t>(n_cur, (uint32_t)(c->num_cus * tp.blocks_per_cu));
+          if (c->gring.ensure(stride * g, st)) return -1;
+          ap.gring = c->gring.p; ap.gring_stride = stride;
+        }
+        if (round == 0) { c->stats.lds_bytes_tier0 = tp.lds; c->stats.blocks_per_cu_tier0 = tp.blocks_per_cu; }
+        ap.work = cur; ap.n_work = n_cur; ap.n_work_dev = cur_len_dev;
+        ap.only_pending = (unfiltered && round == 0) ? 1 : 0;
+        ap.launch_cells = ct + L.ct_cells;
+        const int bpc_cap = c->tuning.max_blocks_per_cu > 0 ? c->tuning.max_blocks_per_cu : 1 << 20;     // (occupancy experiments)
+        const int grid = (int)std::min<uint32_t>(std::min<uint32_t>(n_cur, grid_cap), (uint32_t)(c->num_cus * std::min(tp.blocks_per_cu, bpc_cap)));
+        // arena refill size: as large as lets every workgroup hold a few chunks -- each refill is a
+        // returning atomic on ONE word (~88 per microsecond on this chip), which at 4 KiB refills
+        // was the whole kernel time
+        if (cigar_now) ap.chunk_units = (uint32_t)std::min<unsigned long long>(4096u, std::max<unsigned long long>(256, ap.arena_units / (4ull * (unsigned)grid)));
+        ap.work_shards = 8u;
+        if (zero_counter(c, L.ct_cells, 2)) return -1;   // (the launch's cell count and, next to it, the length of its failure list)
+        HIP_TRY(hipMemsetAsync(c->work_ctr.p, 0, 8 * 64, st));
+        HIP_TRY(hipEventRecord(L.e0, st));
+        wfa_launch_align(ap, tp.tier, cigar_now, raw, grid, st);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(L.e1, st));
+        uint32_t* nxt = spare[flip]; flip ^= 1;
+        LAUNCH_K(k_compact, dim3(cdiv(n_cur, compact_block(n_cur))), dim3(compact_block(n_cur)), 0, st, (const uint32_t*)cur, n_cur, cur_len_dev,
+                           static_cast<const uint32_t*>(c->status.p), MASK(WFA_ST_BAND) | MASK(WFA_ST_SCORE), nxt, ct + L.ct_list);
+        s_hi = std::max<long long>(s_hi, L.banded ? std::min(max_score, 30000) : max_score);
+        ++n_links; ++round;
+        // what the failures of this round run with next
+        cur = nxt; cur_len_dev = ct + L.ct_list;      // (n_cur stays as the upper bound until the chain's synchronisation)
+        if (L.banded) {
+          // banded misses: exact tiers from the start
+        } else if (budget_round) {
+          budget_round = false; max_score = max_error;      // auto-budget misses: the caller's budget
+        } else {
+          // widen: 4x the score budget (and with it the diagonal window); beyond what 16-bit offsets
+          // allow the last resort is the unbounded 32-bit tier
+          if (tp.tier == 3 && max_score == INT_MAX) max_score = -1;       // (nothing wider exists: failures are an error, below)
+          else if (max_score >= 30000 || max_len > 32766u) max_score = INT_MAX;
+          else max_score = (int)std::min<long long>(30000, std::max<long long>(16, 4ll * max_score));   // (a budget of 0 must grow too)
+        }
+        // the re-run of budget misses follows without a round trip; every other escalation waits for the counts
+        if (!(L.budgeted && n_links == 1)) break;
       }
-      if (tp.tier == 3 || tp.tier == 4) {
-        ap.ring16 = max_len <= 32766u ? 1 : 0;
-        const size_t stride = tp.tier == 4 ? ((((size_t)ap.de * ap.rs * 2) + 255) & ~(size_t)255)     // hybrid: the D ring only
-                                           : ((((size_t)(ap.dm + 2 * ap.de) * ap.rs * (ap.ring16 ? 2 : 4)) + 255) & ~(size_t)255);
-        const int grid = (int)std::min<uint32_t>(n_cur, (uint32_t)(c->num_cus * tp.blocks_per_cu));
-        if (c->gring.ensure(stride * grid, st)) return -1;
-        ap.gring = c->gring.p; ap.gring_stride = stride;
-      }
-      if (round == 0) { c->stats.lds_bytes_tier0 = tp.lds; c->stats.blocks_per_cu_tier0 = tp.blocks_per_cu; }
-      ap.work = cur; ap.n_work = n_cur;
-      const int bpc_cap = c->tuning.max_blocks_per_cu > 0 ? c->tuning.max_blocks_per_cu : 1 << 20;     // (occupancy experiments)
-      const int grid = (int)std::min<uint32_t>(std::min<uint32_t>(n_cur, grid_cap), (uint32_t)(c->num_cus * std::min(tp.blocks_per_cu, bpc_cap)));
-      // arena refill size: as large as lets every workgroup hold a few chunks -- each refill is a
-      // returning atomic on ONE word (~88 per microsecond on this chip), which at 4 KiB refills
-      // was the whole kernel time
-      if (cigar_now) ap.chunk_units = (uint32_t)std::min<unsigned long long>(4096u, std::max<unsigned long long>(256, ap.arena_units / (4ull * (unsigned)grid)));
-      ap.work_shards = 8u;
-      if (zero_counter(c, CT_LCELLS, 2)) return -1;   // CT_LCELLS and CT_LIST
-      HIP_TRY(hipMemsetAsync(c->work_ctr.p, 0, 8 * 64, st));
-      HIP_TRY(hipEventRecord(c->ev_a0, st));
-      wfa_launch_align(ap, tp.tier, cigar_now, raw, grid, st);
-      HIP_TRY(hipGetLastError());
-      HIP_TRY(hipEventRecord(c->ev_a1, st));
-      uint32_t* nxt = spare[flip]; flip ^= 1;
-      LAUNCH_K(k_compact, dim3(cdiv(n_cur, 1024)), dim3(1024), 0, st, (const uint32_t*)cur, n_cur,
-                         static_cast<const uint32_t*>(c->status.p), MASK(WFA_ST_BAND) | MASK(WFA_ST_SCORE), nxt, ct + CT_LIST);
-      if (read_counters(c)) return -1;
-      float ms = 0.f;
-      HIP_TRY(hipEventElapsedTime(&ms, c->ev_a0, c->ev_a1));
-      align_ms += ms;
-      c->stats.align_launches++;
-      if (ms > c->stats.main_launch_ms) {
-        c->stats.main_launch_ms = ms; c->stats.main_launch_tier = tp.tier; c->stats.main_launch_pairs = n_cur;
-        c->stats.main_launch_cells = c->h_counters[CT_LCELLS];
-        c->stats.main_launch_seq_bytes = (unsigned long long)((double)b->packed_bytes * n_cur / n);   // (share of the batch)
-      }
-      const uint32_t n_next = (uint32_t)c->h_counters[CT_LIST];
-      c->stats.pairs_tier[tp.tier] += n_cur - n_next;
-      if (round == 0) c->stats.pairs_retried += n_next;
-      if (n_next == 0) break;
-      if ((tp.tier == 3) && max_score == INT_MAX) {
-        fprintf(stderr, "[!] ERROR: %u alignments did not finish in the unbounded tier\n", n_next);
-        return -1;
-      }
-      cur = nxt; n_cur = n_next;
-      if (ap.band_width > 0) { c->stats.pairs_banded -= n_next; continue; }   // banded misses: exact tiers from the start
-      if (budget_round) { budget_round = false; max_score = max_error; c->stats.pairs_budget_missed += n_next; continue; }   // auto-budget misses: the caller's budget
-      // widen: 4x the score budget (and with it the diagonal window); beyond what 16-bit offsets
-      // allow the last resort is the unbounded 32-bit tier
-      if (max_score >= 30000 || max_len > 32766u) max_score = INT_MAX;
-      else max_score = (int)std::min<long long>(30000, std::max<long long>(16, 4ll * max_score));   // (a budget of 0 must grow too)
-    }
-    // ---- backtrace + CIGAR for everything that finished in this pass ---------
-    if (zero_counter(c, CT_SUM_OPS, 2)) return -1;
-    if (zero_counter(c, CT_OPS)) return -1;
-    if (zero_counter(c, CT_MAX_SCORE)) return -1;
-    LAUNCH_K(k_trace_bounds, dim3(std::min<uint32_t>(cdiv(n_pass, 256), 1024u)), dim3(256), 0, st, (const uint32_t*)pending, n_pass,
-                       static_cast<const uint32_t*>(c->status.p), (const int32_t*)d_scores,
-                       static_cast<const uint32_t*>(c->cells.p), std::min(pen.x, pen.e), item_chars, ct);
-    if (cigar_now) {
-      if (read_counters(c)) return -1;       // (score-only calls need none of these sums before the end of the call)
-      const unsigned long long ops_need = c->h_counters[CT_SUM_OPS] + 256;
-      const unsigned long long text_need = text_used + c->h_counters[CT_SUM_TEXT] + 256;
-      if (c->ops.ensure(ops_need, st)) return -1;
-      if (c->text.ensure(std::max<size_t>(text_need, c->text_cfg), st, text_used)) return -1;
-      WfaTraceParams tp{};
-      tp.raw = raw ? 1 : 0;
-      {
+      // ---- backtrace + CIGAR for everything of the chain's list that finished -----------------------------------------
+      if (zero_counter(c, CT_SUM_OPS, 2)) return -1;
+      if (zero_counter(c, CT_OPS)) return -1;
+      if (zero_counter(c, CT_MAX_SCORE)) return -1;
+      LAUNCH_K(k_trace_bounds, dim3(std::min<uint32_t>(cdiv(n_chain, 256), 1024u)), dim3(256), 0, st, (const uint32_t*)chain_list, n_chain,
+                         static_cast<const uint32_t*>(c->status.p), (const int32_t*)d_scores,
+                         static_cast<const uint32_t*>(c->cells.p), std::min(pen.x, pen.e), item_chars, ct);
+      if (cigar_now) {
+        WfaTraceParams tp{};
+        tp.raw = raw ? 1 : 0;
         // both sequences of a pair, as words, per lane; staged in LDS when 64 lanes fit 48 KiB
         const unsigned per_seq = raw ? (max_len + 3) / 4 + 1 : (max_len + 15) / 16 + 1;
         const unsigned stride = (2 * per_seq) | 1u;
@@ -656,12 +688,28 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         // not leave that: the lane-per-alignment walk + windowed emit take any length)
         tp.wave_kernel = (tp.seq_lds_stride == 0 && c->tuning.trace_mode != 1 &&
                           (size_t)2 * tp.seq_words_cap * 4 + 64 * 16 + 64 <= c->lds_per_block_max) ? 1 : 0;
-        // op list (one byte per score point of the largest score of the pass) and CIGAR text of one alignment in LDS,
-        // within 40 KiB per wavefront so that at least four of them fit a CU
+        // Scratch sizes.  Lane-per-alignment kernels with a bounded score: from the bound (no pair of the chain finished
+        // above s_hi), no round trip.  The wave kernels size their LDS from the largest score of the pass and the
+        // unbounded tier has no bound: those read the sums k_trace_bounds has just formed.
+        const unsigned long long ops_bound = (unsigned long long)n_chain * (((unsigned long long)std::max<long long>(s_hi, 0) + 3ull) & ~3ull);
+        const unsigned long long text_bound = (unsigned long long)n_chain *
+            ((unsigned long long)item_chars * (2ull * (unsigned long long)(std::max<long long>(s_hi, 0) / std::min(pen.x, pen.e)) + 1ull) + 1ull);
+        const bool by_bound = !tp.wave_kernel && s_hi >= 0 && s_hi <= 30000 && text_bound <= ((unsigned long long)6 << 30);
+        unsigned long long ops_need, text_sum;
+        if (by_bound) { ops_need = ops_bound + 256; text_sum = text_bound; }
+        else {
+          if (read_counters(c)) return -1;
+          ops_need = c->h_counters[CT_SUM_OPS] + 256; text_sum = c->h_counters[CT_SUM_TEXT];
+        }
+        const unsigned long long text_need = text_used + text_sum + 256;
+        if (c->ops.ensure(ops_need, st)) return -1;
+        if (c->text.ensure(std::max<size_t>(text_need, c->text_cfg), st, text_used)) return -1;
         {
+          // op list (one byte per score point of the largest score of the pass) and CIGAR text of one alignment in LDS,
+          // within 40 KiB per wavefront so that at least four of them fit a CU
           const size_t seq_b = (size_t)2 * tp.seq_words_cap * 4 + 1024;
           size_t room = seq_b < (40u << 10) ? (40u << 10) - seq_b : 0;
-          const size_t smax = (size_t)c->h_counters[CT_MAX_SCORE];
+          const size_t smax = by_bound ? (size_t)s_hi : (size_t)c->h_counters[CT_MAX_SCORE];
           tp.ops_lds_bytes = (int)(((smax + 3) & ~(size_t)3) <= room ? ((smax + 15) & ~(size_t)15) : 0);
           room -= (size_t)tp.ops_lds_bytes;
           tp.text_lds_bytes = (int)(std::min<size_t>(room, 2 * smax + 64) & ~(size_t)15);
@@ -672,47 +720,70 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
           tp.group = 1;
           if (c->tuning.trace_mode == 0 && tp.ops_lds_bytes > 0 && smax <= 512)
             for (int g = 8; g >= 2; g >>= 1)
-              if ((share + (size_t)(64 / g) * 16 + 16) * g <= (40u << 10) && n_pass >= (uint32_t)g * 1024u) { tp.group = g; break; }
+              if ((share + (size_t)(64 / g) * 16 + 16) * g <= (40u << 10) && n_chain >= (uint32_t)g * 1024u) { tp.group = g; break; }
         }
+        tp.packed = ap.packed; tp.meta = ap.meta; tp.work = chain_list; tp.n_work = n_chain;
+        tp.x = pen.x; tp.oe = oe; tp.e = pen.e;
+        tp.score = d_scores; tp.status = static_cast<const uint32_t*>(c->status.p);
+        tp.score_fix = (want_band && !raw) ? d_scores : nullptr;
+        tp.arena = ap.arena; tp.arena_bytes = (unsigned long long)c->arena.cap; tp.bt_final_row = ap.bt_final_row;
+        tp.ops = static_cast<uint8_t*>(c->ops.p); tp.ops_cap = c->ops.cap; tp.ops_top = ct + CT_OPS;
+        tp.text = static_cast<char*>(c->text.p); tp.text_cap = c->text.cap; tp.text_top = ct + CT_TEXT;
+        tp.min_op_cost = std::min(pen.x, pen.e);
+        tp.item_chars = item_chars;
+        // lane-per-alignment emit with whole sequences staged: one replay into a scratch + compaction (big passes only: the
+        // scratch holds the upper bounds, ~3x the text)
+        if (!tp.wave_kernel && tp.seq_lds_stride > 0 && n_chain >= 8192u) {
+          if (c->text_scratch.ensure(text_sum + 4096, st)) return -1;
+          if (zero_counter(c, CT_SCRATCH)) return -1;
+          tp.text_scratch = static_cast<char*>(c->text_scratch.p); tp.text_scratch_cap = c->text_scratch.cap; tp.scratch_top = ct + CT_SCRATCH;
+        }
+        tp.cigar_off = static_cast<unsigned long long*>(c->cig_off.p);
+        tp.cigar_len = static_cast<uint32_t*>(c->cig_len.p);
+        HIP_TRY(hipEventRecord(c->ev_t0, st));
+        wfa_launch_trace(tp, st);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(c->ev_t1, st));
+        // ---- pairs that ran out of arena go into the next pass (CIGAR calls only: score-only calls have no arena) ----
+        LAUNCH_K(k_compact, dim3(cdiv(n_chain, compact_block(n_chain))), dim3(compact_block(n_chain)), 0, st, (const uint32_t*)chain_list, n_chain, (const unsigned long long*)nullptr,
+                           static_cast<const uint32_t*>(c->status.p), MASK(WFA_ST_NOMEM), nxt_pending, ct + CT_NOMEM);
       }
-      tp.packed = ap.packed; tp.meta = ap.meta; tp.work = pending; tp.n_work = n_pass;
-      tp.x = pen.x; tp.oe = oe; tp.e = pen.e;
-      tp.score = d_scores; tp.status = static_cast<const uint32_t*>(c->status.p);
-      tp.score_fix = (want_band && !raw) ? d_scores : nullptr;
-      tp.arena = ap.arena; tp.arena_bytes = (unsigned long long)c->arena.cap; tp.bt_final_row = ap.bt_final_row;
-      tp.ops = static_cast<uint8_t*>(c->ops.p); tp.ops_cap = c->ops.cap; tp.ops_top = ct + CT_OPS;
-      tp.text = static_cast<char*>(c->text.p); tp.text_cap = c->text.cap; tp.text_top = ct + CT_TEXT;
-      tp.min_op_cost = std::min(pen.x, pen.e);
-      tp.item_chars = item_chars;
-      // lane-per-alignment emit with whole sequences staged: one replay into a scratch + compaction (big passes only: the
-      // scratch holds the upper bounds, ~3x the text)
-      if (!tp.wave_kernel && tp.seq_lds_stride > 0 && n_pass >= 8192u) {
-        if (c->text_scratch.ensure(c->h_counters[CT_SUM_TEXT] + 4096, st)) return -1;
-        if (zero_counter(c, CT_SCRATCH)) return -1;
-        tp.text_scratch = static_cast<char*>(c->text_scratch.p); tp.text_scratch_cap = c->text_scratch.cap; tp.scratch_top = ct + CT_SCRATCH;
-      }
-      tp.cigar_off = static_cast<unsigned long long*>(c->cig_off.p);
-      tp.cigar_len = static_cast<uint32_t*>(c->cig_len.p);
-      HIP_TRY(hipEventRecord(c->ev_t0, st));
-      wfa_launch_trace(tp, st);
-      HIP_TRY(hipGetLastError());
-      HIP_TRY(hipEventRecord(c->ev_t1, st));
-    }
-    // ---- pairs that ran out of arena go into the next pass (CIGAR calls only: score-only calls have no arena) ----
-    uint32_t* nxt_pending = (pending == alt0) ? alt1 : alt0;
-    if (cigar_now) {
-      if (zero_counter(c, CT_LIST)) return -1;
-      LAUNCH_K(k_compact, dim3(cdiv(n_pass, 1024)), dim3(1024), 0, st, (const uint32_t*)pending, n_pass,
-                         static_cast<const uint32_t*>(c->status.p), MASK(WFA_ST_NOMEM), nxt_pending, ct + CT_LIST);
+      // ---- the chain's one synchronisation --------------------------------------------------------------------------
       if (read_counters(c)) return -1;
-      float ms = 0.f;
-      HIP_TRY(hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1));
-      trace_ms += ms;
-      text_used = c->h_counters[CT_TEXT];
-    } else {
-      c->h_counters[CT_LIST] = 0;
+      uint32_t n_in = n_chain;
+      for (int l = 0; l < n_links; ++l) {
+        const Link& L = link[l];
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, L.e0, L.e1));
+        align_ms += ms;
+        c->stats.align_launches++;
+        if (ms > c->stats.main_launch_ms) {
+          c->stats.main_launch_ms = ms; c->stats.main_launch_tier = L.tier; c->stats.main_launch_pairs = n_in;
+          c->stats.main_launch_cells = c->h_counters[L.ct_cells];
+          c->stats.main_launch_seq_bytes = (unsigned long long)((double)b->packed_bytes * n_in / n);   // (share of the batch)
+        }
+        const uint32_t n_out = (uint32_t)c->h_counters[L.ct_list];
+        // (an unfiltered list: the pairs of the byte-compare class were skipped, not finished)
+        const uint32_t skipped = (unfiltered && L.first_round) ? (uint32_t)std::min<unsigned long long>(c->h_counters[CT_NRAW], n_in - n_out) : 0u;
+        c->stats.pairs_tier[L.tier] += n_in - n_out - skipped;
+        if (L.banded) c->stats.pairs_banded += n_in - n_out;
+        if (L.first_round) c->stats.pairs_retried += n_out;
+        if (L.budgeted) c->stats.pairs_budget_missed += n_out;
+        n_in = n_out;
+      }
+      if (cigar_now) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1));
+        trace_ms += ms;
+        text_used = c->h_counters[CT_TEXT];
+      }
+      n_cur = n_in;      // failures of the chain's last round: the next chain's list (`cur`), now with its exact length
+      if (n_cur > 0 && max_score < 0) {
+        fprintf(stderr, "[!] ERROR: %u alignments did not finish in the unbounded tier\n", n_cur);
+        return -1;
+      }
     }
-    const uint32_t n_nomem = (uint32_t)c->h_counters[CT_LIST];
+    const uint32_t n_nomem = cigar_now ? (uint32_t)c->h_counters[CT_NOMEM] : 0u;
     if (n_nomem) {
       // grow the arena for the next pass if memory allows; if a pass made no
       // progress at all, also halve the number of alignments in flight
@@ -734,8 +805,6 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         const uint32_t cur_cap = std::min<uint32_t>(grid_cap, std::min<uint32_t>(n_pass, (uint32_t)c->num_cus * 32u));
         grid_cap = std::max<uint32_t>(1u, cur_cap / 2);
       }
-    }
-    if (n_nomem) {
       LAUNCH_K(k_set_pending, dim3(cdiv(n_nomem, 256)), dim3(256), 0, st, (const uint32_t*)nxt_pending, n_nomem,
                          static_cast<uint32_t*>(c->status.p));
     }
@@ -744,8 +813,11 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
     // refine the per-pair estimate from this pass, then queue what was not launched behind the re-runs
     if (cigar_now && n_pass - n_nomem >= 65536u)   // (few pairs per workgroup: refill slack would dominate)
       est_pair_bytes = std::max(256.0, 1.15 * 16.0 * (double)c->h_counters[CT_ARENA] / (double)(n_pass - n_nomem));
-    if (n_pending > n_pass)
-      HIP_TRY(hipMemcpyAsync(nxt_pending + n_nomem, pending + n_pass, (size_t)4 * (n_pending - n_pass), hipMemcpyDeviceToDevice, st));
+    if (n_pending > n_pass) {
+      if (pending) HIP_TRY(hipMemcpyAsync(nxt_pending + n_nomem, pending + n_pass, (size_t)4 * (n_pending - n_pass), hipMemcpyDeviceToDevice, st));
+      else LAUNCH_K(k_iota, dim3(cdiv(n_pending - n_pass, 256)), dim3(256), 0, st, nxt_pending + n_nomem, n_pass, n_pending - n_pass);
+    }
+    // (the list of the next pass is explicit, but still unfiltered where this one was: see only_pending above)
     pending = nxt_pending; n_pending = n_nomem + (n_pending - n_pass);
   }
   return 0;
@@ -767,12 +839,34 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   unsigned bucket_lo = 0;
   for (unsigned bucket_hi = batch_max_len > 4096u ? 1024u : batch_max_len; ; bucket_hi = bucket_hi * 4u) {
     if (bucket_hi >= batch_max_len / 2u || bucket_hi > (1u << 30)) bucket_hi = batch_max_len;   // last bucket takes the rest
-    uint32_t* pending = static_cast<uint32_t*>(c->list_c.p);
-    if (zero_counter(c, CT_LIST)) return -1;
-    LAUNCH_K(k_compact_len, dim3(cdiv(n, 1024)), dim3(1024), 0, st, n, static_cast<const uint32_t*>(c->status.p), class_mask,
-                       ap.meta, bucket_lo, bucket_hi, pending, ct + CT_LIST);
-    if (read_counters(c)) return -1;
-    uint32_t n_pending = (uint32_t)c->h_counters[CT_LIST];
+    uint32_t* const bucket_list = static_cast<uint32_t*>(c->list_c.p);
+    uint32_t* pending = bucket_list;
+    uint32_t n_pending = n;
+    // One bucket, packed class, and no sample to draw (budgets inherited from an earlier batch of the stream, or none to
+    // be tuned): the bucket is the identity list, UNFILTERED -- no compaction, no round trip before the first wavefront
+    // launch, which skips the pairs flagged for the byte-compare class (their number arrives with the pass's
+    // synchronisation).
+    bool unfiltered = false;
+    if (!raw && bucket_lo == 0 && bucket_hi >= batch_max_len) {
+      const bool would_tune = (!want_band || !c->tuning.force_band) && n >= 8192 && !c->tuning.no_auto_budget &&
+                              window_width(max_error, pen.o, pen.e, bucket_hi) > 128;
+      bool inherited = false;
+      if (would_tune && c->same_stream)
+        for (int i = 0; i < c->n_saved_q; ++i) {
+          const auto& sq = c->saved_q[i];
+          if (sq.bucket_hi == bucket_hi && sq.x == pen.x && sq.o == pen.o && sq.e == pen.e && sq.max_error == max_error) inherited = true;
+        }
+      unfiltered = !would_tune || inherited;
+    }
+    if (unfiltered) {
+      pending = nullptr;
+    } else {
+      if (zero_counter(c, CT_LIST)) return -1;
+      LAUNCH_K(k_compact_len, dim3(cdiv(n, 1024)), dim3(1024), 0, st, n, static_cast<const uint32_t*>(c->status.p), class_mask,
+                         ap.meta, bucket_lo, bucket_hi, pending, ct + CT_LIST);
+      if (read_counters(c)) return -1;
+      n_pending = (uint32_t)c->h_counters[CT_LIST];
+    }
     if (raw) c->stats.pairs_raw += n_pending;
     if (n_pending) {
       max_len = bucket_hi;
@@ -880,7 +974,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
           // the sampled pairs are done: drop them from the bucket's list
           uint32_t* rest = static_cast<uint32_t*>(c->list_e.p);
           if (zero_counter(c, CT_LIST)) return -1;
-          LAUNCH_K(k_compact, dim3(cdiv(n_pending, 1024)), dim3(1024), 0, st, (const uint32_t*)pending, n_pending,
+          LAUNCH_K(k_compact, dim3(cdiv(n_pending, compact_block(n_pending))), dim3(compact_block(n_pending)), 0, st, (const uint32_t*)pending, n_pending, (const unsigned long long*)nullptr,
                              static_cast<const uint32_t*>(c->status.p), class_mask, rest, ct + CT_LIST);
           if (read_counters(c)) return -1;
           n_pending = (uint32_t)c->h_counters[CT_LIST];
@@ -892,7 +986,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         c->stats.auto_budget = 0;
       }
       const unsigned missed_before = c->stats.pairs_budget_missed;
-      if (n_pending && run_list(pending, n_pending, raw, budgets, budget_cap, static_cast<uint32_t*>(c->list_d.p), pending)) return -1;
+      if (n_pending && run_list(pending, n_pending, raw, budgets, budget_cap, static_cast<uint32_t*>(c->list_d.p), bucket_list)) return -1;
       if (saved_idx >= 0 && (c->stats.pairs_budget_missed - missed_before) * 20u > n_pending) {
         // more than 5 % of the batch missed the inherited budgets: the stream has drifted, sample again next time
         c->saved_q[saved_idx] = c->saved_q[--c->n_saved_q];

@@ -219,7 +219,12 @@ struct Lane {
 struct InSlot { char* d_seq = nullptr; size_t seq_cap = 0; sequence_pair_t* d_meta = nullptr; size_t meta_cap = 0; };
 struct DevState {
   int device = -1;
-  hipStream_t up = nullptr;                    // H2D of the batches, in order
+  // H2D of the batches, in order.  ONE stream: the runtime moves pageable memory in 32 MiB pieces with ~30 us of host
+  // work between them (53.7 GB/s instead of the 57 GB/s of a piece); feeding two streams from two threads closes
+  // those gaps but costs more than it gives -- whole batches on alternate streams arrive in pairs, twice as late (1M x
+  // 1 kbp pairs: 51 ms instead of 43), two halves of every batch on two streams: upload 38.6 -> 37.2 ms, call 43.2 -> 45.0
+  // (five busy host threads on a 16-core quota).
+  hipStream_t up = nullptr;
   std::vector<hipEvent_t> up_done;             // one per batch of a call: "its copies have landed"
   std::vector<InSlot> in;
   Lane lane[MAX_LANES];

@@ -226,6 +226,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-to-host", action="store_true")
     ap.add_argument("--force-band", action="store_true", help="banded workloads: always run the banded kernels (tuning.force_band)")
+    ap.add_argument("--tuning", action="append", default=[], metavar="KEY=INT",
+                    help="wfagpu_amd_tuning_t field for A/B runs (waves_per_simd=7, max_blocks_per_cu=24, ...)")
     ap.add_argument("--virtual-devices", type=int, default=0,
                     help="--mode library: shard the call over this many device slots mapped onto the visible GPUs")
     ap.add_argument("--cpu-harness", action="store_true",
@@ -265,6 +267,7 @@ def main():
     buf, meta = wfagpu.generate_pairs(n_pairs, wl["length"], wl["error"], seed=shardlib.shard_seed(1000, rank),
                                       nthreads=min(16, usable_cores()))
     tuning = {"force_band": 1} if args.force_band else {}
+    tuning.update({kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.tuning})
     al = wfagpu.DeviceAligner(local_rank, **tuning)
     batch = al.upload(buf, meta)
     dptt = int((meta["pattern_len"].astype(np.int64) * meta["text_len"].astype(np.int64)).sum())
@@ -303,7 +306,7 @@ def main():
         alg = algorithmic_bytes(int(st.main_launch_seq_bytes), int(st.main_launch_pairs), int(st.main_launch_cells), wl["cigar"])
         achieved = alg / (main_ms * 1e-3) / 1e9 if main_ms > 0 else 0.0
         # (the committed counters belong to the default command: not to other sizes, and not to runs with the A/B switches set)
-        default_cmd = not args.pairs and not args.max_error and not args.force_band
+        default_cmd = not args.pairs and not args.max_error and not tuning
         pmc, pmc_src, pmc_stale = _pmc_main_launch(args.workload, ["FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_INSTS_SALU"]) \
             if default_cmd else (None, None, None)
         # HBM bytes of the main launch: (FETCH_SIZE*2 + WRITE_SIZE) KB -- FETCH_SIZE counts half of a wide coalesced
@@ -346,7 +349,7 @@ def main():
             "gcups": round(gcups, 2),
             "stage_ms_per_step": {"pack": round(acc["pack_ms"] / steps, 3), "align": round(acc["align_ms"] / steps, 3),
                                   "trace": round(acc["trace_ms"] / steps, 3)},
-            "tiers": {"lds_bytes_first": int(st.lds_bytes_tier0), "blocks_per_cu_first": int(st.blocks_per_cu_tier0),
+            "tiers": {"lds_bytes_first": int(st.lds_bytes_tier0), "blocks_per_cu_first": int(st.blocks_per_cu_tier0), "waves_per_simd_first": int(st.waves_per_simd_tier0),
                       "pairs_per_tier": [int(v) for v in st.pairs_tier], "pairs_retried": int(st.pairs_retried),
                       "pairs_banded": int(st.pairs_banded), "auto_budget": int(st.auto_budget),
                       "pairs_budget_missed": int(st.pairs_budget_missed), "passes": int(st.sub_batches),

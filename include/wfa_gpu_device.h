@@ -31,6 +31,8 @@ typedef struct {
     int no_auto_budget;    /* never tune per-pair score budgets from a sample                                            */
     int max_blocks_per_cu; /* occupancy experiments: cap on resident workgroups per CU (0: none)                         */
     int t0_min_blocks;     /* one-wave tier only while LDS leaves at least this many rings per CU (0: default, 10)       */
+    int waves_per_simd;    /* one-wave exact kernels: force the instantiation compiled for 8, 7, 6 or 4 waves per SIMD
+                              (0: matched to the rings LDS lets a CU hold)                                               */
     int trace_mode;        /* 0: automatic; 1: lane-per-alignment walk + windowed emit whatever the length (the fallback
                               of the wave-per-alignment kernel); 2: never several alignments per wavefront               */
 } wfagpu_amd_tuning_t;
@@ -90,6 +92,7 @@ typedef struct {
     unsigned long long sample_cells;
     int sample_launches;
     unsigned int sample_passes;
+    int waves_per_simd_tier0;          /* instantiation the first wavefront launch used (one-wave exact kernels: 8, 7, 6 or 4) */
 } wfagpu_amd_stats_t;
 
 /* 0 on success, negative on error (message on stderr). */

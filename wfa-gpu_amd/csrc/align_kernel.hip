@@ -153,8 +153,12 @@ __device__ __forceinline__ ColdParams cold_params() {
 // HYBRID: the M and I rings in LDS, the D ring (2 of the 9 rows at the default penalties) in global memory -- for
 // wavefronts whose whole ring misses the 160 KiB of a CU by a little (30 kbp at 10 % error: 9 rows x 18 KB).  The
 // all-global ring moves 16 bytes per cell through L2; this one 4.
-template <int NW, bool BT, typename OffT, bool GLOBAL_RING, bool RAW, bool BANDED, bool HYBRID = false>
-__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu((NW == 1 && !BANDED) ? 8 : 1, 8)))   // (the banded one-wave kernels would spill at 8)
+// WPE: waves per SIMD the one-wave exact kernels are compiled for.  Their residency is set by LDS (one ring per wave):
+// where that leaves 7 or fewer waves per SIMD, the register diet of 8 (64 VGPRs, 78 SGPRs: 123 scalar spills, each a
+// v_readlane/v_writelane on the pipe the kernel saturates, and scratch) buys nothing; the host picks the instantiation
+// that matches the rings a CU holds (plan_tier).
+template <int NW, bool BT, typename OffT, bool GLOBAL_RING, bool RAW, bool BANDED, bool HYBRID = false, int WPE = 8>
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu((NW == 1 && !BANDED) ? WPE : 1, 8)))   // (the banded one-wave kernels would spill at 8)
 wfa_align_kernel(const WfaAlignParams p) {
   static_assert(!HYBRID || (!GLOBAL_RING && !BANDED), "the hybrid ring is an exact LDS tier");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1402,9 +1406,9 @@ wfa_align_kernel(const WfaAlignParams p) {
   }
 }
 
-template <int NW, bool BT, typename OffT, bool GR, bool RAW, bool BANDED, bool HYBRID = false>
+template <int NW, bool BT, typename OffT, bool GR, bool RAW, bool BANDED, bool HYBRID = false, int WPE = 8>
 void launch_inst(const WfaAlignParams& p, size_t lds, int grid, hipStream_t stream) {
-  auto k = wfa_align_kernel<NW, BT, OffT, GR, RAW, BANDED, HYBRID>;
+  auto k = wfa_align_kernel<NW, BT, OffT, GR, RAW, BANDED, HYBRID, WPE>;
   // the opt-in for large dynamic LDS is sticky per device and per kernel: pay the driver call once
   static thread_local size_t allowed[16] = {0};
   int dev = 0;
@@ -1416,9 +1420,9 @@ void launch_inst(const WfaAlignParams& p, size_t lds, int grid, hipStream_t stre
   hipLaunchKernelGGL(k, dim3(grid), dim3(NW * 64), lds, stream, p);
 }
 
-template <int NW, bool BT, typename OffT, bool GR, bool RAW, bool BANDED, bool HYBRID = false>
+template <int NW, bool BT, typename OffT, bool GR, bool RAW, bool BANDED, bool HYBRID = false, int WPE = 8>
 int occ_inst(size_t lds) {
-  auto k = wfa_align_kernel<NW, BT, OffT, GR, RAW, BANDED, HYBRID>;
+  auto k = wfa_align_kernel<NW, BT, OffT, GR, RAW, BANDED, HYBRID, WPE>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   int nb = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k), NW * 64, lds) != hipSuccess) nb = 0;
@@ -1427,9 +1431,16 @@ int occ_inst(size_t lds) {
 
 // tier -> instantiation (banded kernels exist for the packed LDS tiers only)
 template <bool BT, bool RAW>
-void launch_tier(const WfaAlignParams& p, int tier, size_t lds, int grid, hipStream_t stream) {
+void launch_tier(const WfaAlignParams& p, int tier, size_t lds, int grid, hipStream_t stream, int wpe) {
   switch (tier) {
-    case 0: launch_inst<1, BT, int16_t, false, RAW, false>(p, lds, grid, stream); break;
+    case 0:
+      // (the byte-compare class keeps the one instantiation: it is the rare path)
+      if constexpr (!RAW) {
+        if (wpe == 7) { launch_inst<1, BT, int16_t, false, false, false, false, 7>(p, lds, grid, stream); break; }
+        if (wpe == 6) { launch_inst<1, BT, int16_t, false, false, false, false, 6>(p, lds, grid, stream); break; }
+        if (wpe == 4) { launch_inst<1, BT, int16_t, false, false, false, false, 4>(p, lds, grid, stream); break; }
+      }
+      launch_inst<1, BT, int16_t, false, RAW, false>(p, lds, grid, stream); break;
     case 1: launch_inst<4, BT, int16_t, false, RAW, false>(p, lds, grid, stream); break;
     case 2: launch_inst<16, BT, int16_t, false, RAW, false>(p, lds, grid, stream); break;
     case 4: if constexpr (!RAW) launch_inst<16, BT, int16_t, false, false, false, true>(p, lds, grid, stream); break;    // hybrid ring
@@ -1448,9 +1459,15 @@ void launch_tier_banded(const WfaAlignParams& p, int tier, size_t lds, int grid,
   }
 }
 template <bool BT, bool RAW>
-int occ_tier(int tier, size_t lds) {
+int occ_tier(int tier, size_t lds, int wpe) {
   switch (tier) {
-    case 0: return occ_inst<1, BT, int16_t, false, RAW, false>(lds);
+    case 0:
+      if constexpr (!RAW) {
+        if (wpe == 7) return occ_inst<1, BT, int16_t, false, false, false, false, 7>(lds);
+        if (wpe == 6) return occ_inst<1, BT, int16_t, false, false, false, false, 6>(lds);
+        if (wpe == 4) return occ_inst<1, BT, int16_t, false, false, false, false, 4>(lds);
+      }
+      return occ_inst<1, BT, int16_t, false, RAW, false>(lds);
     case 1: return occ_inst<4, BT, int16_t, false, RAW, false>(lds);
     case 2: return occ_inst<16, BT, int16_t, false, RAW, false>(lds);
     case 4: if constexpr (!RAW) return occ_inst<16, BT, int16_t, false, false, false, true>(lds); else return 0;
@@ -1479,18 +1496,18 @@ size_t wfa_align_lds_bytes(const WfaAlignParams& p, int tier) {
   return ((ring + seq + meta) + 15) & ~(size_t)15;
 }
 
-void wfa_launch_align(const WfaAlignParams& p, int tier, bool with_bt, bool raw, int grid, hipStream_t stream) {
+void wfa_launch_align(const WfaAlignParams& p, int tier, bool with_bt, bool raw, int grid, hipStream_t stream, int wpe) {
   const size_t lds = wfa_align_lds_bytes(p, tier);
   if (p.band_width > 0) {
     if (with_bt) launch_tier_banded<true>(p, tier, lds, grid, stream); else launch_tier_banded<false>(p, tier, lds, grid, stream);
     return;
   }
-  if (with_bt) { if (raw) launch_tier<true, true>(p, tier, lds, grid, stream); else launch_tier<true, false>(p, tier, lds, grid, stream); }
-  else { if (raw) launch_tier<false, true>(p, tier, lds, grid, stream); else launch_tier<false, false>(p, tier, lds, grid, stream); }
+  if (with_bt) { if (raw) launch_tier<true, true>(p, tier, lds, grid, stream, wpe); else launch_tier<true, false>(p, tier, lds, grid, stream, wpe); }
+  else { if (raw) launch_tier<false, true>(p, tier, lds, grid, stream, wpe); else launch_tier<false, false>(p, tier, lds, grid, stream, wpe); }
 }
 
-int wfa_align_max_blocks_per_cu(int tier, bool with_bt, bool raw, bool banded, size_t lds) {
+int wfa_align_max_blocks_per_cu(int tier, bool with_bt, bool raw, bool banded, size_t lds, int wpe) {
   if (banded) return with_bt ? occ_tier_banded<true>(tier, lds) : occ_tier_banded<false>(tier, lds);
-  if (with_bt) return raw ? occ_tier<true, true>(tier, lds) : occ_tier<true, false>(tier, lds);
-  return raw ? occ_tier<false, true>(tier, lds) : occ_tier<false, false>(tier, lds);
+  if (with_bt) return raw ? occ_tier<true, true>(tier, lds, wpe) : occ_tier<true, false>(tier, lds, wpe);
+  return raw ? occ_tier<false, true>(tier, lds, wpe) : occ_tier<false, false>(tier, lds, wpe);
 }

@@ -136,6 +136,7 @@ void wfa_launch_pack(const char* d_ascii, const WfaSeqPair* d_meta, uint32_t n_p
 // tier: 0 -> 1 wave/alignment (LDS ring), 1 -> 4 waves (LDS), 2 -> 16 waves (LDS), 4 -> 16 waves, M and I rings in LDS + D ring in HBM,
 //       3 -> 16 waves, ring in HBM (int16 or int32 offsets, WfaAlignParams::ring16).  Returns the dynamic LDS bytes used.
 size_t wfa_align_lds_bytes(const WfaAlignParams& p, int tier);
-void wfa_launch_align(const WfaAlignParams& p, int tier, bool with_bt, bool raw, int grid, hipStream_t stream);
-int wfa_align_max_blocks_per_cu(int tier, bool with_bt, bool raw, bool banded, size_t lds_bytes);
+// wpe: waves per SIMD the one-wave exact kernels (tier 0, packed class) are compiled for: 8, 7, 6 or 4 (others: 8).
+void wfa_launch_align(const WfaAlignParams& p, int tier, bool with_bt, bool raw, int grid, hipStream_t stream, int wpe = 8);
+int wfa_align_max_blocks_per_cu(int tier, bool with_bt, bool raw, bool banded, size_t lds_bytes, int wpe = 8);
 void wfa_launch_trace(const WfaTraceParams& p, hipStream_t stream);

@@ -352,7 +352,7 @@ void wfagpu_amd_last_stats(const wfagpu_amd_ctx_t* c, wfagpu_amd_stats_t* out) {
 
 namespace {
 
-struct TierPlan { int tier; int width; int max_score; size_t lds; int blocks_per_cu; };
+struct TierPlan { int tier; int width; int max_score; size_t lds; int blocks_per_cu; int wpe = 8; };
 
 // Widest diagonal window an alignment of score <= S can need (see the kernel): (S - o)/e + 1,
 // never more than every diagonal of the longest pair.
@@ -395,8 +395,19 @@ bool plan_tier(const wfagpu_amd_ctx* c, WfaAlignParams& p, int max_score, unsign
     // a single wavefront sweeps up to ~16 chunks per score before more waves pay off
     if (t == 0 && (width > 1024 || p.dm > 64)) continue;
     if (t == 1 && width > 8192) continue;
-    const int nb = wfa_align_max_blocks_per_cu(t, bt, raw, false, lds);
+    int nb = wfa_align_max_blocks_per_cu(t, bt, raw, false, lds);
     if (nb < 1) continue;
+    // Occupancy-matched instantiation of the one-wave kernels: LDS decides how many rings a CU holds; compiled for 8 waves
+    // per SIMD the kernel lives on 64 VGPRs and 78 SGPRs (123 scalar spills + scratch), which only pays when 8 waves per
+    // SIMD really are resident.  The smallest of 4 / 6 / 7 / 8 that keeps all the rings LDS allows but at most one.
+    int wpe = 8;
+    if (t == 0 && !raw) {
+      const int forced = c->tuning.waves_per_simd;
+      for (int w : {4, 6, 7, 8}) if (4 * w >= nb - 1) { wpe = w; break; }
+      if (forced == 4 || forced == 6 || forced == 7 || forced == 8) wpe = forced;
+      if (wpe != 8) nb = std::min(nb, wfa_align_max_blocks_per_cu(t, bt, raw, false, lds, wpe));
+      if (nb < 1) continue;
+    }
     // One wave per alignment needs its own ring: when LDS leaves fewer than 2.5 wavefronts per SIMD and the rows are wide
     // enough to share, four waves per alignment (same LDS per workgroup, 4x the resident waves) win although every wave
     // repeats the per-score bookkeeping: 16k x 10 kbp @ 3 % (24 KB rings, 6 per CU): 25.6 -> 20.3 ms (final kernels: 16.4);
@@ -404,7 +415,7 @@ bool plan_tier(const wfagpu_amd_ctx* c, WfaAlignParams& p, int max_score, unsign
     // (profiles/r02/mid_lengths.txt).  tuning.t0_min_blocks: A/B.
     const int t0_min_blocks = c->tuning.t0_min_blocks > 0 ? c->tuning.t0_min_blocks : 10;
     if (t == 0 && !min_tier && nb < t0_min_blocks && width >= 384) continue;
-    *out = {t, width, max_score, lds, nb};
+    *out = {t, width, max_score, lds, nb, wpe};
     return true;
   }
   // hybrid ring: everything but the D rows in LDS (one workgroup of 16 waves per CU)
@@ -630,7 +641,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
           if (c->gring.ensure(stride * g, st)) return -1;
           ap.gring = c->gring.p; ap.gring_stride = stride;
         }
-        if (round == 0) { c->stats.lds_bytes_tier0 = tp.lds; c->stats.blocks_per_cu_tier0 = tp.blocks_per_cu; }
+        if (round == 0) { c->stats.lds_bytes_tier0 = tp.lds; c->stats.blocks_per_cu_tier0 = tp.blocks_per_cu; c->stats.waves_per_simd_tier0 = tp.wpe; }
         ap.work = cur; ap.n_work = n_cur; ap.n_work_dev = cur_len_dev;
         ap.only_pending = (unfiltered && round == 0) ? 1 : 0;
         ap.launch_cells = ct + L.ct_cells;
@@ -644,7 +655,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         if (zero_counter(c, L.ct_cells, 2)) return -1;   // (the launch's cell count and, next to it, the length of its failure list)
         HIP_TRY(hipMemsetAsync(c->work_ctr.p, 0, 8 * 64, st));
         HIP_TRY(hipEventRecord(L.e0, st));
-        wfa_launch_align(ap, tp.tier, cigar_now, raw, grid, st);
+        wfa_launch_align(ap, tp.tier, cigar_now, raw, grid, st, tp.wpe);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(L.e1, st));
         uint32_t* nxt = spare[flip]; flip ^= 1;

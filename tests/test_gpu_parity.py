@@ -609,3 +609,36 @@ def test_band_is_only_used_where_it_pays():
                 assert np.array_equal(s, so) and c == co
         finally:
             al.close()
+
+
+def test_big_batch_with_budget_misses_and_escalation():
+    """A big batch through the chained first pass (wavefront kernel -> compaction -> re-run of the budget misses with its
+    length read on the device -> backtrace, one synchronisation): 150k x 300 bp pairs, most at 4 % error, every 97th at
+    25 % -- those miss the auto-tuned budgets -- and every 1000th pair unrelated: those exceed max_error too and are
+    escalated in a further chain."""
+    n = 150_000
+    buf, meta = wfagpu.generate_pairs(n, 300, 0.04, seed=77)
+    hard, mh = wfagpu.generate_pairs(n // 97 + 1, 300, 0.25, seed=78)
+    wild, mw = wfagpu.generate_pairs(n // 1000 + 1, 300, 0.75, seed=79)
+    pairs = wfagpu.pairs_from_layout(buf, meta)
+    ph, pw = wfagpu.pairs_from_layout(hard, mh), wfagpu.pairs_from_layout(wild, mw)
+    for j, i in enumerate(range(0, n, 97)):
+        pairs[i] = ph[j]
+    for j, i in enumerate(range(5, n, 1000)):
+        pairs[i] = pw[j]
+    buf, meta = wfagpu.layout_pairs(pairs)
+    so, co, _ = oracle_lib.oracle_batch(buf, meta, (2, 3, 1), cigar=True, nthreads=16)
+    al = wfagpu.DeviceAligner(0)
+    try:
+        batch = al.upload(buf, meta)
+        s, c = al.align(batch, (2, 3, 1), max_error=200, compute_cigar=True)
+        st = al.stats()
+        assert st.auto_budget > 0 and st.pairs_budget_missed > 1000     # the 25 % pairs
+        assert st.pairs_retried > st.pairs_budget_missed - 1 and sum(st.pairs_tier) == n
+        assert int((so > 200).sum()) > 50                                # pairs beyond max_error: escalated
+        assert np.array_equal(s, so)
+        assert c == co
+        s2, _ = al.align(batch, (2, 3, 1), max_error=200, compute_cigar=False)
+        assert np.array_equal(s2, so)
+    finally:
+        al.close()

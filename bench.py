@@ -396,6 +396,21 @@ def main():
             budget = int(max(16, min(n_pairs, 20e6 / per_pair_us)))
             out["cpu_baseline"] = cpu_baseline(buf, meta, wl["cigar"], budget)
     if dist is not None:
+        # N > 1: the ranks above never share anything but the barrier.  The reference's user calls launch_alignments()
+        # ONCE and the library shards the call over the N devices from one process: host RAM bandwidth, the PCIe root and
+        # the scatter threads are shared then.  Rank 0 measures that too, on N x P pairs, while the other
+        # ranks (their contexts closed above) wait at the barrier; it never replaces `value`.
+        dist.barrier()
+        if rank == 0 and not args.no_host_to_host:
+            try:
+                big_buf, big_meta = wfagpu.generate_pairs(n_pairs * world, wl["length"], wl["error"], seed=1000,
+                                                          nthreads=min(16, usable_cores()))
+                h2h = host_to_host(big_buf, big_meta, wl, max_error, n_devices=world, reps=4, tuning=tuning)
+                out["library_call"] = h2h
+                out["library_call_value"] = h2h["pageable"]["warm"]
+                del big_buf, big_meta
+            except Exception as ex:
+                out["library_call"] = {"error": str(ex)}
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

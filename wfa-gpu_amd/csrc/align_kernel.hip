@@ -308,22 +308,26 @@ wfa_align_kernel(const WfaAlignParams p) {
       }
       block_sync<NW>();
 
+      // A fresh chunk of the backtrace arena for this workgroup, at least `units` (16-byte units) long: one returning
+      // atomic on the arena's bump pointer.  false: the arena is exhausted (chunk_left = 0).  The one place arena space is
+      // claimed; what is left of the old chunk is given up.
+      auto refill_arena = [&](const uint32_t units) -> bool {
+        ColdParams cp = cold_params();
+        const uint32_t grab = max(units, cp->chunk_units);
+        uint32_t base = WFA_ROW_NONE;
+        if (tid == 0) {
+          const unsigned long long b = atomicAdd(cp->arena_top, (unsigned long long)grab);
+          if (b + grab <= cp->arena_units) base = (uint32_t)b;
+        }
+        base = block_bcast<NW>(base, bslot);
+        chunk_cur = base; chunk_left = (base == WFA_ROW_NONE) ? 0u : grab;
+        return base != WFA_ROW_NONE;
+      };
       // ---- score 0: M[0][0] = extend(0) ------------------------------------------------------
       if constexpr (BT) {
         // the row table (8 bytes per score up to the budget) and the one-cell row of score 0
         const uint32_t tab_units = (uint32_t)(((long long)budget + 2) >> 1);
-        if (chunk_left < tab_units + 1) {
-          ColdParams cp = cold_params();
-          const uint32_t grab = max(tab_units + 1, cp->chunk_units);
-          uint32_t base = WFA_ROW_NONE;
-          if (tid == 0) {
-            const unsigned long long b = atomicAdd(cp->arena_top, (unsigned long long)grab);
-            if (b + grab <= cp->arena_units) base = (uint32_t)b;
-          }
-          base = block_bcast<NW>(base, bslot);
-          if (base == WFA_ROW_NONE) status = WFA_ST_NOMEM;
-          chunk_cur = base; chunk_left = (base == WFA_ROW_NONE) ? 0 : grab;
-        }
+        if (chunk_left < tab_units + 1 && !refill_arena(tab_units + 1)) status = WFA_ST_NOMEM;
         if (status == WFA_ST_DONE) {
           tab_base = chunk_cur; row_s = chunk_cur + tab_units; chunk_cur += tab_units + 1; chunk_left -= tab_units + 1;
           tab = reinterpret_cast<uint2*>(p.arena + (size_t)tab_base * 16);
@@ -379,18 +383,7 @@ wfa_align_kernel(const WfaAlignParams p) {
       // arena chunk, refilled with one atomic when it runs dry.  false: arena exhausted.
       auto alloc_row = [&](int width) -> bool {
         const uint32_t need = ((uint32_t)width + 15u) >> 4;
-        if (need + WFA_ARENA_ROW_SLACK > chunk_left) {
-          ColdParams cp = cold_params();
-          const uint32_t grab = max(need + WFA_ARENA_ROW_SLACK, cp->chunk_units);
-          uint32_t base = WFA_ROW_NONE;
-          if (tid == 0) {
-            const unsigned long long b = atomicAdd(cp->arena_top, (unsigned long long)grab);
-            if (b + grab <= cp->arena_units) base = (uint32_t)b;
-          }
-          base = block_bcast<NW>(base, bslot);
-          if (base == WFA_ROW_NONE) { chunk_left = 0; return false; }
-          chunk_cur = base; chunk_left = grab;
-        }
+        if (need + WFA_ARENA_ROW_SLACK > chunk_left && !refill_arena(need + WFA_ARENA_ROW_SLACK)) return false;
         row_s = chunk_cur; chunk_cur += need; chunk_left -= need;
         return true;
       };
@@ -752,18 +745,10 @@ wfa_align_kernel(const WfaAlignParams p) {
                 need = ((uint32_t)wm1 + 16u) >> 4;
                 code_addr += need_prev << 4;
                 if (__builtin_expect(need + WFA_ARENA_ROW_SLACK > chunk_left, 0)) {
-                  ColdParams cp = cold_params();
-                  const uint32_t grab = max(need + WFA_ARENA_ROW_SLACK, cp->chunk_units);
-                  uint32_t base = WFA_ROW_NONE;
-                  if (tid == 0) {
-                    const unsigned long long b = atomicAdd(cp->arena_top, (unsigned long long)grab);
-                    if (b + grab <= cp->arena_units) base = (uint32_t)b;
-                  }
-                  base = block_bcast<NW>(base, bslot);
-                  chunk_cur = base; chunk_left = (base == WFA_ROW_NONE) ? 0u : grab;
-                  code_addr = (GlobalBytes)(uintptr_t)cp->arena + ((size_t)chunk_cur * 16u + (uint32_t)tid);
+                  const bool got = refill_arena(need + WFA_ARENA_ROW_SLACK);
+                  code_addr = (GlobalBytes)(uintptr_t)cold_params()->arena + ((size_t)chunk_cur * 16u + (uint32_t)tid);
                   need_prev = 0;
-                  if (chunk_left < need) { why = 2; continue; }
+                  if (!got) { why = 2; continue; }
                 }
               }
               a_m += rsb;  if (a_m == a_end) a_m = a_first;
@@ -846,96 +831,6 @@ wfa_align_kernel(const WfaAlignParams p) {
             if (done) break;
           }
         }
-        if constexpr (!BANDED && !HOT) {
-          if (e == 1 && !touched_ever) {
-            int lo = last_lo, hi = last_hi;
-            // (e == 1: the reach interval is [kend - (budget - s), kend + (budget - s)]; `reach` is budget - s)
-            int reach = bounded ? budget - s : INT_MAX / 2;
-            const int s_in = s;
-            // the I/D ring has two rows: "advance with wrap" is a swap
-            OffT* i_cur = p_ic; OffT* i_prev = p_ip;
-            bool nomem = false;
-            for (;;) {
-              int nlo = max(lo - 1, wlo), nhi = min(hi + 1, whi);
-              if constexpr (NW == 1) asm volatile("" : "+s"(nlo), "+s"(nhi));   // (keeps the chains off v_max3/v_min3)
-              nlo = max(nlo, kend - (reach - 1)); nhi = min(nhi, kend + (reach - 1));
-              if (nlo > nhi) break;
-              lo = nlo; hi = nhi;
-              ++s; --reach;
-              if constexpr (NW > 1) {
-                if (tid < 8) red[8 * ((s + 1) % 3) + tid] = (tid == 6) ? 0 : ((tid & 1) ? INT_MIN : INT_MAX);
-              }
-              p_m += rs;  if (p_m == m_end) p_m = m_first;
-              p_x += rs;  if (p_x == m_end) p_x = m_first;
-              p_oe += rs; if (p_oe == m_end) p_oe = m_first;
-              { OffT* t = i_cur; i_cur = i_prev; i_prev = t; }
-              const int width = hi - lo + 1;
-              ncells += (uint32_t)width;
-              uint8_t* codes = nullptr;
-              if constexpr (BT) {
-                if (!alloc_row(width)) { nomem = true; break; }
-                if constexpr (NW == 1) {
-                  // row table, buffered by lane: a new group of 64 scores starts at every multiple of 64
-                  if ((s & 63) == 0) tab[s - 64 + lane] = make_uint2((uint32_t)tabv_row, (uint32_t)tabv_lo);
-                  const bool mine = lane == (s & 63);
-                  tabv_row = mine ? (int)row_s : tabv_row; tabv_lo = mine ? lo : tabv_lo;
-                } else {
-                  if (tid == 0) tab[s] = make_uint2(row_s, (uint32_t)lo);
-                }
-                codes = p.arena + (size_t)row_s * 16;
-              }
-              OffT* out_m = p_m; OffT* out_i = i_cur; OffT* out_d = d_of(i_cur);
-              // Ring invariant: the slots written now last held scores s-dm (M) and s-2 (I, D).  Until a cell touches a
-              // sequence end the limits move by at most one diagonal per score (wavefronts that exist: [lo - 1, hi + 1]
-              // clipped by the window and by the reach interval, which itself moves one diagonal per score; scores
-              // without a wavefront leave their slots all NULL), so whatever those rows hold beyond [lo, hi] lies within
-              // dm diagonals of it: NULL the dm cells beyond each end (rows carry dm guard cells per side).
-              // (lanes beyond 2 dm repeat the last of those cells: same value, same address, no exec mask)
-              for (int j0 = 0; j0 < 2 * dm; j0 += NT) {
-                const int j = min(j0 + tid, 2 * dm - 1);
-                const int q = (j < dm) ? lo - 1 - j : hi + 1 - dm + j;
-                out_m[q] = (OffT)OffNull<OffT>::value; out_i[q] = (OffT)OffNull<OffT>::value; out_d[q] = (OffT)OffNull<OffT>::value;
-              }
-              bool my_over = false;
-              unsigned long long touch_mask = 0;
-              cells_of_score(std::true_type{}, lo, hi, codes, p_x, p_oe - 1, i_prev - 1, d_of(i_prev) + 1, out_m, out_i, out_d, BandCtx{},
-                             my_over, touch_mask);
-              const bool wave_touch = touch_mask != 0ull;
-              bool any_touch;
-              if constexpr (NW == 1) {
-                block_sync<NW>();
-                any_touch = wave_touch;
-              } else {
-                int* acc = red + 8 * (s % 3);
-                if (lane == 0 && wave_touch) atomicOr(&acc[6], 4);
-                __syncthreads();
-                any_touch = (acc[6] & 4) != 0;
-              }
-              book.set_a(s & bkm, pack_range(lo, hi));    // (the I and D limits equal it: written back when the loop is left)
-              if constexpr (NW == 1) block_sync<NW>();
-              if (any_touch) {
-                // a cell sits on a sequence end: it may be the last one (wavefront_extend.c:47-67), and from the next
-                // score on values may run past the ends -- the careful path takes over
-                touched_ever = true;
-                done = ((unsigned)(kend - lo) <= (unsigned)(hi - lo)) && __builtin_amdgcn_readfirstlane((int)out_m[kend]) >= tlen;
-                break;
-              }
-            }
-            // back to the general state
-            const int n_lean = s - s_in;
-            if (n_lean > 0) book.copy_a_to_id(tid, NT, bkm);
-            regular += n_lean;
-            last_lo = lo; last_hi = hi;
-            p_ic = i_cur; p_ip = i_prev;
-            if (bounded) { rlo += n_lean; rhi -= n_lean; }
-            tab_group = s >> 6;
-            if (nomem) { status = WFA_ST_NOMEM; break; }
-            if (done) break;
-            if (n_lean > 0 && !touched_ever) {
-              // left because the reach interval is empty: the careful path reports it (no wavefront at s + 1, budget exhausted)
-            }
-          }
-        }
         // ---- lean path, any gap extension: the same cells, but the limits come from the row book (three reads:
         // lo = min(lo[s-x], lo[s-o-e] - 1, lo[s-e] - 1), hi alike -- every row that exists carries all three components over
         // its limits here), the reach interval moves one diagonal every e scores, and scores without any predecessor row
@@ -985,18 +880,10 @@ wfa_align_kernel(const WfaAlignParams p) {
                   need = ((uint32_t)wm1 + 16u) >> 4;
                   code_addr += need_prev << 4;
                   if (__builtin_expect(need + WFA_ARENA_ROW_SLACK > chunk_left, 0)) {
-                    ColdParams cp = cold_params();
-                    const uint32_t grab = max(need + WFA_ARENA_ROW_SLACK, cp->chunk_units);
-                    uint32_t base = WFA_ROW_NONE;
-                    if (tid == 0) {
-                      const unsigned long long b = atomicAdd(cp->arena_top, (unsigned long long)grab);
-                      if (b + grab <= cp->arena_units) base = (uint32_t)b;
-                    }
-                    base = block_bcast<NW>(base, bslot);
-                    chunk_cur = base; chunk_left = (base == WFA_ROW_NONE) ? 0u : grab;
-                    code_addr = (GlobalBytes)(uintptr_t)cp->arena + ((size_t)chunk_cur * 16u + (uint32_t)tid);
+                    const bool got = refill_arena(need + WFA_ARENA_ROW_SLACK);
+                    code_addr = (GlobalBytes)(uintptr_t)cold_params()->arena + ((size_t)chunk_cur * 16u + (uint32_t)tid);
                     need_prev = 0;
-                    if (chunk_left < need) { why = 2; continue; }
+                    if (!got) { why = 2; continue; }
                   }
                 }
               }
@@ -1071,7 +958,9 @@ wfa_align_kernel(const WfaAlignParams p) {
           }
         }
         if constexpr (!BANDED && !HOT) {
-          if (e != 1 && !touched_ever) {
+          // (the tiers whose ring lives in HBM: one loop for every gap extension -- they are bound by the ring traffic, a
+          // closed-form e == 1 twin of it bought nothing there)
+          if (!touched_ever) {
             const int s_in = s;
             bool nomem = false;
             for (;;) {

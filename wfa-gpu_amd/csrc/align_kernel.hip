@@ -136,9 +136,6 @@ template <int NW> struct RowBook {
   }
 };
 
-// What the banded cells need to know about the rows they read (each lives at its own window base).
-struct BandCtx { bool mx_null, mo_null, ie_null, de_null; int mxlo, mxhi, molo, mohi, ielo, iehi, delo, dehi; };
-
 // Kernel arguments that are only needed between alignments (work list, result arrays, arena
 // bookkeeping) are re-read from the kernarg segment where they are used instead of being held in
 // SGPRs across the score loop: the loop needs every scalar register it can get (spilled SGPRs come
@@ -158,7 +155,7 @@ __device__ __forceinline__ ColdParams cold_params() {
 // v_readlane/v_writelane on the pipe the kernel saturates, and scratch) buys nothing; the host picks the instantiation
 // that matches the rings a CU holds (plan_tier).
 template <int NW, bool BT, typename OffT, bool GLOBAL_RING, bool RAW, bool BANDED, bool HYBRID = false, int WPE = 8>
-__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu((NW == 1 && !BANDED) ? WPE : 1, 8)))   // (the banded one-wave kernels would spill at 8)
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu((NW == 1 && !BANDED) ? WPE : 1, 8)))
 wfa_align_kernel(const WfaAlignParams p) {
   static_assert(!HYBRID || (!GLOBAL_RING && !BANDED), "the hybrid ring is an exact LDS tier");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -166,12 +163,19 @@ wfa_align_kernel(const WfaAlignParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int dm = p.dm, de = p.de, rs = p.rs;
-  constexpr int ROW_PAD = (!GLOBAL_RING && !BANDED && sizeof(OffT) == 2) ? WFA_RING_ROW_PAD : 0;     // (see wfa_device.h)
+  constexpr int ROW_PAD = (!GLOBAL_RING && sizeof(OffT) == 2) ? WFA_RING_ROW_PAD : 0;     // (see wfa_device.h)
   // the exact tiers with 16-bit offsets in LDS (0, 1, 2 and the hybrid ring, whose D rows live in global memory): their
   // lean loops have a form of their own; HM_ROW: the one-wave tier also keeps min(plen + k, tlen) per diagonal in LDS (the
   // multi-wave tiers are LDS-bound: 16k x 10 kbp, four waves: 6 rings per CU without the row, 5 with it, 16.4 vs 17.7 ms)
-  constexpr bool HOT = !BANDED && !GLOBAL_RING && sizeof(OffT) == 2;
-  constexpr bool HM_ROW = HOT && !HYBRID && NW == 1;
+  // BANDED (adaptive band, a heuristic): every score's limits are cut to band_width diagonals (band_cut below) and a ring
+  // row holds just those: the row of a score is stored RELATIVE to its own lower limit (column GZ = its diagonal lo), so
+  // the "diagonal 0" address of a row is its slot base plus a per-row scalar offset -- everything else (lean cells, lean
+  // loop, ring invariant through NULL guard zones) is shared with the exact search.  The band moves by at most two
+  // diagonals per score, so the rows a cell reads (at most dm scores old) sit within 2 dm diagonals of its own row and
+  // every read lands in a row's cells or in its guard zones (GZ = 4 dm + 2 columns on either side, NULL).
+  constexpr bool HOT = !GLOBAL_RING && sizeof(OffT) == 2;
+  constexpr bool HM_ROW = HOT && !HYBRID && NW == 1 && !BANDED;
+  const int GZ = BANDED ? 4 * dm + 2 : 0;
   const int x = p.x, oe = p.oe, e = p.e;
 
   // ---- carve LDS -----------------------------------------------------------------------------
@@ -254,7 +258,7 @@ wfa_align_kernel(const WfaAlignParams p) {
     }
     int wlo = -plen, whi = tlen;
     bool feasible = true;
-    if constexpr (!BANDED) {
+    {
       if (budget < INT_MAX / 2) {
         const long long S = budget, o = oe - e;
         const int ak = kend < 0 ? -kend : kend;
@@ -266,7 +270,7 @@ wfa_align_kernel(const WfaAlignParams p) {
         whi = min(whi, tlen); wlo = max(wlo, -plen);
       }
     }
-    const int kidx0 = dm - wlo;             // exact mode: row index of diagonal 0 (dm guard cells each side: the lean path
+    const int kidx0 = BANDED ? 0 : dm - wlo;             // exact mode: row index of diagonal 0 (dm guard cells each side: the lean path
                                             // re-NULLs up to dm cells beyond a row's ends without looking anything up)
 
     if (!feasible) {
@@ -280,8 +284,8 @@ wfa_align_kernel(const WfaAlignParams p) {
       const uint32_t* __restrict__ gt = packed + ((RAW ? mp.text_offset : mp.text_offset_packed) >> 2);
       for (int i = tid; i < pwords; i += NT) Pw[i] = gp[i];
       for (int i = tid; i < twords; i += NT) Tw[i] = gt[i];
-      if constexpr (!BANDED) {
-        // Ring invariant (exact mode): a row holds NULL everywhere outside the limits it was last written
+      {
+        // Ring invariant: a row holds NULL everywhere outside the limits it was last written
         // with, so reads next to a row's ends need no predicate and no per-score guard fill.  It starts
         // here (rows of M, I, D are contiguous) and is kept by clearing, whenever a row is overwritten,
         // what the previous occupant of its slot had beyond the new limits.
@@ -345,7 +349,7 @@ wfa_align_kernel(const WfaAlignParams p) {
           h0 += n; rem -= n;
           if (n < PER) break;
         }
-        Mr[BANDED ? 0 : kidx0] = (OffT)h0;
+        Mr[kidx0 + GZ] = (OffT)h0;      // (banded: the row of score 0 has lo = 0)
         d0 = ((kend == 0 && h0 >= tlen) ? 1u : 0u) | (h0 >= min(plen, tlen) ? 2u : 0u);
       }
       book.set(0, pack_range(0, 0), ROW_NONE_A, ROW_NONE_A);
@@ -358,12 +362,12 @@ wfa_align_kernel(const WfaAlignParams p) {
       // in the loop): the M rows of s, s-x, s-(o+e) and the I rows of s, s-e (the D ring sits de rows
       // behind the I ring).  In exact mode the pointers address diagonal 0 of their row.  The row book is
       // indexed by (score & bkm); its entries for scores < 0 still hold the "no wavefront" reset value.
-      OffT* const m_first = Mr + (BANDED ? 0 : kidx0);
+      OffT* const m_first = Mr + kidx0;
       OffT* const m_end = m_first + dm * rs;
       OffT* const i_first = m_end;
       OffT* const i_end = i_first + de * rs;
       // the D row that belongs to an I row (same slot of the other ring)
-      OffT* const d_first = HYBRID ? Dg + (BANDED ? 0 : kidx0) : i_first + de * rs;
+      OffT* const d_first = HYBRID ? Dg + kidx0 : i_first + de * rs;
       auto d_of = [&](OffT* ip) -> OffT* { return d_first + (ip - i_first); };
       OffT* p_m = m_first; OffT* p_x = m_first + (dm - x) * rs; OffT* p_oe = m_first + (dm - oe) * rs;
       OffT* p_ic = i_first; OffT* p_ip = i_first + (de - e) * rs;
@@ -372,7 +376,7 @@ wfa_align_kernel(const WfaAlignParams p) {
       // the budget only |k - kend| <= (budget - s) / e can still matter (exact, same argument as the
       // window).  [rlo, rhi] is that interval; it loses a diagonal on each side whenever the quotient
       // drops, tracked through the remainder reach_r without a division per score.
-      const bool bounded = !BANDED && budget < INT_MAX / 2;
+      const bool bounded = budget < INT_MAX / 2;
       int reach_r = bounded ? budget % e : INT_MAX;
       int rlo = bounded ? kend - budget / e : INT_MIN / 2, rhi = bounded ? kend + budget / e : INT_MAX / 2;
       // Number of consecutive scores up to s-1 whose wavefront exists with all three components and
@@ -419,7 +423,7 @@ wfa_align_kernel(const WfaAlignParams p) {
       // LEAN (regular regime, no cell has touched a sequence end yet): no value can run past an end, so the
       // overrun test and the saturation of I are dropped.  wave_touch: lanes whose M cell reached min(plen + k, tlen).
       auto cells_of_score = [&](auto lean_tag, const int lo, const int hi, uint8_t* codes, const OffT* rb_mx, const OffT* rb_mo,
-                                const OffT* rb_ie, const OffT* rb_de, OffT* wb_m, OffT* wb_i, OffT* wb_d, const BandCtx& bc,
+                                const OffT* rb_ie, const OffT* rb_de, OffT* wb_m, OffT* wb_i, OffT* wb_d,
                                 bool& my_over, unsigned long long& wave_touch) {
         constexpr bool LEAN = decltype(lean_tag)::value;
         // (the 16-bit LDS tiers never get here with LEAN set: their lean loops call hot_cells below)
@@ -431,19 +435,7 @@ wfa_align_kernel(const WfaAlignParams p) {
           uint32_t code = 0;
           {
             int m_x, m_ol, m_or, i_e, d_e;
-            if constexpr (BANDED) {
-              // rows live at their own window base: form the index only for diagonals inside the row
-              const bool in_x = !bc.mx_null && (unsigned)(k - bc.mxlo) <= (unsigned)(bc.mxhi - bc.mxlo);
-              const bool in_ol = !bc.mo_null && (unsigned)(k - 1 - bc.molo) <= (unsigned)(bc.mohi - bc.molo);
-              const bool in_or = !bc.mo_null && (unsigned)(k + 1 - bc.molo) <= (unsigned)(bc.mohi - bc.molo);
-              const bool in_ie = !bc.ie_null && (unsigned)(k - 1 - bc.ielo) <= (unsigned)(bc.iehi - bc.ielo);
-              const bool in_de = !bc.de_null && (unsigned)(k + 1 - bc.delo) <= (unsigned)(bc.dehi - bc.delo);
-              m_x = in_x ? (int)rb_mx[k] : OffNull<OffT>::value;
-              m_ol = in_ol ? (int)rb_mo[k] : OffNull<OffT>::value;
-              m_or = in_or ? (int)rb_mo[k + 2] : OffNull<OffT>::value;
-              i_e = in_ie ? (int)rb_ie[k] : OffNull<OffT>::value;
-              d_e = in_de ? (int)rb_de[k] : OffNull<OffT>::value;
-            } else {
+            {
               m_x = (int)rb_mx[k];
               m_ol = (int)rb_mo[k];
               m_or = (int)rb_mo[k + 2];
@@ -536,7 +528,7 @@ wfa_align_kernel(const WfaAlignParams p) {
       typedef __attribute__((address_space(3))) const uint32_t* LdsWords;
       typedef __attribute__((address_space(1))) uint8_t* GlobalBytes;
       typedef __attribute__((address_space(1))) OffT* GlobalRow;
-      OffT* const hm_row0 = Mr + (dm + 2 * de) * rs + (BANDED ? 0 : kidx0);      // (HOT) diagonal 0 of the run-limit row
+      OffT* const hm_row0 = Mr + (dm + 2 * de) * rs + kidx0;      // (HOT) diagonal 0 of the run-limit row
       auto hot_cells = [&](const int lo, const int wm1, GlobalBytes& codes, const uint32_t a_oe, const uint32_t a_x, const uint32_t a_m,
                            const uint32_t a_ip, const uint32_t a_ic, const uint32_t a_dp, const uint32_t a_dc, const uint32_t pw_addr, const uint32_t tw_addr,
                            const uint32_t a_hm, unsigned long long& touch) {
@@ -662,6 +654,51 @@ wfa_align_kernel(const WfaAlignParams p) {
           codes -= adv;
         }
       };
+      // Adaptive band (reference: sequence_distance_kernel_aband.cu:104-130): a score keeps at most band_width diagonals;
+      // every band_period scores the window is re-centred on the diagonal of the mismatch-source wavefront M[score - x]
+      // (limits [mxlo, mxhi], `row_mx`: its diagonal 0) whose furthest point is closest to the end, otherwise the excess is
+      // shaved off both sides.  Deterministic (the reference's kernels race here).  Every thread calls it
+      // with the same arguments.
+      auto band_cut = [&](int& lo, int& hi, const int score, const int prev_lo, const int mxlo, const int mxhi, const OffT* row_mx) {
+        const int beta = p.band_width;
+        const int excess = (hi - lo + 1) - beta;
+        if (excess > 0) {
+          bool recentred = false;
+          if (mxlo <= mxhi && (score % p.band_period) == 0) {
+            uint32_t best = 0xFFFFFFFFu;
+            for (int kk = mxlo + tid; kk <= mxhi; kk += NT) {
+              const int off = (int)row_mx[kk];
+              if (off >= 0) {
+                const int dist = max(plen - (off - kk), tlen - off);
+                best = min(best, ((uint32_t)dist << 16) | (uint32_t)(kk - mxlo));
+              }
+            }
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, d));
+            if constexpr (NW > 1) {
+              if (tid == 0) bslot[0] = 0xFFFFFFFFu;
+              __syncthreads();
+              if (lane == 0) atomicMin(&bslot[0], best);
+              __syncthreads();
+              best = bslot[0];
+              __syncthreads();
+            }
+            best = __builtin_amdgcn_readfirstlane(best);      // (uniform: keeps what follows on the scalar unit)
+            if (best != 0xFFFFFFFFu) {
+              const int centre = mxlo + (int)(best & 0xFFFFu);
+              const int nlo = max(lo, min(centre - beta / 2, hi - beta + 1));
+              lo = nlo; hi = nlo + beta - 1;
+              recentred = true;
+            }
+          }
+          if (!recentred) { hi -= (excess + 1) / 2; lo += excess / 2; }
+        }
+        // The window moves by at most two diagonals per score (rows are stored relative to their lower limit: this is what
+        // keeps the rows a cell reads within reach of each other -- see GZ); a wavefront narrower than the band keeps its
+        // lower limit within the same bound.
+        const int slo = min(max(lo, prev_lo - 2), prev_lo + 2);
+        if (slo != lo) { lo = slo; hi = min(hi, lo + beta - 1); }
+      };
       // Limits of the last score (the lean path derives the next ones from them alone).
       int last_lo = 0, last_hi = 0;
       // Has any M cell reached the end of a sequence (offset == min(plen + k, tlen)) so far?  Only after that can an
@@ -686,7 +723,7 @@ wfa_align_kernel(const WfaAlignParams p) {
         // (every neighbour is a non-negative immediate away), row book written when the loop is left (its entries are
         // a function of the score), row-table entries by v_writelane, guard cells re-NULLed only once the budget's
         // reach makes the wavefront shrink (a growing wavefront overwrites everything its slot held before).
-        if constexpr (HOT) {
+        if constexpr (HOT && !BANDED) {
           if (e == 1 && !touched_ever) {
             const int s_in = s, lo_in = last_lo, hi_in = last_hi;
             // lo(s) = max(lo_in - (s - s_in), wlo, s + c_lo), hi(s) = min(hi_in + (s - s_in), whi, c_hi - s)
@@ -838,7 +875,7 @@ wfa_align_kernel(const WfaAlignParams p) {
         // is computed.
         if constexpr (HOT) {
           // (the same trimmed bookkeeping as the e == 1 loop above, except that the limits come from the row book)
-          if (e != 1 && !touched_ever) {
+          if ((BANDED || e != 1) && !touched_ever) {
             const int s_in = s;
             const uint32_t rsb = (uint32_t)rs * 2u;
             const uint32_t a_first = lds_addr(m_first), a_end = lds_addr(m_end), ai_first = lds_addr(i_first), ai_end = lds_addr(i_end);
@@ -857,6 +894,8 @@ wfa_align_kernel(const WfaAlignParams p) {
               __syncthreads();
             }
             int lo = 0, hi = -1;
+            int prev_lo = last_lo;        // (banded: lower limit of the last wavefront that exists)
+            uint32_t o_cur = 0;           // (banded: byte offset of diagonal 0 in the row written last: (GZ - lo) * 2)
             // why the loop ends: 1 = budget exhausted, 2 = arena exhausted, 3 = a cell touched a sequence end
             int why = 0;
             do {
@@ -871,6 +910,11 @@ wfa_align_kernel(const WfaAlignParams p) {
               lo = max(lo, wlo); hi = min(hi, whi);
               if constexpr (NW == 1) asm volatile("" : "+s"(lo), "+s"(hi));
               lo = max(lo, n_rlo); hi = min(hi, n_rhi);
+              if constexpr (BANDED) {
+                uint32_t ax_n = a_x + rsb; if (ax_n == a_end) ax_n = a_first;       // slot of M[ns - x]; its diagonal 0: + (GZ - lo of that row)
+                band_cut(lo, hi, ns, prev_lo, range_lo(b_x), range_hi(b_x),
+                         reinterpret_cast<const OffT*>(reinterpret_cast<const char*>(m_first) + (ax_n - a_first)) + (GZ - range_lo(b_x)));
+              }
               const bool none = lo > hi;
               if (__builtin_expect(none && bounded && ns > budget, 0)) { why = 1; continue; }      // the careful path reports it
               const int wm1 = hi - lo;
@@ -894,6 +938,15 @@ wfa_align_kernel(const WfaAlignParams p) {
               a_ic += rsb; if (a_ic == ai_end) a_ic = ai_first;
               a_ip += rsb; if (a_ip == ai_end) a_ip = ai_first;
               const uint32_t a_dc = a_ic + d_delta, a_dp = a_ip + d_delta;
+              // (banded: rows relative to their own lower limit -- the per-row offsets of diagonal 0; a row that does not
+              // exist reads through the mapping of the current one: its slot is NULL all over)
+              uint32_t o_x = 0, o_oe = 0, o_e = 0;
+              if constexpr (BANDED) {
+                o_cur = (uint32_t)(GZ - lo) << 1;
+                o_x = range_lo(b_x) <= range_hi(b_x) ? (uint32_t)(GZ - range_lo(b_x)) << 1 : o_cur;
+                o_oe = range_lo(b_oe) <= range_hi(b_oe) ? (uint32_t)(GZ - range_lo(b_oe)) << 1 : o_cur;
+                o_e = range_lo(b_e) <= range_hi(b_e) ? (uint32_t)(GZ - range_lo(b_e)) << 1 : o_cur;
+              }
               auto store_null = [&](const uint32_t qa) {
                 *(LdsRow)(qa + a_m) = (OffT)OffNull<OffT>::value;
                 *(LdsRow)(qa + a_ic) = (OffT)OffNull<OffT>::value;
@@ -902,9 +955,13 @@ wfa_align_kernel(const WfaAlignParams p) {
               };
               if (none) {
                 // no wavefront at this score: the slots it would have written must read as NULL everywhere
-                const int o_m = book.get_a((s - dm) & bkm), o_e = book.get_a((s - de) & bkm);
-                const int f0 = min(range_lo(o_m), range_lo(o_e)), f1 = max(range_hi(o_m), range_hi(o_e));
-                for (int q = f0 + tid; q <= f1; q += NT) store_null((uint32_t)q << 1);
+                if constexpr (BANDED) {
+                  for (int q = tid; q < p.band_width + 2 * GZ; q += NT) store_null((uint32_t)q << 1);      // (the whole slot)
+                } else {
+                  const int o_m = book.get_a((s - dm) & bkm), o_e = book.get_a((s - de) & bkm);
+                  const int f0 = min(range_lo(o_m), range_lo(o_e)), f1 = max(range_hi(o_m), range_hi(o_e));
+                  for (int q = f0 + tid; q <= f1; q += NT) store_null((uint32_t)q << 1);
+                }
                 book.set_a(s & bkm, ROW_NONE_A);
                 block_sync<NW>();
                 continue;
@@ -914,9 +971,14 @@ wfa_align_kernel(const WfaAlignParams p) {
                 row_s = chunk_cur; chunk_cur += need; chunk_left -= need; need_prev = need;
                 tab_set(s, row_s, lo);
               }
-              // ring invariant: the limits move by at most one diagonal per score (see the e == 1 loop): dm cells beyond each end
-              // (lanes beyond 2 dm repeat the last of those cells: same value, same address, no exec mask)
-              {
+              if constexpr (BANDED) {
+                // ring invariant of relative rows: the guard zones on both sides of the row (columns 0 .. GZ-1 and GZ beyond
+                // its last cell) read NULL whatever the slot held before; nothing further out is ever read (see GZ)
+                for (int j = tid; j < 2 * GZ; j += NT) store_null((uint32_t)(j < GZ ? j : wm1 + 1 + j) << 1);
+                prev_lo = lo;
+              } else {
+                // ring invariant: the limits move by at most one diagonal per score (see the e == 1 loop): dm cells beyond each end
+                // (lanes beyond 2 dm repeat the last of those cells: same value, same address, no exec mask)
                 auto clear_guards = [&](const int j0) {
                   const int j = min(j0, 2 * dm - 1);
                   store_null((uint32_t)((j < dm) ? lo - 1 - j : hi + 1 - dm + j) << 1);
@@ -924,8 +986,8 @@ wfa_align_kernel(const WfaAlignParams p) {
                 clear_guards(tid);
                 if constexpr (NW == 1) { if (__builtin_expect(2 * dm > 64, 0)) clear_guards(tid + 64); }
               }
-              hot_cells(lo, wm1, code_addr, a_oe, a_x, a_m, a_ip, a_ic, a_dp, a_dc, pw_addr, tw_addr, a_hm, touch);
-              a_last = a_m;
+              hot_cells(lo, wm1, code_addr, a_oe + o_oe, a_x + o_x, a_m + o_cur, a_ip + o_e, a_ic + o_cur, a_dp + o_e, a_dc + o_cur, pw_addr, tw_addr, a_hm, touch);
+              a_last = a_m + o_cur;
               if constexpr (NW == 1) {
                 block_sync<NW>();
                 if (touch != 0ull) why = 3;
@@ -950,6 +1012,7 @@ wfa_align_kernel(const WfaAlignParams p) {
                      __builtin_amdgcn_readfirstlane((int)*(LdsRow)(a_last + ((uint32_t)kend << 1))) >= tlen;
             }
             if (s != s_in) book.copy_a_to_id(tid, NT, bkm);
+            if constexpr (BANDED) last_lo = prev_lo;
             regular = 0;      // (the careful path's shortcut for runs of regular scores starts counting afresh)
             p_m = m_first + (a_m - a_first) / 2; p_x = m_first + (a_x - a_first) / 2; p_oe = m_first + (a_oe - a_first) / 2;
             p_ic = m_first + (a_ic - a_first) / 2; p_ip = m_first + (a_ip - a_first) / 2;
@@ -957,7 +1020,7 @@ wfa_align_kernel(const WfaAlignParams p) {
             if (done) break;
           }
         }
-        if constexpr (!BANDED && !HOT) {
+        if constexpr (!HOT) {
           // (the tiers whose ring lives in HBM: one loop for every gap extension -- they are bound by the ring traffic, a
           // closed-form e == 1 twin of it bought nothing there)
           if (!touched_ever) {
@@ -1013,7 +1076,7 @@ wfa_align_kernel(const WfaAlignParams p) {
               }
               bool my_over = false;
               unsigned long long touch_mask = 0;
-              cells_of_score(std::true_type{}, lo, hi, codes, p_x, p_oe - 1, p_ip - 1, d_of(p_ip) + 1, out_m, out_i, out_d, BandCtx{},
+              cells_of_score(std::true_type{}, lo, hi, codes, p_x, p_oe - 1, p_ip - 1, d_of(p_ip) + 1, out_m, out_i, out_d,
                              my_over, touch_mask);
               const bool wave_touch = touch_mask != 0ull;
               bool any_touch;
@@ -1041,8 +1104,7 @@ wfa_align_kernel(const WfaAlignParams p) {
           }
         }
         ++s;
-        // (exact mode: past the budget the reach interval is empty, so the test sits on the "no wavefront" path)
-        if constexpr (BANDED) { if (s > budget) { status = WFA_ST_SCORE; break; } }
+        // (past the budget the reach interval is empty, so that test sits on the "no wavefront" path)
         if (reach_r == 0) { ++rlo; --rhi; reach_r = e - 1; } else --reach_r;
         if constexpr (NW > 1) {
           // reduction slot of the NEXT score (nobody reads it any more: its readers passed barrier s-1)
@@ -1061,11 +1123,11 @@ wfa_align_kernel(const WfaAlignParams p) {
         // limits (wavefront_compute.c:41-71; null rows carry lo=1, hi=-1)
         // (the empty asm keeps the chains on the scalar unit: min(min(a,b),c) would be matched to v_min3)
         int lo = min(mxlo, molo - 1), hi = max(mxhi, mohi + 1);
-        if constexpr (NW == 1 && !BANDED) asm volatile("" : "+s"(lo), "+s"(hi));
-        bool mx_null = false, mo_null = false, ie_null = false, de_null = false;   // (read by the banded cells)
+        if constexpr (NW == 1) asm volatile("" : "+s"(lo), "+s"(hi));
+        bool mx_null = false, mo_null = false, ie_null = false, de_null = false;
         bool all_null = false, have_i = true, have_d = true;
         int ielo, iehi, delo, dehi;
-        const bool fast = !BANDED && regular >= dm - 1;
+        const bool fast = regular >= dm - 1;
         if (fast) {
           // I and D of s-e span the M limits of s-e: min(lo+1, lo-1), max(hi+1, hi-1)
           const int a_e = book.get_a(bk_e);
@@ -1079,10 +1141,10 @@ wfa_align_kernel(const WfaAlignParams p) {
           all_null = mx_null && mo_null && ie_null && de_null;
           have_i = !(mo_null && ie_null); have_d = !(mo_null && de_null);
           lo = min(lo, ielo + 1); hi = max(hi, iehi + 1);
-          if constexpr (NW == 1 && !BANDED) asm volatile("" : "+s"(lo), "+s"(hi));
+          if constexpr (NW == 1) asm volatile("" : "+s"(lo), "+s"(hi));
           lo = min(lo, delo - 1); hi = max(hi, dehi - 1);
         }
-        if constexpr (!BANDED) {
+        {
           if constexpr (NW == 1) asm volatile("" : "+s"(lo), "+s"(hi));
           lo = max(lo, wlo); hi = min(hi, whi);
           if constexpr (NW == 1) asm volatile("" : "+s"(lo), "+s"(hi));
@@ -1093,10 +1155,15 @@ wfa_align_kernel(const WfaAlignParams p) {
         OffT* out_d = d_of(p_ic);
         if (all_null || lo > hi) {
           // no wavefront at this score (wavefront_compute_affine.c:236-243)
-          if constexpr (!BANDED) { if (s > budget) { status = WFA_ST_SCORE; break; } }
+          if (s > budget) { status = WFA_ST_SCORE; break; }
           regular = 0;
           book.set(bk_s, ROW_NONE_A, ROW_NONE_A, ROW_NONE_A);
-          if constexpr (!BANDED) {
+          if constexpr (BANDED) {
+            // (relative rows: the whole slot)
+            for (int q = tid; q < p.band_width + 2 * GZ; q += NT) {
+              out_m[q] = (OffT)OffNull<OffT>::value; out_i[q] = (OffT)OffNull<OffT>::value; out_d[q] = (OffT)OffNull<OffT>::value;
+            }
+          } else {
             // the slots this score would have written: clear what their previous occupants left
             const int o_m = book.get_a((s - dm) & bkm), o_e = book.get_a((s - de) & bkm);
             const int f0 = min(range_lo(o_m), range_lo(o_e)), f1 = max(range_hi(o_m), range_hi(o_e));
@@ -1107,48 +1174,7 @@ wfa_align_kernel(const WfaAlignParams p) {
           block_sync<NW>();
           continue;
         }
-        const int base_mx = BANDED ? mxlo : 0, base_mo = BANDED ? molo : 0, base_e = BANDED ? range_lo(book.get_a(bk_e)) : 0;
-        if constexpr (BANDED) {
-          // Adaptive band (reference: sequence_distance_kernel_aband.cu:104-130): keep at most
-          // band_width diagonals; every band_period scores re-centre the window on the diagonal of
-          // the mismatch-source wavefront whose furthest point is closest to the end, otherwise
-          // shave the excess off both sides.  Rows are stored relative to their own lo.
-          const int beta = p.band_width;
-          const int excess = (hi - lo + 1) - beta;
-          if (excess > 0) {
-            bool recentred = false;
-            if (!mx_null && (s % p.band_period) == 0) {
-              const OffT* rowc = p_x;
-              uint32_t best = 0xFFFFFFFFu;
-              for (int kk = mxlo + tid; kk <= mxhi; kk += NT) {
-                const int off = (int)rowc[kk - mxlo];
-                if (off >= 0) {
-                  const int dist = max(plen - (off - kk), tlen - off);
-                  best = min(best, ((uint32_t)dist << 16) | (uint32_t)(kk - mxlo));
-                }
-              }
-#pragma unroll
-              for (int d = 32; d > 0; d >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, d));
-              if constexpr (NW > 1) {
-                uint32_t* slot = bslot + 1;
-                if (tid == 0) *slot = 0xFFFFFFFFu;
-                __syncthreads();
-                if (lane == 0) atomicMin(slot, best);
-                __syncthreads();
-                best = *slot;
-                __syncthreads();
-              }
-              if (best != 0xFFFFFFFFu) {
-                const int centre = mxlo + (int)(best & 0xFFFFu);
-                int nlo = centre - beta / 2;
-                nlo = max(lo, min(nlo, hi - beta + 1));
-                lo = nlo; hi = nlo + beta - 1;
-                recentred = true;
-              }
-            }
-            if (!recentred) { hi -= (excess + 1) / 2; lo += excess / 2; }
-          }
-        }
+        if constexpr (BANDED) band_cut(lo, hi, s, last_lo, mxlo, mxhi, p_x + (GZ - mxlo));
         const int width = hi - lo + 1;
         ncells += (uint32_t)width;
 
@@ -1163,9 +1189,14 @@ wfa_align_kernel(const WfaAlignParams p) {
         const OffT* row_mo = p_oe;
         const OffT* row_ie = p_ip;
         const OffT* row_de = d_of(p_ip);
-        const int wbase = BANDED ? -lo : 0;       // index of diagonal 0 in the rows written now
 
-        if constexpr (!BANDED) {
+        if constexpr (BANDED) {
+          // ring invariant of relative rows: NULL guard zones on both sides of the row, whatever the slot held before
+          for (int j = tid; j < 2 * GZ; j += NT) {
+            const int q = j < GZ ? j : width + j;
+            out_m[q] = (OffT)OffNull<OffT>::value; out_i[q] = (OffT)OffNull<OffT>::value; out_d[q] = (OffT)OffNull<OffT>::value;
+          }
+        } else {
           // Keep the ring invariant: the M slot last held score s-dm, the I/D slots score s-e-1; whatever
           // those rows had beyond [lo, hi] becomes NULL again (nothing while the wavefront grows).
           const int o_m = book.get_a((s - dm) & bkm), o_e = book.get_a((s - de) & bkm);
@@ -1184,20 +1215,24 @@ wfa_align_kernel(const WfaAlignParams p) {
         // The vector ALU is the unit this kernel saturates (one integer wave64 instruction holds its
         // SIMD for 4 cycles), so everything uniform is folded into scalar row bases: each LDS address
         // is one v_lshl_add of the diagonal.
-        const OffT* rb_mx = row_mx + (BANDED ? -base_mx : 0);          // [k]
-        const OffT* rb_mo = row_mo + (BANDED ? -base_mo : 0) - 1;      // [k] = k-1, [k+2] = k+1
-        const OffT* rb_ie = row_ie + (BANDED ? -base_e : 0) - 1;       // [k] = k-1
-        const OffT* rb_de = row_de + (BANDED ? -base_e : 0) + 1;       // [k] = k+1
-        OffT* wb_m = out_m + wbase;
-        OffT* wb_i = out_i + wbase;
-        OffT* wb_d = out_d + wbase;
+        // (banded: a row is stored relative to its own lower limit -- diagonal 0 of a row with limits [lo_r, ..] is column
+        // GZ - lo_r of its slot; M, I and D of a score share the mapping; a row that does not exist is read through the
+        // mapping of the current one: its slot is NULL all over)
+        const int rel_cur = BANDED ? GZ - lo : 0;
+        const int rel_x = BANDED ? (mxlo <= mxhi ? GZ - mxlo : rel_cur) : 0;
+        const int rel_oe = BANDED ? (molo <= mohi ? GZ - molo : rel_cur) : 0;
+        int rel_e = 0;
+        if constexpr (BANDED) { const int a_e2 = book.get_a(bk_e); rel_e = range_lo(a_e2) <= range_hi(a_e2) ? GZ - range_lo(a_e2) : rel_cur; }
+        const OffT* rb_mx = row_mx + rel_x;          // [k]
+        const OffT* rb_mo = row_mo + rel_oe - 1;      // [k] = k-1, [k+2] = k+1
+        const OffT* rb_ie = row_ie + rel_e - 1;      // [k] = k-1
+        const OffT* rb_de = row_de + rel_e + 1;      // [k] = k+1
+        OffT* wb_m = out_m + rel_cur;
+        OffT* wb_i = out_i + rel_cur;
+        OffT* wb_d = out_d + rel_cur;
         bool my_over = false;
         unsigned long long touch_mask = 0;
-        {
-          BandCtx bc;
-          if constexpr (BANDED) bc = BandCtx{mx_null, mo_null, ie_null, de_null, mxlo, mxhi, molo, mohi, ielo, iehi, delo, dehi};
-          cells_of_score(std::false_type{}, lo, hi, codes, rb_mx, rb_mo, rb_ie, rb_de, wb_m, wb_i, wb_d, bc, my_over, touch_mask);
-        }
+        cells_of_score(std::false_type{}, lo, hi, codes, rb_mx, rb_mo, rb_ie, rb_de, wb_m, wb_i, wb_d, my_over, touch_mask);
         bool any_over = false;
         {
           const bool wave_over = __builtin_amdgcn_ballot_w64(my_over) != 0ull;
@@ -1237,8 +1272,8 @@ wfa_align_kernel(const WfaAlignParams p) {
             const int kraw = k0 + tid;
             const bool active = kraw <= hi;
             const int k = active ? kraw : hi;
-            const int iv = have_i ? (int)out_i[wbase + k] : OffNull<OffT>::value;
-            const int dv = have_d ? (int)out_d[wbase + k] : OffNull<OffT>::value;
+            const int iv = have_i ? (int)wb_i[k] : OffNull<OffT>::value;
+            const int dv = have_d ? (int)wb_d[k] : OffNull<OffT>::value;
             const bool i_ok = ((unsigned)iv <= (unsigned)tlen) && ((unsigned)(iv - k) <= (unsigned)plen);
             const bool d_ok = ((unsigned)dv <= (unsigned)tlen) && ((unsigned)(dv - k) <= (unsigned)plen);
             const int b = k0 + wave * 64;
@@ -1258,11 +1293,11 @@ wfa_align_kernel(const WfaAlignParams p) {
           if (r[0] > r[1]) { r[0] = ROW_NONE_LO; r[1] = ROW_NONE_HI; }
           if (r[2] > r[3]) { r[2] = ROW_NONE_LO; r[3] = ROW_NONE_HI; }
           lim_i = pack_range(r[0], r[1]); lim_d = pack_range(r[2], r[3]);
-          if constexpr (!BANDED) {
+          {
             // trimmed-away cells read as NULL from now on (wavefront_compute.c:480-520)
             for (int q = lo + tid; q <= hi; q += NT) {
-              if (q < r[0] || q > r[1]) out_i[q] = (OffT)OffNull<OffT>::value;
-              if (q < r[2] || q > r[3]) out_d[q] = (OffT)OffNull<OffT>::value;
+              if (q < r[0] || q > r[1]) wb_i[q] = (OffT)OffNull<OffT>::value;
+              if (q < r[2] || q > r[3]) wb_d[q] = (OffT)OffNull<OffT>::value;
             }
             if constexpr (NW > 1) __syncthreads();
           }

@@ -366,14 +366,15 @@ int window_width(long long S, int o, int e, unsigned max_seq_len) {
 bool plan_tier(const wfagpu_amd_ctx* c, WfaAlignParams& p, int max_score, unsigned max_seq_len, bool bt, bool raw, TierPlan* out) {
   p.max_score = max_score;
   if (p.band_width > 0) {
-    // adaptive band: the ring rows hold band_width diagonals whatever the score
-    p.rs = (p.band_width + 2 + 1) & ~1;
-    // (the single-wavefront kernels keep the row book in VGPR lanes: at most 64 ring rows)
-    // One wavefront per alignment up to 512 diagonals (beta 352: 26.8 -> 18.4 ms per 16k 10 kbp pairs, 512: 26.4 -> 24.8,
-    // 1024: 33 -> 55, so not beyond): the banded kernels spend most of their
-    // instructions on per-score scalar bookkeeping, which every wave of a workgroup repeats.
+    // Adaptive band: a ring row holds the band_width diagonals of its score, stored relative to the row's own lower limit,
+    // between two guard zones of 4 dm + 2 NULL cells (see the kernel: the band moves by at most two diagonals per score),
+    // plus the padding chunk of the lean cells.
+    p.rs = ((p.band_width + 2 * (4 * p.dm + 2) + 2 + 1) & ~1) + WFA_RING_ROW_PAD;
+    // One wavefront per alignment up to 512 diagonals, four up to 1024, sixteen beyond (the per-score bookkeeping is
+    // repeated by every wave of a workgroup).
     constexpr int t0_max = 512;
-    const int t = (p.band_width <= t0_max && p.dm <= 64) ? 0 : (p.band_width <= 1024 ? 1 : 2);
+    int t = (p.band_width <= t0_max && p.dm <= 64) ? 0 : (p.band_width <= 1024 ? 1 : 2);
+    if (c->tuning.min_tier >= 1 && c->tuning.min_tier <= 2) t = std::max(t, c->tuning.min_tier);      // (test hook)
     const size_t lds = wfa_align_lds_bytes(p, t);
     if (lds > c->lds_per_block_max || max_seq_len > 32766u || max_score > 30000) return false;
     const int nb = wfa_align_max_blocks_per_cu(t, bt, false, true, lds);

@@ -66,7 +66,7 @@ def algorithmic_bytes(seq_bytes, pairs, cells, compute_cigar):
     return int(seq_bytes + 68 * pairs + (6 * cells if compute_cigar else 0))
 
 
-def _pmc_main_launch(workload, counters):
+def _pmc_main_launch(workload, counters, optional=()):
     """Counters of the MAIN launch (largest WRITE_SIZE+FETCH_SIZE) of wfa_align_kernel from the newest committed rocprofv3
     PMC summary of this same command (profiles/rNN/<workload>_pmc_counters.csv; separate --pmc passes over one step).
     Returns (values, source, stale) -- stale when the summary was taken with other kernel sources than the ones here."""
@@ -84,8 +84,12 @@ def _pmc_main_launch(workload, counters):
     for c in counters:
         vals = [float(r["value"]) for r in rows if r["counter"] == c]
         if not vals:
+            if c in optional:
+                continue
             return None, None, None
         out[c] = max(vals)          # the main launch dominates every counter used here
+        ms = [float(r["kernel_ms_under_pmc"]) for r in rows if r["counter"] == c and float(r["value"]) == out[c]]
+        out["_ms_" + c] = ms[0] if ms else None
     return out, os.path.relpath(src, ROOT), stale
 
 
@@ -307,7 +311,9 @@ def main():
         achieved = alg / (main_ms * 1e-3) / 1e9 if main_ms > 0 else 0.0
         # (the committed counters belong to the default command: not to other sizes, and not to runs with the A/B switches set)
         default_cmd = not args.pairs and not args.max_error and not tuning
-        pmc, pmc_src, pmc_stale = _pmc_main_launch(args.workload, ["FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_INSTS_SALU"]) \
+        hw = ["SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_LDS", "GRBM_GUI_ACTIVE", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES",
+              "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS"]
+        pmc, pmc_src, pmc_stale = _pmc_main_launch(args.workload, ["FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_INSTS_SALU"] + hw, optional=hw) \
             if default_cmd else (None, None, None)
         # HBM bytes of the main launch: (FETCH_SIZE*2 + WRITE_SIZE) KB -- FETCH_SIZE counts half of a wide coalesced
         # read on gfx950 (MI355X_MICROARCH.md, HBM section)
@@ -334,6 +340,21 @@ def main():
             for pipe, key in (("valu", "SQ_INSTS_VALU"), ("salu", "SQ_INSTS_SALU")):
                 ach = pmc[key] / (main_ms * 1e-3) / 1e9
                 roofline["issue"][pipe] = {"achieved": round(ach, 1), "frac": round(ach / peak, 3), "insts": int(pmc[key])}
+            if "SQ_ACTIVE_INST_VALU" in pmc and pmc.get("GRBM_GUI_ACTIVE"):
+                # The same from the hardware's own busy counters (the gfx9 VALUBusy / SALUBusy formulas): SQ_ACTIVE_INST_*
+                # count quad-cycles a pipe spent on instructions, summed over the chip; GRBM_GUI_ACTIVE is summed over the 8
+                # XCDs.  No microbenchmark in the denominator.
+                simds, xcds = 1024, 8
+                cyc = pmc["GRBM_GUI_ACTIVE"] / xcds
+                roofline["issue"]["hw_counters"] = {
+                    "valu_busy": round(pmc["SQ_ACTIVE_INST_VALU"] * 4 / simds / cyc, 3),
+                    "salu_busy": round(pmc["SQ_ACTIVE_INST_SCA"] * 4 / simds / cyc, 3),
+                    "lds_busy": round(pmc.get("SQ_ACTIVE_INST_LDS", 0) * 4 / simds / cyc, 3),
+                    "wave_cycles_split": {k: round(pmc[c] / pmc["SQ_WAVE_CYCLES"], 3) for k, c in
+                                          (("issuing", "SQ_ACTIVE_INST_ANY"), ("stalled_at_issue", "SQ_WAIT_INST_ANY"), ("parked_waitcnt_or_barrier", "SQ_WAIT_ANY"))
+                                          if pmc.get("SQ_WAVE_CYCLES") and c in pmc},
+                    "clock_ghz_during_launch": round(cyc / (pmc["_ms_GRBM_GUI_ACTIVE"] * 1e-3) / 1e9, 3) if pmc.get("_ms_GRBM_GUI_ACTIVE") else None,
+                    "formula": "SQ_ACTIVE_INST_{VALU,SCA,LDS} * 4 / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs)"}
         out = {
             "metric": "alignments_per_sec", "value": round(value, 1), "unit": "alignments/s",
             "n_gpus": world, "steps": steps, "warmup": args.warmup,

@@ -264,8 +264,10 @@ def main():
 
     dist = None
     torch.cuda.set_device(local_rank)
+    host_grp = None
     if world > 1:
         dist = shardlib.init_distributed("nccl", device=torch.device("cuda", local_rank))   # "nccl" is RCCL on ROCm
+        host_grp = shardlib.host_group(dist)
 
     # synthetic data (seeded; every rank its own shard), resident in HBM before the clock starts
     buf, meta = wfagpu.generate_pairs(n_pairs, wl["length"], wl["error"], seed=shardlib.shard_seed(1000, rank),
@@ -421,17 +423,28 @@ def main():
         # ONCE and the library shards the call over the N devices from one process: host RAM bandwidth, the PCIe root and
         # the scatter threads are shared then.  Rank 0 measures that too, on N x P pairs, while the other
         # ranks (their contexts closed above) wait at the barrier; it never replaces `value`.
-        dist.barrier()
-        if rank == 0 and not args.no_host_to_host:
+        # (the wait is a gloo barrier: an RCCL barrier would keep a spinning kernel on every waiting rank's GPU)
+        # (... and the call runs in a CHILD process of rank 0 -- `bench.py --mode library --gpus N` -- so that nothing it
+        # does, not even a fatal device error, can cost the ranks' own line)
+        def library_leg():
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK",
+                                                                    "ROLE_RANK", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+            cmd = [sys.executable, os.path.abspath(__file__), "--mode", "library", "--gpus", str(world), "--workload", args.workload,
+                   "--pairs", str(n_pairs), "--max-error", str(max_error), "--steps", "4", "--warmup", "2"]
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not lines:
+                return {"error": f"exit code {r.returncode}: {r.stderr[-400:]}"}
+            return json.loads(lines[-1])
+        if not args.no_host_to_host:
             try:
-                big_buf, big_meta = wfagpu.generate_pairs(n_pairs * world, wl["length"], wl["error"], seed=1000,
-                                                          nthreads=min(16, usable_cores()))
-                h2h = host_to_host(big_buf, big_meta, wl, max_error, n_devices=world, reps=4, tuning=tuning)
-                out["library_call"] = h2h
-                out["library_call_value"] = h2h["pageable"]["warm"]
-                del big_buf, big_meta
+                leg = shardlib.rank0_exclusive(dist, host_grp, rank, library_leg)
+                if rank == 0:
+                    out["library_call"] = leg
+                    out["library_call_value"] = leg.get("value")
             except Exception as ex:
-                out["library_call"] = {"error": str(ex)}
+                if rank == 0:
+                    out["library_call"] = {"error": str(ex)}
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
@@ -497,13 +510,17 @@ def cpu_harness(args, rank, world, n_pairs, steps):
         state["s"], _, _ = oracle_lib.oracle_batch(buf, meta, PEN, cigar=False)
 
     elapsed = shardlib.timed_steps(step, steps, args.warmup, dist=dist)
+    excl = None
     if dist is not None:
+        # the rank-0-alone leg of the GPU run (the in-library sharded call), with a stand-in for the call
+        grp = shardlib.host_group(dist)
+        excl = shardlib.rank0_exclusive(dist, grp, rank, lambda: {"ranks_parked": world - 1})
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps({"metric": "alignments_per_sec", "harness_only": True, "n_gpus": world, "steps": steps,
                           "warmup": args.warmup, "value": n * steps * world / elapsed, "unit": "alignments/s",
-                          "ms_per_step": elapsed / steps * 1e3, "scaling": "weak"}))
+                          "ms_per_step": elapsed / steps * 1e3, "scaling": "weak", "library_call": excl}))
 
 
 if __name__ == "__main__":

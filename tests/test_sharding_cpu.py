@@ -84,6 +84,7 @@ def test_bench_gpus_flag_starts_its_own_ranks():
     GPU step for the oracle and RCCL for gloo so that this launch path is covered here."""
     out = _bench_json(["--gpus", "2", "--cpu-harness", "--steps", "2", "--warmup", "1"])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["harness_only"] is True
+    assert out["library_call"] == {"ranks_parked": 1}      # the rank-0-alone leg ran between two host barriers
     one = _bench_json(["--cpu-harness", "--steps", "2", "--warmup", "1"])
     assert one["n_gpus"] == 1
 

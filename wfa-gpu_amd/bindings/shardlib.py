@@ -22,6 +22,7 @@ def init_distributed(backend, device=None):
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")     # (one node: the host group of rank0_exclusive needs no name lookup)
     kw = {}
     if device is not None:
         kw["device_id"] = device
@@ -51,3 +52,26 @@ def timed_steps(step, steps, warmup, dist=None, sync=lambda: None, device="cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed
+
+
+def host_group(dist):
+    """A second process group on gloo (CPU sockets) for waits that must not occupy the GPUs: a barrier of the RCCL group is
+    a kernel that spins on every rank's device.  Collective: every rank calls it, right after init_distributed."""
+    return dist.new_group(backend="gloo")
+
+
+def rank0_exclusive(dist, group, rank, fn):
+    """Every rank meets at a host barrier, rank 0 alone runs fn() (it may use every GPU of the node: the other ranks are
+    parked in a socket wait, their devices idle), every rank meets again.  Returns fn()'s result on rank 0, None elsewhere."""
+    dist.barrier(group=group)
+    out = None
+    err = None
+    if rank == 0:
+        try:
+            out = fn()
+        except Exception as ex:     # the other ranks must not be left waiting
+            err = ex
+    dist.barrier(group=group)
+    if err is not None:
+        raise err
+    return out

@@ -99,6 +99,9 @@ typedef struct {
 int wfagpu_amd_create(wfagpu_amd_ctx_t** ctx, const wfagpu_amd_config_t* cfg);
 void wfagpu_amd_destroy(wfagpu_amd_ctx_t* ctx);
 
+/* The HIP stream (hipStream_t) the context runs on -- its own, or the one given at creation. */
+void* wfagpu_amd_stream(const wfagpu_amd_ctx_t* ctx);
+
 /* Replaces the tuning switches of a live context (between calls).  NULL: the defaults. */
 void wfagpu_amd_set_tuning(wfagpu_amd_ctx_t* ctx, const wfagpu_amd_tuning_t* tuning);
 

@@ -643,3 +643,39 @@ def test_big_batch_with_budget_misses_and_escalation():
         assert np.array_equal(s2, so)
     finally:
         al.close()
+
+
+def test_cigar_runs_of_six_and_more_digits():
+    """Near-identical reads beyond 100 kbp: a match run prints as six or more digits ("150000M").  The text bound is sized
+    from the longest sequence of the batch (not from a fixed five digits per item) and the RLE printer handles ten digits."""
+    rng = random.Random(99)
+    a = bytes(rng.choice(b"ACGT") for _ in range(150_000))
+    b = bytearray(a); b[70_000] = ord("A") if a[70_000] != ord("A") else ord("C")
+    c = a[:100_000] + a[100_003:]
+    pairs = [(a, a), (a, bytes(b)), (a, c), (c, a)]
+    buf, meta = wfagpu.layout_pairs(pairs)
+    so, co = _truth(buf, meta, (2, 3, 1))
+    assert co[0] == "150000M" and co[1] == "70000M1X79999M"
+    al = wfagpu.DeviceAligner(0)
+    try:
+        s, cg = _run(al, buf, meta, (2, 3, 1), max_error=100)
+        assert np.array_equal(s, so) and cg == co
+    finally:
+        al.close()
+
+
+@pytest.mark.parametrize("trace_mode", [1, 2])
+def test_fallback_backtrace_paths(trace_mode):
+    """wfagpu_amd_tuning_t::trace_mode 1: lane-per-alignment walk + the windowed emit kernel whatever the length (the
+    fallback for sequences that leave the wave-per-alignment kernel no LDS); 2: never several alignments per wavefront.
+    Same CIGARs as the default choice."""
+    rng = random.Random(5150 + trace_mode)
+    pairs = _rand_pairs(rng, 200, 2500, err=0.06) + _rand_pairs(rng, 64, 300, err=0.1) + [(b"", b"ACGT"), (b"ACGT" * 700, b"ACGT" * 650)]
+    buf, meta = wfagpu.layout_pairs(pairs)
+    so, co, _ = oracle_lib.oracle_batch(buf, meta, (2, 3, 1), cigar=True, nthreads=8)
+    al = wfagpu.DeviceAligner(0, trace_mode=trace_mode)
+    try:
+        s, cg = _run(al, buf, meta, (2, 3, 1), max_error=2000)
+        assert np.array_equal(s, so) and cg == co
+    finally:
+        al.close()

@@ -93,7 +93,7 @@ ABI_SYMBOLS = [
     "wfagpu_amd_create", "wfagpu_amd_destroy", "wfagpu_amd_fill_packed_offsets", "wfagpu_amd_pack_device",
     "wfagpu_amd_align_device", "wfagpu_amd_last_stats", "wfagpu_amd_set_num_devices", "wfagpu_amd_release_cache",
     "wfagpu_amd_check_failures", "wfagpu_amd_hint_same_stream", "wfagpu_amd_configure_launch",
-    "wfagpu_amd_last_launch_stats", "wfagpu_amd_set_tuning",
+    "wfagpu_amd_last_launch_stats", "wfagpu_amd_set_tuning", "wfagpu_amd_stream",
 ]
 
 _lib = None

@@ -334,6 +334,8 @@ int wfagpu_amd_pack_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_batch_t* b, voi
   return 0;
 }
 
+void* wfagpu_amd_stream(const wfagpu_amd_ctx_t* c) { return c ? static_cast<void*>(c->stream) : nullptr; }
+
 void wfagpu_amd_set_tuning(wfagpu_amd_ctx_t* c, const wfagpu_amd_tuning_t* tuning) {
   if (c) c->tuning = tuning ? *tuning : wfagpu_amd_tuning_t{};
 }

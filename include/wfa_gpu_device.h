@@ -123,7 +123,8 @@ int wfagpu_amd_pack_device(wfagpu_amd_ctx_t* ctx, const wfagpu_amd_batch_t* batc
  *   d_scores      device int32[num_pairs], positive scores
  *   compute_cigar when true the CIGAR text stays in the context's arena:
  *                 *d_text, *d_off (uint64 byte offsets), *d_len (uint32 strlen)
- *                 are device pointers valid until the next call on ctx.
+ *                 are device pointers that stay valid THROUGH the next call on ctx (two sets of
+ *                 buffers alternate: a pipelined caller downloads batch j under the kernels of j+1).
  * Blocking (returns after the stream has drained).  0 on success. */
 int wfagpu_amd_align_device(wfagpu_amd_ctx_t* ctx, const wfagpu_amd_batch_t* batch,
                             affine_penalties_t penalties, int max_error, int band, int band_width,
@@ -150,7 +151,7 @@ typedef struct {
     size_t input_pool_bytes;  /* device memory for resident input per device (0: a quarter of the free memory, <= 24 GiB) */
     int numa_pin;             /* 0: pin a device's host threads to its NUMA node when several devices are used,
                                  1: always (test hook for one-GPU boxes), -1: never                                      */
-    int timing;               /* 1: print the stage times of every device on stderr                                      */
+    int timing;               /* 1: print the stage times of every device on stderr; 2: also a clock line per batch       */
     wfagpu_amd_tuning_t tuning;   /* handed to every context the calls create                                            */
 } wfagpu_amd_launch_config_t;
 

@@ -18,8 +18,8 @@ lib = wfagpu.load()
 lanes = int(sys.argv[7]) if len(sys.argv) > 7 else 0
 nbatch = int(sys.argv[8]) if len(sys.argv) > 8 else 0
 bpc = int(sys.argv[9]) if len(sys.argv) > 9 else 0
-wfagpu.configure_launch(timing=0, lanes_per_device=lanes, batches_per_device=nbatch, tuning={"max_blocks_per_cu": bpc})
-buf, meta = wfagpu.generate_pairs(n, length, err, seed=7, nthreads=16)
+wfagpu.configure_launch(timing=int(os.environ.get("TIMING", "0")), lanes_per_device=lanes, batches_per_device=nbatch, tuning={"max_blocks_per_cu": bpc})
+buf, meta = wfagpu.generate_pairs(n, length, err, seed=int(os.environ.get("SEED", "7")), nthreads=16)
 res = C.POINTER(wfagpu.AlignmentResult)()
 assert lib.initialize_wfa_results(C.byref(res), n, 256)
 opt = wfagpu.Options(max_error=int(length * 0.1 * 3), threads_per_block=64, num_workers=0, band=-1, batch_size=batch,

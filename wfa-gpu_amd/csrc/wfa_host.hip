@@ -243,7 +243,12 @@ struct wfagpu_amd_ctx {
   size_t lds_per_block_max = 0;
   size_t arena_cfg = 0, text_cfg = 0, arena_limit = 0, arena_limit_max = 0;
   wfagpu_amd_tuning_t tuning{};
-  DevBuf packed, flags, status, cells, bt_final, list_a, list_b, list_c, list_d, list_e, work_ctr, sample, ratio, budget, counters, arena, ops, text, text_scratch, cig_off, cig_len, gring;
+  DevBuf packed, flags, status, cells, bt_final, list_a, list_b, list_c, list_d, list_e, work_ctr, sample, ratio, budget, counters, arena, ops, text_scratch, gring;
+  // The results of a CIGAR call -- dense text, offsets, lengths -- alternate between two sets of buffers: the pointers a call
+  // hands out stay valid through the NEXT call, so a pipelined caller copies the results of batch j to the host while the
+  // kernels of batch j+1 run (launch_alignments*: the copy left the lanes' critical path).
+  DevBuf text[2], cig_off[2], cig_len[2];
+  int out_set = 0;
   unsigned long long* h_counters = nullptr;  // pinned
   hipEvent_t ev_start = nullptr, ev_pack = nullptr, ev_a0 = nullptr, ev_a1 = nullptr, ev_b0 = nullptr, ev_b1 = nullptr, ev_t0 = nullptr, ev_t1 = nullptr, ev_end = nullptr;
   wfagpu_amd_stats_t stats{};
@@ -304,7 +309,7 @@ void wfagpu_amd_destroy(wfagpu_amd_ctx_t* c) {
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
   for (DevBuf* b : {&c->packed, &c->flags, &c->status, &c->cells, &c->bt_final, &c->list_a, &c->list_b, &c->list_c, &c->list_d, &c->list_e, &c->work_ctr, &c->sample, &c->ratio, &c->budget,
-                    &c->counters, &c->arena, &c->ops, &c->text, &c->text_scratch, &c->cig_off, &c->cig_len, &c->gring})
+                    &c->counters, &c->arena, &c->ops, &c->text[0], &c->text[1], &c->text_scratch, &c->cig_off[0], &c->cig_off[1], &c->cig_len[0], &c->cig_len[1], &c->gring})
     b->release();
   if (c->h_counters) hipHostFree(c->h_counters);
   for (hipEvent_t ev : {c->ev_start, c->ev_pack, c->ev_a0, c->ev_a1, c->ev_b0, c->ev_b1, c->ev_t0, c->ev_t1, c->ev_end})
@@ -495,8 +500,8 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   if (c->list_d.ensure((size_t)4 * n, st)) return -1;
   if (compute_cigar) {
     if (c->bt_final.ensure((size_t)4 * n, st)) return -1;
-    if (c->cig_off.ensure((size_t)8 * n, st)) return -1;
-    if (c->cig_len.ensure((size_t)4 * n, st)) return -1;
+    if (c->cig_off[c->out_set].ensure((size_t)8 * n, st)) return -1;
+    if (c->cig_len[c->out_set].ensure((size_t)4 * n, st)) return -1;
   }
   const unsigned batch_max_len = std::max(1u, b->max_seq_len);
   unsigned max_len = batch_max_len;    // of the pairs being run: the whole batch, or one length bucket of it
@@ -717,7 +722,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         }
         const unsigned long long text_need = text_used + text_sum + 256;
         if (c->ops.ensure(ops_need, st)) return -1;
-        if (c->text.ensure(std::max<size_t>(text_need, c->text_cfg), st, text_used)) return -1;
+        if (c->text[c->out_set].ensure(std::max<size_t>(text_need, c->text_cfg), st, text_used)) return -1;
         {
           // op list (one byte per score point of the largest score of the pass) and CIGAR text of one alignment in LDS,
           // within 40 KiB per wavefront so that at least four of them fit a CU
@@ -742,7 +747,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         tp.score_fix = (want_band && !raw) ? d_scores : nullptr;
         tp.arena = ap.arena; tp.arena_bytes = (unsigned long long)c->arena.cap; tp.bt_final_row = ap.bt_final_row;
         tp.ops = static_cast<uint8_t*>(c->ops.p); tp.ops_cap = c->ops.cap; tp.ops_top = ct + CT_OPS;
-        tp.text = static_cast<char*>(c->text.p); tp.text_cap = c->text.cap; tp.text_top = ct + CT_TEXT;
+        tp.text = static_cast<char*>(c->text[c->out_set].p); tp.text_cap = c->text[c->out_set].cap; tp.text_top = ct + CT_TEXT;
         tp.min_op_cost = std::min(pen.x, pen.e);
         tp.item_chars = item_chars;
         // lane-per-alignment emit with whole sequences staged: one replay into a scratch + compaction (big passes only: the
@@ -752,8 +757,8 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
           if (zero_counter(c, CT_SCRATCH)) return -1;
           tp.text_scratch = static_cast<char*>(c->text_scratch.p); tp.text_scratch_cap = c->text_scratch.cap; tp.scratch_top = ct + CT_SCRATCH;
         }
-        tp.cigar_off = static_cast<unsigned long long*>(c->cig_off.p);
-        tp.cigar_len = static_cast<uint32_t*>(c->cig_len.p);
+        tp.cigar_off = static_cast<unsigned long long*>(c->cig_off[c->out_set].p);
+        tp.cigar_len = static_cast<uint32_t*>(c->cig_len[c->out_set].p);
         HIP_TRY(hipEventRecord(c->ev_t0, st));
         wfa_launch_trace(tp, st);
         HIP_TRY(hipGetLastError());
@@ -1036,9 +1041,10 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   c->stats.trace_ms = trace_ms;
   c->stats.text_bytes = text_used;
   if (compute_cigar) {
-    if (d_text) *d_text = static_cast<const char*>(c->text.p);
-    if (d_off) *d_off = static_cast<const unsigned long long*>(c->cig_off.p);
-    if (d_len) *d_len = static_cast<const unsigned int*>(c->cig_len.p);
+    if (d_text) *d_text = static_cast<const char*>(c->text[c->out_set].p);
+    if (d_off) *d_off = static_cast<const unsigned long long*>(c->cig_off[c->out_set].p);
+    if (d_len) *d_len = static_cast<const unsigned int*>(c->cig_len[c->out_set].p);
+    c->out_set ^= 1;      // (the next call writes the other set)
   }
   return rc;
 }

@@ -14,9 +14,11 @@
 //                    whole slice stays resident (1M x 1 kbp pairs: 2 GB), so the copy engine never idles while a
 //                    batch computes: the call is bound by PCIe (2 GB at ~56 GB/s = 36 ms) or by the kernels,
 //                    whichever is longer, plus the tail of the last batch
-//   K compute lanes  contexts (stream, backtrace arena, scratch) that take alternate batches: the host round trips,
-//                    backtrace kernels and result copies of one lane are filled by the wavefront kernels of the other
-//   K scatter lanes  pinned staging -> the caller's wfa_alignment_result_t records (+ the -c check)
+//   K compute lanes  contexts (stream, backtrace arena, scratch) that take alternate batches: the host round trips and
+//                    backtrace kernels of one lane are filled by the wavefront kernels of the other
+//   K result lanes   D2H of a batch's results into pinned staging -- under the kernels of the lane's NEXT batch: a context
+//                    alternates between two sets of output buffers --, then staging -> the caller's
+//                    wfa_alignment_result_t records (+ the -c check)
 //
 // The reference overlaps the same phases by hand with two streams and double buffers (lib/align.cu:63-68,177-385).
 // The library reads no environment variables: see wfagpu_amd_launch_config_t.
@@ -208,9 +210,8 @@ int check_batch(const CallArgs& a, size_t from, size_t to, int batch_idx, unsign
 // single-threaded by contract (lib/aligner.h of the reference is not re-entrant); a mutex per slot guards the cache anyway.
 struct Lane {
   wfagpu_amd_ctx_t* ctx = nullptr;
-  hipStream_t down = nullptr;                  // D2H of this lane's results: the context's own stream (idle once a batch is done;
-                                               // every stream less is ~5 ms less of a cold call)
-  int32_t* d_scores = nullptr; size_t scores_cap = 0;
+  hipStream_t down = nullptr;                  // D2H of this lane's results, beside the context's stream
+  int32_t* d_scores[2] = {nullptr, nullptr}; size_t scores_cap[2] = {0, 0};      // (alternate like the context's CIGAR buffers)
   struct Out {
     char* text = nullptr; size_t text_cap = 0;
     unsigned long long* off = nullptr; unsigned int* len = nullptr; size_t cig_cap = 0;   // CIGAR calls only
@@ -243,7 +244,8 @@ void release_dev(DevState& d) {
   for (auto& e : d.up_done) (void)hipEventDestroy(e);
   d.up_done.clear();
   for (auto& l : d.lane) {
-    if (l.d_scores) (void)hipFree(l.d_scores);
+    for (auto& ds : l.d_scores) if (ds) (void)hipFree(ds);
+    if (l.down) (void)hipStreamDestroy(l.down);
     for (auto& o : l.out) {
       if (o.text) (void)hipHostFree(o.text);
       if (o.off) (void)hipHostFree(o.off);
@@ -292,7 +294,7 @@ int acquire_dev(int slot, int device, int lanes, int sharers, const wfagpu_amd_l
       c.arena_limit_max_bytes = std::max<size_t>(c.arena_limit_bytes, std::min<size_t>((size_t)32 << 30, share));
     }
     if (wfagpu_amd_create(&l.ctx, &c)) return -1;
-    l.down = static_cast<hipStream_t>(wfagpu_amd_stream(l.ctx));
+    HIP_OK(hipStreamCreateWithFlags(&l.down, hipStreamNonBlocking));
   }
   *out = &d;
   return 0;
@@ -392,7 +394,13 @@ int run_device(const CallArgs& a, Shard& sh) {
   }
 
   Flags fl;
-  std::vector<char> prepped(nb, 0), uploaded(nb, 0), computed(nb, 0), scattered(nb, 0);
+  std::vector<char> prepped(nb, 0), uploaded(nb, 0), computed(nb, 0), downloaded(nb, 0), scattered(nb, 0);
+  // what a computed batch left on the device (valid through the lane's next batch)
+  struct BatchOut { const int32_t* d_scores = nullptr; const char* d_text = nullptr; const unsigned long long* d_off = nullptr;
+                    const unsigned int* d_len = nullptr; unsigned long long text_bytes = 0; };
+  std::vector<BatchOut> bout(nb);
+  struct BatchClock { double up0 = 0, up1 = 0, dev0 = 0, dev1 = 0, d2h1 = 0, sc0 = 0, sc1 = 0; };      // (timing >= 2: ms since the start of the slice)
+  std::vector<BatchClock> clk(nb);
   struct StageTimes { double prep = 0, up = 0, up_wait = 0, dev = 0, dev_wait = 0, d2h = 0, scatter = 0, check = 0; };
   StageTimes t_prep_thread, t_up_thread;
   std::vector<StageTimes> t_lane(K), t_scat(K);
@@ -434,6 +442,7 @@ int run_device(const CallArgs& a, Shard& sh) {
       if (!fl.wait(prepped, i)) return;
       if (!fl.wait(computed, i - R)) return;          // (a ring of slots: the one of batch i - R must have been consumed)
       t_up_thread.up_wait += now_ms() - t0; t0 = now_ms();
+      clk[i].up0 = t0 - t_begin;
       const BatchPlan& b = plan[i];
       const size_t n = b.to - b.from;
       InSlot& in = d.in[i % R];
@@ -465,10 +474,43 @@ int run_device(const CallArgs& a, Shard& sh) {
     int j = 0;
     for (int i = k; i < nb; i += K, ++j) {
       if (!fl.wait(computed, i)) return;
-      const double t0 = now_ms();
+      double t0 = now_ms();
       const BatchPlan& b = plan[i];
       const size_t n = b.to - b.from;
-      const Lane::Out& o = d.lane[k].out[j & 1];
+      Lane& L = d.lane[k];
+      Lane::Out& o = L.out[j & 1];
+      {
+        // results of the batch -> pinned staging, on the lane's copy stream: the lane's context is already running its next batch
+        auto okh = [&](hipError_t e, const char* what) { if (e != hipSuccess) { LOG_ERROR("HIP call %s failed: %s", what, hipGetErrorString(e)); fl.fail(-1); return false; } return true; };
+        const BatchOut& bo = bout[i];
+        if (n > o.n_cap) {
+          const size_t cap = n + n / 8;
+          if (grow_pinned(&o.score, cap)) { fl.fail(-1); return; }
+          o.n_cap = cap;
+        }
+        if (a.cigar && n > o.cig_cap) {
+          const size_t cap = n + n / 8;
+          if (grow_pinned(&o.off, cap) || grow_pinned(&o.len, cap)) { fl.fail(-1); return; }
+          o.cig_cap = cap;
+        }
+        if (!okh(hipMemcpyAsync(o.score, bo.d_scores, n * sizeof(int32_t), hipMemcpyDeviceToHost, L.down), "D2H scores")) return;
+        if (a.cigar) {
+          if (bo.text_bytes + 1 > o.text_cap) {
+            const size_t cap = (size_t)bo.text_bytes + (size_t)bo.text_bytes / 8 + 4096;
+            if (grow_pinned(&o.text, cap)) { fl.fail(-1); return; }
+            o.text_cap = cap;
+          }
+          if (!okh(hipMemcpyAsync(o.off, bo.d_off, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, L.down), "D2H offsets")) return;
+          if (!okh(hipMemcpyAsync(o.len, bo.d_len, n * sizeof(unsigned int), hipMemcpyDeviceToHost, L.down), "D2H lengths")) return;
+          if (bo.text_bytes && !okh(hipMemcpyAsync(o.text, bo.d_text, bo.text_bytes, hipMemcpyDeviceToHost, L.down), "D2H text")) return;
+        }
+        if (!okh(hipStreamSynchronize(L.down), "D2H sync")) return;
+        t_scat[k].d2h += now_ms() - t0;
+        clk[i].d2h1 = now_ms() - t_begin;
+        fl.set(downloaded, i);
+        t0 = now_ms();
+      }
+      clk[i].sc0 = t0 - t_begin;
       std::atomic<int> bad{0};
       // Every cigar.buffer stays the caller's own, individually free()-able allocation (the ABI: lib/alignment_results.c).
       // One that is too small grows to the longest text of the batch, so that the following calls of a process (same
@@ -499,6 +541,7 @@ int run_device(const CallArgs& a, Shard& sh) {
       t_scat[k].scatter += now_ms() - t0;
       if (bad.load()) { fl.fail(-1); return; }
       if (a.check) { const double t1 = now_ms(); check_batch(a, b.from, b.to, i, lane_threads); t_scat[k].check += now_ms() - t1; }
+      clk[i].sc1 = now_ms() - t_begin;
       fl.set(scattered, i);
     }
   };
@@ -513,50 +556,31 @@ int run_device(const CallArgs& a, Shard& sh) {
       if (!fl.wait(uploaded, i)) return fl.rc.load();
       HIP_OK(hipEventSynchronize(d.up_done[i]));
       t_lane[k].dev_wait += now_ms() - t0; t0 = now_ms();
+      clk[i].up1 = clk[i].dev0 = t0 - t_begin;
       const BatchPlan& b = plan[i];
       const size_t n = b.to - b.from;
       const InSlot& in = d.in[i % R];
-      if (n > L.scores_cap) {
-        if (L.d_scores) (void)hipFree(L.d_scores);
-        L.d_scores = nullptr; L.scores_cap = n + n / 8;
-        HIP_OK(hipMalloc(&L.d_scores, L.scores_cap * sizeof(int32_t)));
+      int32_t*& d_sc = L.d_scores[j & 1];
+      if (n > L.scores_cap[j & 1]) {
+        if (d_sc) (void)hipFree(d_sc);
+        d_sc = nullptr; L.scores_cap[j & 1] = n + n / 8;
+        HIP_OK(hipMalloc(&d_sc, L.scores_cap[j & 1] * sizeof(int32_t)));
       }
+      // (the output set this batch writes was last used by the lane's batch before last: its download must be over)
+      if (!fl.wait(downloaded, i - 2 * K)) return fl.rc.load();
       wfagpu_amd_batch_t wb{};
       wb.d_sequences = reinterpret_cast<const char*>(reinterpret_cast<uintptr_t>(in.d_seq) - b.lo);     // [offset of the caller's buffer]
       wb.sequences_bytes = b.lo + b.span; wb.d_metadata = in.d_meta; wb.num_pairs = n;
       wb.packed_bytes = b.packed_bytes; wb.max_seq_len = b.max_len;
-      const char* d_text = nullptr; const unsigned long long* d_off = nullptr; const unsigned int* d_len = nullptr;
+      BatchOut& bo = bout[i];
       wfagpu_amd_hint_same_stream(L.ctx, j > 0 ? 1 : 0);     // the batches of a call come from one stream of reads
       const int arc = wfagpu_amd_align_device(L.ctx, &wb, a.opt.penalties, a.opt.max_error, a.opt.band, a.opt.threads_per_block, a.cigar,
-                                              L.d_scores, &d_text, &d_off, &d_len);
+                                              d_sc, &bo.d_text, &bo.d_off, &bo.d_len);
       if (arc) return arc;
-      t_lane[k].dev += now_ms() - t0; t0 = now_ms();
-      if (!fl.wait(scattered, i - 2 * K)) return fl.rc.load();   // staging j % 2 is free once this lane's batch j-2 has been scattered
-      Lane::Out& o = L.out[j & 1];
-      if (n > o.n_cap) {
-        const size_t cap = n + n / 8;
-        if (grow_pinned(&o.score, cap)) return -1;
-        o.n_cap = cap;
-      }
-      if (a.cigar && n > o.cig_cap) {
-        const size_t cap = n + n / 8;
-        if (grow_pinned(&o.off, cap) || grow_pinned(&o.len, cap)) return -1;
-        o.cig_cap = cap;
-      }
-      HIP_OK(hipMemcpyAsync(o.score, L.d_scores, n * sizeof(int32_t), hipMemcpyDeviceToHost, L.down));
-      if (a.cigar) {
-        wfagpu_amd_stats_t stt; wfagpu_amd_last_stats(L.ctx, &stt);
-        if (stt.text_bytes + 1 > o.text_cap) {
-          const size_t cap = (size_t)stt.text_bytes + (size_t)stt.text_bytes / 8 + 4096;
-          if (grow_pinned(&o.text, cap)) return -1;
-          o.text_cap = cap;
-        }
-        HIP_OK(hipMemcpyAsync(o.off, d_off, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, L.down));
-        HIP_OK(hipMemcpyAsync(o.len, d_len, n * sizeof(unsigned int), hipMemcpyDeviceToHost, L.down));
-        if (stt.text_bytes) HIP_OK(hipMemcpyAsync(o.text, d_text, stt.text_bytes, hipMemcpyDeviceToHost, L.down));
-      }
-      HIP_OK(hipStreamSynchronize(L.down));
-      t_lane[k].d2h += now_ms() - t0;
+      bo.d_scores = d_sc;
+      if (a.cigar) { wfagpu_amd_stats_t stt; wfagpu_amd_last_stats(L.ctx, &stt); bo.text_bytes = stt.text_bytes; }
+      t_lane[k].dev += now_ms() - t0;
+      clk[i].dev1 = now_ms() - t_begin;
       fl.set(computed, i);
     }
     return 0;
@@ -576,7 +600,7 @@ int run_device(const CallArgs& a, Shard& sh) {
   st.acquire_ms = t_created - t_begin;
   st.prep_ms = t_prep_thread.prep; st.upload_ms = t_up_thread.up; st.upload_wait_ms = t_up_thread.up_wait;
   for (int k = 0; k < K; ++k) {
-    st.device_ms += t_lane[k].dev; st.device_wait_ms += t_lane[k].dev_wait; st.d2h_ms += t_lane[k].d2h;
+    st.device_ms += t_lane[k].dev; st.device_wait_ms += t_lane[k].dev_wait; st.d2h_ms += t_scat[k].d2h;
     st.scatter_ms += t_scat[k].scatter; st.check_ms += t_scat[k].check;
   }
   st.lanes = K; st.batches = nb;
@@ -585,6 +609,10 @@ int run_device(const CallArgs& a, Shard& sh) {
             "device %.1f (+%.1f waiting), d2h %.1f, scatter %.1f, check %.1f; total %.1f\n",
             sh.device, sh.slot, nb, K, R, st.acquire_ms, st.prep_ms, st.upload_ms, st.upload_wait_ms, st.device_ms, st.device_wait_ms,
             st.d2h_ms, st.scatter_ms, st.check_ms, st.total_ms);
+  if (a.cfg.timing >= 2)
+    for (int i = 0; i < nb; ++i)
+      fprintf(stderr, "[wfagpu timing]   batch %2d (%zu pairs): upload issued %.2f, landed <= %.2f | device %.2f - %.2f | d2h done %.2f | scatter %.2f - %.2f\n",
+              i, plan[i].to - plan[i].from, clk[i].up0, clk[i].up1, clk[i].dev0, clk[i].dev1, clk[i].d2h1, clk[i].sc0, clk[i].sc1);
   return fl.rc.load();
 }
 

@@ -254,7 +254,10 @@ struct wfagpu_amd_ctx {
   wfagpu_amd_stats_t stats{};
   // budgets learnt from the sample of an earlier batch of the same stream (wfagpu_amd_hint_same_stream)
   bool same_stream = false;
+  // (keyed by the length CLASS of the bucket -- the power of two above its longest pair: the budget is a score per 1024
+  // bases, it carries over between batches whose longest reads differ by a few bases)
   struct SavedQ { unsigned bucket_hi; int q; int x, o, e, max_error; } saved_q[8] = {};
+  static unsigned length_class(unsigned len) { unsigned c = 1; while (c < len && c < (1u << 31)) c <<= 1; return c; }
   int n_saved_q = 0;
 };
 
@@ -873,7 +876,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       if (would_tune && c->same_stream)
         for (int i = 0; i < c->n_saved_q; ++i) {
           const auto& sq = c->saved_q[i];
-          if (sq.bucket_hi == bucket_hi && sq.x == pen.x && sq.o == pen.o && sq.e == pen.e && sq.max_error == max_error) inherited = true;
+          if (sq.bucket_hi == wfagpu_amd_ctx::length_class(bucket_hi) && sq.x == pen.x && sq.o == pen.o && sq.e == pen.e && sq.max_error == max_error) inherited = true;
         }
       unfiltered = !would_tune || inherited;
     }
@@ -918,7 +921,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       if (try_budget && c->same_stream) {
         for (int i = 0; i < c->n_saved_q; ++i) {
           const auto& sq = c->saved_q[i];
-          if (sq.bucket_hi == bucket_hi && sq.x == pen.x && sq.o == pen.o && sq.e == pen.e && sq.max_error == max_error) saved_idx = i;
+          if (sq.bucket_hi == wfagpu_amd_ctx::length_class(bucket_hi) && sq.x == pen.x && sq.o == pen.o && sq.e == pen.e && sq.max_error == max_error) saved_idx = i;
         }
       }
       if (try_budget && saved_idx >= 0) {
@@ -982,9 +985,9 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
           c->stats.auto_budget = budget_cap;
           // remember it for later batches of the same stream
           int slot = -1;
-          for (int i = 0; i < c->n_saved_q; ++i) if (c->saved_q[i].bucket_hi == bucket_hi) slot = i;
+          for (int i = 0; i < c->n_saved_q; ++i) if (c->saved_q[i].bucket_hi == wfagpu_amd_ctx::length_class(bucket_hi)) slot = i;
           if (slot < 0 && c->n_saved_q < 8) slot = c->n_saved_q++;
-          if (slot >= 0) c->saved_q[slot] = {bucket_hi, q, pen.x, pen.o, pen.e, max_error};
+          if (slot >= 0) c->saved_q[slot] = {wfagpu_amd_ctx::length_class(bucket_hi), q, pen.x, pen.o, pen.e, max_error};
         }
         if (sample_again) {
           // the sampled pairs go through the bucket's run like everybody else

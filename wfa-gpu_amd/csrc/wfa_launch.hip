@@ -573,7 +573,10 @@ int run_device(const CallArgs& a, Shard& sh) {
       wb.sequences_bytes = b.lo + b.span; wb.d_metadata = in.d_meta; wb.num_pairs = n;
       wb.packed_bytes = b.packed_bytes; wb.max_seq_len = b.max_len;
       BatchOut& bo = bout[i];
-      wfagpu_amd_hint_same_stream(L.ctx, j > 0 ? 1 : 0);     // the batches of a call come from one stream of reads
+      // The batches of a call come from one stream of reads -- and so, as far as the budgets go, do the calls of a process:
+      // the budgets a lane learnt from a sample stay on trial (same penalties, same max_error, same length bucket; results are
+      // exact either way, and a batch in which more than 5 % of the pairs miss them makes the next one sample again).
+      wfagpu_amd_hint_same_stream(L.ctx, 1);
       const int arc = wfagpu_amd_align_device(L.ctx, &wb, a.opt.penalties, a.opt.max_error, a.opt.band, a.opt.threads_per_block, a.cigar,
                                               d_sc, &bo.d_text, &bo.d_off, &bo.d_len);
       if (arc) return arc;

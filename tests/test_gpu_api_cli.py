@@ -355,3 +355,25 @@ def test_budgets_inherited_across_batches_stay_exact_when_the_stream_drifts():
     lib.wfagpu_amd_set_num_devices(0)
     assert np.array_equal(s, so)
     assert c == co
+
+
+@pytest.mark.parametrize("lanes,pool,batch", [(1, 0, 64), (3, 1 << 16, 50), (2, 1 << 16, 37), (4, 0, 25)])
+def test_launch_pipeline_shapes(golden_dir, lanes, pool, batch):
+    """The launch pipeline in the shapes the defaults never take on a small call: one, three and four compute lanes, and an
+    input pool too small for the call (input_pool_bytes: the slots become a ring and an upload waits for the batch that
+    used its slot) -- results complete, in input order, CIGARs included, twice (cached per-device state)."""
+    lib = wfagpu.load()
+    wfagpu.configure_launch(lanes_per_device=lanes, input_pool_bytes=pool)
+    pairs = wfagpu.read_seq_file(os.path.join(golden_dir, "seq1k.seq"))[:433]
+    buf, meta = wfagpu.layout_pairs(pairs)
+    so, co, _ = oracle_lib.oracle_batch(buf, meta, (2, 3, 1), cigar=True, nthreads=8)
+    for cigar in (True, False, True):
+        s, c = _api_align(pairs, (2, 3, 1), cigar=cigar, batch=batch)
+        assert np.array_equal(s, np.asarray(so))
+        if cigar:
+            assert c == co
+    st = wfagpu.last_launch_stats()
+    nb = (len(pairs) + batch - 1) // batch
+    assert st["lanes"] == min(lanes, nb) and st["batches"] == nb
+    wfagpu.configure_launch()
+    lib.wfagpu_amd_release_cache()

@@ -471,6 +471,8 @@ int run_device(const CallArgs& a, Shard& sh) {
   // ---- stage 3: staging -> the caller's records (+ -c), one thread per lane --------------------------------------------
   const unsigned lane_threads = std::max(1u, sh.host_threads / (unsigned)K);
   auto scatter_lane = [&](int k) {
+    // (this thread issues the D2H copies of its lane: every thread that talks to HIP selects the slice's device first)
+    if (hipSetDevice(sh.device) != hipSuccess) { fl.fail(-1); return; }
     int j = 0;
     for (int i = k; i < nb; i += K, ++j) {
       if (!fl.wait(computed, i)) return;

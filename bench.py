@@ -229,6 +229,7 @@ def main():
     ap.add_argument("--mode", default="ranks", choices=["ranks", "library"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-to-host", action="store_true")
+    ap.add_argument("--no-inherit-budgets", action="store_true", help="sample the score budgets again in every step")
     ap.add_argument("--force-band", action="store_true", help="banded workloads: always run the banded kernels (tuning.force_band)")
     ap.add_argument("--tuning", action="append", default=[], metavar="KEY=INT",
                     help="wfagpu_amd_tuning_t field for A/B runs (waves_per_simd=7, max_blocks_per_cu=24, ...)")
@@ -293,6 +294,12 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # The steps of a run are batches of one stream of reads: like launch_alignments* does for the batches of a call, the
+    # score budgets tuned on a sample during the warm-up are tried again without sampling (results stay exact: a pair that
+    # misses its budget is re-run, and the parity sample below is taken from the last timed step).
+    inherit = args.warmup > 0 and not args.no_inherit_budgets
+    if inherit:
+        al.hint_same_stream(True)
     for k in acc:
         acc[k] = 0
     elapsed = shardlib.timed_steps(step, steps, 0, dist=dist, sync=torch.cuda.synchronize, device="cuda")
@@ -365,6 +372,8 @@ def main():
             "config": {"workload": f"{args.workload}: {wl['desc']}", "pairs_per_gpu_per_step": n_pairs, "length": wl["length"],
                        "error": wl["error"], "penalties": "x=2,o=3,e=1", "max_error": max_error,
                        "compute_cigar": wl["cigar"],
+                       "budgets": "tuned on a sample in the warm-up, inherited by the timed steps (same stream of reads)" if inherit
+                                  else "tuned on a sample in every step",
                        "band": {"period": band[0], "width": band[1], "forced": bool(args.force_band),
                                 "policy": "the band is used only where the sampled score budgets leave the exact wavefronts wider "
                                           "than 2.5 bands (tiers.pairs_banded counts the pairs it finished)"} if band else None,

@@ -317,6 +317,13 @@ class DeviceAligner:
         if self.lib.wfagpu_amd_create(C.byref(self.ctx), C.byref(cfg)) != 0:
             raise RuntimeError("wfagpu_amd_create failed")
 
+    def hint_same_stream(self, on=True):
+        """The following batches come from the same stream of reads as the last one: score budgets learnt from a sample are
+        tried again without sampling (results stay exact; see wfagpu_amd_hint_same_stream)."""
+        self.lib.wfagpu_amd_hint_same_stream.argtypes = [C.c_void_p, C.c_int]
+        self.lib.wfagpu_amd_hint_same_stream.restype = None
+        self.lib.wfagpu_amd_hint_same_stream(self.ctx, 1 if on else 0)
+
     def set_tuning(self, **tuning):
         """Replace the context's tuning switches (no arguments: the defaults)."""
         t = Tuning(**tuning)

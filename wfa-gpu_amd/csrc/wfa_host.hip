@@ -635,7 +635,9 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         TierPlan tp;
         ap.budget = budget_round ? budgets : nullptr;
         // banded first attempt (packed class only); whatever it cannot finish goes to the exact tiers
-        ap.band_width = (want_band && allow_band && !raw && round == 0 && !budgets) ? band_width : 0;
+        // (with tuned budgets the band keeps them: the reach interval of a tight budget makes the banded wavefront shrink
+        // towards the end like the exact one; a pair whose banded score exceeds its budget is re-run exactly like any miss)
+        ap.band_width = (want_band && allow_band && !raw && round == 0) ? band_width : 0;
         ap.band_period = band;
         if (ap.band_width > 0 && !plan_tier(c, ap, std::min(max_score, 30000), max_len, cigar_now, raw, &tp)) ap.band_width = 0;
         L.banded = ap.band_width > 0;
@@ -676,10 +678,10 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         ++n_links; ++round;
         // what the failures of this round run with next
         cur = nxt; cur_len_dev = ct + L.ct_list;      // (n_cur stays as the upper bound until the chain's synchronisation)
-        if (L.banded) {
+        if (budget_round) {
+          budget_round = false; max_score = max_error;      // auto-budget misses (banded or not): the caller's budget, exact tiers
+        } else if (L.banded) {
           // banded misses: exact tiers from the start
-        } else if (budget_round) {
-          budget_round = false; max_score = max_error;      // auto-budget misses: the caller's budget
         } else {
           // widen: 4x the score budget (and with it the diagonal window); beyond what 16-bit offsets
           // allow the last resort is the unbounded 32-bit tier
@@ -690,6 +692,8 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         // the re-run of budget misses follows without a round trip; every other escalation waits for the counts
         if (!(L.budgeted && n_links == 1)) break;
       }
+      // (whatever the budget, no optimal alignment costs more than mismatching the shorter sequence and one gap for the rest)
+      s_hi = std::min<long long>(s_hi, (long long)pen.x * max_len + oe + (long long)pen.e * max_len);
       // ---- backtrace + CIGAR for everything of the chain's list that finished -----------------------------------------
       if (zero_counter(c, CT_SUM_OPS, 2)) return -1;
       if (zero_counter(c, CT_OPS)) return -1;
@@ -870,7 +874,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
     // synchronisation).
     bool unfiltered = false;
     if (!raw && bucket_lo == 0 && bucket_hi >= batch_max_len) {
-      const bool would_tune = (!want_band || !c->tuning.force_band) && n >= 8192 && !c->tuning.no_auto_budget &&
+      const bool would_tune = n >= 8192 && !c->tuning.no_auto_budget &&
                               window_width(max_error, pen.o, pen.e, bucket_hi) > 128;
       bool inherited = false;
       if (would_tune && c->same_stream)
@@ -910,12 +914,8 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       // saves a whole 64-lane chunk).
       constexpr double budget_q = 0.99;
       constexpr int budget_margin = 100, budget_slack = 2;
-      // With a band requested the sample still runs (exactly): if the budgets it yields make the exact wavefronts no
-      // wider than 2.5 bands, the exact search is at least as fast as the band (16k x 10 kbp @ 3 %, window 1017: 20.3 ms
-      // exact against 24.8 ms with beta 512 and 18.8 ms with beta 352) and the band -- a permission to approximate, not an obligation -- is not used
-      // for this bucket; tuning.force_band keeps it.
-      const bool band_optional = want_band && !c->tuning.force_band;
-      const bool try_budget = !raw && (!want_band || band_optional) && n_pending >= 8192 && !c->tuning.no_auto_budget &&
+      // (with a band requested the sample still runs, exactly: the budgets serve the banded kernels too -- see the band policy below)
+      const bool try_budget = !raw && n_pending >= 8192 && !c->tuning.no_auto_budget &&
                               window_width(max_error, pen.o, pen.e, max_len) > 128;
       int saved_idx = -1;
       if (try_budget && c->same_stream) {
@@ -1003,12 +1003,14 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
           HIP_TRY(hipMemcpyAsync(pending, rest, (size_t)4 * n_pending, hipMemcpyDeviceToDevice, st));
         }
       }
-      if (want_band && budgets && 2 * window_width(budget_cap, pen.o, pen.e, max_len) > 5 * band_width) {
-        budgets = nullptr; budget_cap = max_error;       // wide wavefronts: the band is worth having
-        c->stats.auto_budget = 0;
-      }
+      // Band policy: the band is a permission to approximate, not an obligation.  Where the tuned budgets leave the exact
+      // wavefronts no wider than 2.5 bands the exact search costs about what the band does and every result is optimal: the
+      // band is not used for the bucket (tuning.force_band keeps it).  Otherwise, and in batches too small to tune, the
+      // banded kernels run -- with the budgets, where there are any.
+      const bool use_band = want_band && (!budgets || c->tuning.force_band ||
+                                          2 * window_width(budget_cap, pen.o, pen.e, max_len) > 5 * band_width);
       const unsigned missed_before = c->stats.pairs_budget_missed;
-      if (n_pending && run_list(pending, n_pending, raw, budgets, budget_cap, static_cast<uint32_t*>(c->list_d.p), bucket_list)) return -1;
+      if (n_pending && run_list(pending, n_pending, raw, budgets, budget_cap, static_cast<uint32_t*>(c->list_d.p), bucket_list, use_band)) return -1;
       if (saved_idx >= 0 && (c->stats.pairs_budget_missed - missed_before) * 20u > n_pending) {
         // more than 5 % of the batch missed the inherited budgets: the stream has drifted, sample again next time
         c->saved_q[saved_idx] = c->saved_q[--c->n_saved_q];

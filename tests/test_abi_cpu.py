@@ -123,3 +123,23 @@ def test_reference_examples_compile_unchanged(lib, src, cc):
     subprocess.run([cc, f"/root/reference/examples/{src}", "-o", exe, f"-I{pkg}/lib", f"-I{pkg}", f"-L{pkg}",
                     "-lwfagpu", f"-Wl,-rpath,{pkg}"], check=True)
     assert os.path.exists(exe)
+
+
+def test_device_header_structs_match_the_python_mirrors():
+    """include/wfa_gpu_device.h as the C compiler sees it against the ctypes mirrors in bindings/wfagpu.py: a field added on
+    one side only would shift everything behind it (tuning switches, launch configuration, stage times, statistics)."""
+    src = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "wfa_gpu_device.h"
+int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n",sizeof(wfagpu_amd_tuning_t),sizeof(wfagpu_amd_config_t),
+ offsetof(wfagpu_amd_config_t,tuning),sizeof(wfagpu_amd_launch_config_t),offsetof(wfagpu_amd_launch_config_t,tuning),
+ sizeof(wfagpu_amd_launch_stats_t),offsetof(wfagpu_amd_launch_stats_t,devices),sizeof(wfagpu_amd_stats_t),
+ offsetof(wfagpu_amd_stats_t,main_launch_ms),sizeof(wfagpu_amd_batch_t));return 0;}'''
+    exe = "/tmp/wfagpu_device_abi_probe"
+    subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe], input=src.encode(), check=True)
+    out = [int(v) for v in subprocess.run([exe], capture_output=True, check=True).stdout.split()]
+    assert out == [C.sizeof(wfagpu.Tuning), C.sizeof(wfagpu.Config), wfagpu.Config.tuning.offset,
+                   C.sizeof(wfagpu.LaunchConfig), wfagpu.LaunchConfig.tuning.offset,
+                   C.sizeof(wfagpu.LaunchStats), wfagpu.LaunchStats.devices.offset, C.sizeof(wfagpu.Stats),
+                   wfagpu.Stats.main_launch_ms.offset, C.sizeof(wfagpu.Batch)]

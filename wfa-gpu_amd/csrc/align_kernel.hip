@@ -38,7 +38,14 @@
 //     kernel is bound by; the lean loop exists to issue fewer instructions per cell and per score.
 //   * NW == 1: no barrier anywhere in the score loop (LDS operations of one wavefront execute in
 //     order) and the per-score bookkeeping lives in three VGPRs indexed by lane (v_readlane), not in
-//     memory; the kernel is compiled for 8 waves per SIMD.  NW > 1: one barrier per score.
+//     memory; the exact one-wave kernels exist compiled for 8, 7, 6 and 4 waves per SIMD (WPE) and the host
+//     picks the one that matches the rings LDS lets a CU hold.  NW > 1: one barrier per score.
+//   * Score loops: the careful one; the closed-form lean loop (exact LDS tiers, e == 1); the general lean loop
+//     (LDS tiers, any gap extension, and the adaptive band); one lean loop for the tiers whose ring lives in
+//     HBM.  They share the cells, refill_arena (the one place arena space is claimed) and band_cut.
+//   * Adaptive band (BANDED): a row holds band_width diagonals, stored relative to its own lower limit
+//     between two NULL guard zones -- per-row scalar offsets on the row addresses, the same cells and loops
+//     as the exact search; the band moves by at most two diagonals per score.
 //   * extend(): two 32-bit LDS words per sequence, v_alignbit_b32 to the base position, XOR,
 //     count-trailing-zeros: 16 bases per iteration (4 bytes in the byte-compare instantiation).
 //   * For CIGARs each cell emits ONE origin byte (64 consecutive bytes per wavefront store) into a

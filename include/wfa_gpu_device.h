@@ -71,7 +71,8 @@ typedef struct {
     unsigned long long cells;          /* wavefront cells computed (sum of widths)        */
     unsigned long long arena_units;    /* 16-byte units of backtrace arena used           */
     unsigned long long text_bytes;     /* CIGAR text bytes produced                       */
-    unsigned int pairs_tier[5];        /* pairs finished per kernel tier (0: 1 wave, 1: 4 waves, 2: 16 waves, 3: HBM ring, 4: hybrid ring) */
+    unsigned int pairs_tier[6];        /* pairs finished per kernel tier (0: 1 wave, 1: 4 waves, 2: 16 waves, 3: HBM ring, 4: hybrid ring,
+                                          5: short wavefronts -- several alignments per wave, score-only)                      */
     unsigned int pairs_retried;        /* pairs that needed a wider tier                  */
     unsigned int pairs_raw;            /* pairs with bytes outside ACGT (byte-compare kernels) */
     unsigned int pairs_banded;         /* pairs finished by the adaptive-band kernels          */

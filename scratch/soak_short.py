@@ -1,0 +1,42 @@
+"""Soak of the short-wavefront tier (tier 5): random short pairs, score-only, penalty sets the tier is compiled for, budgets
+small enough for 16- and 32-lane groups, batches above and below the budget-tuning threshold; every score against the checker.
+  python scratch/soak_short.py <seed> <iterations>"""
+import os, random, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "wfa-gpu_amd", "bindings"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+import numpy as np, wfagpu, oracle_lib
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+rng = random.Random(seed)
+al = wfagpu.DeviceAligner(0)
+bad = 0; used = 0; t0 = time.time()
+def rand_pair(maxlen, err):
+    t = bytes(rng.choice(b"ACGT") for _ in range(rng.randint(0, maxlen)))
+    p = bytearray(t)
+    for _ in range(int(len(t) * err) + rng.randint(0, 2)):
+        op = rng.randint(0, 2)
+        if op == 0 and p: p[rng.randrange(len(p))] = rng.choice(b"ACGT")
+        elif op == 1 and p: a = rng.randrange(len(p)); del p[a:a + rng.randint(1, 6)]
+        else: a = rng.randint(0, len(p)); p[a:a] = bytes(rng.choice(b"ACGT") for _ in range(rng.randint(1, 6)))
+    return (bytes(p), t) if rng.random() < 0.5 else (t, bytes(p))
+for it in range(iters):
+    pen = rng.choice([(2, 3, 1), (4, 6, 2), (1, 2, 1), (6, 9, 3), (3, 6, 3)])
+    n = rng.choice([64, 500, 9000, 12000])
+    maxlen = rng.choice([30, 150, 300, 600])
+    err = rng.choice([0.0, 0.01, 0.03, 0.08])
+    base = [rand_pair(maxlen, err) for _ in range(min(n, 600))]
+    pairs = [base[i % len(base)] for i in range(n)]
+    pairs[0] = (b"", b""); pairs[1] = (b"A", b""); pairs[2] = (b"ACGT" * 10, b"ACGT" * 10)
+    buf, meta = wfagpu.layout_pairs(pairs)
+    so, _, _ = oracle_lib.oracle_batch(buf, meta, pen, cigar=False, nthreads=16)
+    batch = al.upload(buf, meta)
+    g = {(2, 3, 1): 1, (4, 6, 2): 2, (1, 2, 1): 1, (6, 9, 3): 3, (3, 6, 3): 3}[pen]
+    for me in (rng.choice([3, 8, 14]) * g, rng.choice([20, 30, 45]) * g, 2000):
+        s, _ = al.align(batch, pen, max_error=me, compute_cigar=False)
+        used += al.stats().pairs_tier[5]
+        if not np.array_equal(s, so):
+            bad += 1
+            k = int(np.nonzero(s != so)[0][0])
+            print("MISMATCH it", it, "pen", pen, "max_error", me, "n", n, "pair", k, pairs[k], int(s[k]), int(so[k]), flush=True)
+print("short-tier soak seed", seed, "iterations", iters, "mismatching runs", bad, "pairs finished in tier 5:", used, "%.1f s" % (time.time() - t0))
+sys.exit(1 if bad else 0)

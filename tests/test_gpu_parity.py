@@ -679,3 +679,42 @@ def test_fallback_backtrace_paths(trace_mode):
         assert np.array_equal(s, so) and cg == co
     finally:
         al.close()
+
+
+@pytest.mark.parametrize("pen,expect_short", [((2, 3, 1), True), ((4, 6, 2), True), ((1, 2, 1), True), ((5, 3, 2), False)])
+def test_short_wavefront_tier_scores(pen, expect_short):
+    """Score-only batches of short reads run on tier 5 (short_kernel.hip: four or two alignments per wavefront, rings in
+    registers, neighbours by DPP row shifts) once their budgets are tuned: 20k x 150 bp pairs at 2 %, with every 200th pair at
+    12 % (below the 99th percentile the budgets come from: it misses its budget and is re-run in the ordinary tiers), pairs whose lengths differ so much that their diagonal window does
+    not fit a group (BAND failure -> ordinary tiers), empty and one-base sequences.  Every score equals the checker's; penalty
+    sets the tier is not compiled for take the ordinary path."""
+    n = 20000
+    buf, meta = wfagpu.generate_pairs(n, 150, 0.02, seed=515)
+    hard, mh = wfagpu.generate_pairs(n // 200 + 1, 150, 0.12, seed=516)
+    pairs = wfagpu.pairs_from_layout(buf, meta)
+    ph = wfagpu.pairs_from_layout(hard, mh)
+    for j, i in enumerate(range(3, n, 200)):      # (odd positions: the strided sample of the budget tuning never draws one)
+        pairs[i] = ph[j]
+    rng = random.Random(517)
+    for i in range(7, n, 400):          # lengths far apart: |kend| beyond any 32-lane window
+        t = bytes(rng.choice(b"ACGT") for _ in range(150))
+        pairs[i] = (t[:rng.randint(20, 90)], t)
+    pairs[11] = (b"", b"ACGT"); pairs[12] = (b"A", b"A"); pairs[13] = (b"", b""); pairs[14] = (b"ACGTACGT", b"")
+    buf, meta = wfagpu.layout_pairs(pairs)
+    so, _, _ = oracle_lib.oracle_batch(buf, meta, pen, cigar=False, nthreads=16)
+    al = wfagpu.DeviceAligner(0)
+    try:
+        batch = al.upload(buf, meta)
+        for max_error in (45 * max(1, pen[0] // 2), 400):
+            s, _ = al.align(batch, pen, max_error=max_error, compute_cigar=False)
+            st = al.stats()
+            assert np.array_equal(s, so), (pen, max_error)
+            if expect_short:
+                assert st.pairs_tier[5] > n * 0.9 and st.pairs_retried > 100, list(st.pairs_tier)
+            else:
+                assert st.pairs_tier[5] == 0
+        # and with CIGARs (tier 5 is score-only: the ordinary tiers), same scores
+        s2, c2 = al.align(batch, pen, max_error=400, compute_cigar=True)
+        assert np.array_equal(s2, so) and al.stats().pairs_tier[5] == 0
+    finally:
+        al.close()

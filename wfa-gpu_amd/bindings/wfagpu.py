@@ -75,7 +75,7 @@ class Batch(C.Structure):  # wfagpu_amd_batch_t
 class Stats(C.Structure):  # wfagpu_amd_stats_t
     _fields_ = [("pack_ms", C.c_float), ("align_ms", C.c_float), ("trace_ms", C.c_float), ("total_ms", C.c_float),
                 ("align_launches", C.c_int), ("cells", C.c_ulonglong), ("arena_units", C.c_ulonglong),
-                ("text_bytes", C.c_ulonglong), ("pairs_tier", C.c_uint * 5), ("pairs_retried", C.c_uint), ("pairs_raw", C.c_uint), ("pairs_banded", C.c_uint), ("pairs_budget_missed", C.c_uint), ("auto_budget", C.c_int),
+                ("text_bytes", C.c_ulonglong), ("pairs_tier", C.c_uint * 6), ("pairs_retried", C.c_uint), ("pairs_raw", C.c_uint), ("pairs_banded", C.c_uint), ("pairs_budget_missed", C.c_uint), ("auto_budget", C.c_int),
                 ("sub_batches", C.c_uint), ("lds_bytes_tier0", C.c_size_t), ("blocks_per_cu_tier0", C.c_int),
                 ("main_launch_ms", C.c_float), ("main_launch_tier", C.c_int), ("main_launch_pairs", C.c_uint),
                 ("main_launch_cells", C.c_ulonglong), ("main_launch_seq_bytes", C.c_ulonglong),

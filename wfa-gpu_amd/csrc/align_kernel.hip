@@ -224,10 +224,17 @@ wfa_align_kernel(const WfaAlignParams p) {
       while (shards_left) {
         const uint32_t lo_w = (uint32_t)(((unsigned long long)n_work * shard) / nsh);
         const uint32_t hi_w = (uint32_t)(((unsigned long long)n_work * (shard + 1)) / nsh);
-        uint32_t c = 0;
-        if (tid == 0) c = atomicAdd(cp->work_counter + shard * 16, 1u);
-        c = block_bcast<NW>(c, bslot);
-        if (c < hi_w - lo_w) { w = lo_w + c; break; }
+        // (a claim is a returning atomic on one word, ~88 per microsecond: an EMPTY shard -- the speculative re-run launch of a
+        // chain mostly finds nothing at all -- is skipped without one: 8192 workgroups x 8 shards of atomics were 0.17 ms of an
+        // empty launch.  Looking at the counter with a plain load before every claim was tried too: it costs the full launch
+        // of BASELINE configs[2] 2.6 %, a round trip per pair.)
+        const uint32_t size_w = hi_w - lo_w;
+        if (size_w != 0u) {
+          uint32_t c = 0;
+          if (tid == 0) c = atomicAdd(cp->work_counter + shard * 16, 1u);
+          c = block_bcast<NW>(c, bslot);
+          if (c < size_w) { w = lo_w + c; break; }
+        }
         shard = (shard + 1) & (nsh - 1u); --shards_left;
       }
     }

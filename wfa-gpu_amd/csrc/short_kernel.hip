@@ -1,0 +1,195 @@
+// Score-only gap-affine WFA for SHORT wavefronts: several alignments per 64-lane wavefront, rings in registers.
+//
+// The one-wave tier of align_kernel.hip gives every alignment a whole wavefront: at BASELINE configs[1] (150 bp reads at
+// 2 % error: optimal scores of 2..12, a score budget of ~14 once it is tuned) a wavefront row is 5..13 diagonals wide, so
+// 80 % of the lanes carry nothing and the per-score bookkeeping -- as many instructions as a 64-diagonal chunk of cells --
+// is paid per alignment.  Here a group of L = 16 (or 32) lanes is one alignment, lane j of the group is diagonal wlo + j for
+// the WHOLE alignment (the exact diagonal window of the pair's score budget must fit the group: the same window argument as
+// in align_kernel.hip), and the wavefront history a cell needs -- M of the last max(x, o+e) scores, I and D of the last
+// one (e == 1) -- lives in registers of the lane itself: M[s-x][k] is a register, M[s-o-e][k-1], I[s-1][k-1],
+// M[s-o-e][k+1], D[s-1][k+1] are DPP row shifts (v_mov_b32_dpp row_shr:1 / row_shl:1: a "row" of the DPP network is 16
+// lanes = one group; the lanes a shift cannot feed keep NULL) of the neighbours' registers.  No LDS ring, no row limits, no
+// ring invariant, no barrier; LDS only holds the packed sequences of the G = 64 / L pairs for the extend.  The score loop is
+// unrolled over the ring depth so that every register index is a compile-time constant.
+//
+// Replaces, for such batches, the reference's distance_kernel (lib/kernels/sequence_distance_kernel.cu:175-425).  Results:
+// the optimal gap-affine score (wavefront_compute_affine.c:45-87 recurrences, out-of-range values are NULL,
+// termination M[s][tlen - plen] >= tlen: wavefront_extend.c:47-67) -- a score does not depend on tie-breaks or on which
+// cells outside the window are computed.  Pairs whose window does not fit a group (status BAND) or whose score exceeds
+// the budget (status SCORE) go on to the ordinary tiers on the device like the failures of any tier.
+#include "wfa_device.h"
+
+namespace {
+
+constexpr int S_NULL = -(1 << 28);
+
+// value of the lane one diagonal below (k - 1) / above (k + 1) within the group; lanes without such a neighbour get NULL
+template <int L> __device__ __forceinline__ int from_below(int v, int j) {
+  if constexpr (L == 16) return __builtin_amdgcn_update_dpp(S_NULL, v, 0x111 /* row_shr:1 */, 0xF, 0xF, false);
+  else { const int r = __shfl_up(v, 1, L); return j == 0 ? S_NULL : r; }
+}
+template <int L> __device__ __forceinline__ int from_above(int v, int j) {
+  if constexpr (L == 16) return __builtin_amdgcn_update_dpp(S_NULL, v, 0x101 /* row_shl:1 */, 0xF, 0xF, false);
+  else { const int r = __shfl_down(v, 1, L); return j == L - 1 ? S_NULL : r; }
+}
+
+// X = mismatch, OE = gap open + extend; gap extend is 1.  L lanes per alignment.
+template <int L, int X, int OE>
+__global__ void __launch_bounds__(64) wfa_short_score_kernel(const WfaAlignParams p) {
+  static_assert(X >= 1 && X <= 4 && OE >= 1 && OE <= 4, "history of four scores");
+  extern __shared__ __attribute__((aligned(16))) uint32_t slds[];
+  constexpr int G = 64 / L;
+  const int lane = threadIdx.x & 63, grp = lane / L, j = lane % L;
+  const int cap = p.seq_words_cap;
+  uint32_t* const Pw = slds + (size_t)grp * 2 * cap;
+  uint32_t* const Tw = Pw + cap;
+  uint32_t n_work = p.n_work;
+  if (p.n_work_dev) n_work = min(n_work, (uint32_t)*p.n_work_dev);
+  const unsigned long long grp_mask = (L == 64) ? ~0ull : (((1ull << L) - 1ull) << (grp * L));
+  unsigned long long blk_cells = 0;
+
+  for (uint32_t base = blockIdx.x * G; base < n_work; base += gridDim.x * G) {
+    const uint32_t w = base + grp;
+    bool active = w < n_work;
+    uint32_t pair = 0;
+    if (active) pair = p.work ? p.work[w] : w;
+    if (active && p.only_pending && p.status[pair] != WFA_ST_PENDING) active = false;
+    int plen = 0, tlen = 0;
+    const uint32_t* gp = nullptr; const uint32_t* gt = nullptr;
+    if (active) {
+      const WfaSeqPair mp = p.meta[pair];
+      plen = (int)mp.pattern_len; tlen = (int)mp.text_len;
+      gp = p.packed + (mp.pattern_offset_packed >> 2);
+      gt = p.packed + (mp.text_offset_packed >> 2);
+    }
+    const int kend = tlen - plen;
+    const int pwords = ((plen + 15) >> 4) + 1, twords = ((tlen + 15) >> 4) + 1;
+    // the pair's score budget and the diagonal window that can hold an alignment within it (align_kernel.hip: a path that
+    // visits diagonal k beyond both 0 and kend pays one gap out and one gap back)
+    int budget = p.max_score;
+    if (active && p.budget) budget = min(budget, p.budget[pair]);
+    {
+      const long long worst = (long long)X * min(plen, tlen) + (kend ? OE + (long long)(abs(kend) - 1) : 0);
+      budget = (int)min((long long)budget, worst);
+    }
+    uint32_t status = WFA_ST_DONE;
+    int wlo = 0;
+    if (active) {
+      const long long S = budget, o = OE - 1;
+      const int ak = kend < 0 ? -kend : kend;
+      const bool feasible = (ak ? o + (long long)ak : 0) <= S;
+      const long long a_hi = S - 2 * o + kend, a_lo = S - 2 * o - kend;
+      const int kmax0 = max(0, kend), kmin0 = min(0, kend);
+      int whi = a_hi >= 0 ? max(kmax0, (int)min((long long)tlen, a_hi / 2)) : kmax0;
+      wlo = a_lo >= 0 ? min(kmin0, -(int)min((long long)plen, a_lo / 2)) : kmin0;
+      whi = min(whi, tlen); wlo = max(wlo, -plen);
+      if (!feasible) status = WFA_ST_SCORE;
+      else if (whi - wlo + 1 > L || pwords > cap || twords > cap) status = WFA_ST_BAND;
+    }
+    const bool run = active && status == WFA_ST_DONE;
+    const int k = wlo + j;                                  // this lane's diagonal, for the whole alignment
+    if (run) {
+      for (int i = j; i < pwords; i += L) Pw[i] = gp[i];
+      for (int i = j; i < twords; i += L) Tw[i] = gt[i];
+    }
+    __builtin_amdgcn_wave_barrier();                        // (one wavefront: LDS operations execute in order)
+
+    // run length from (v, h) on this lane's diagonal, 16 bases per step, wave-uniform continuation
+    auto extend = [&](int h, bool ok) -> int {
+      const int hmax = min(plen + k, tlen);
+      const int v = h - k;
+      int rem = ok ? hmax - h : 0;
+      const uint32_t* pw = Pw + (ok ? (v >> 4) : 0);
+      const uint32_t* tw = Tw + (ok ? (h >> 4) : 0);
+      const uint32_t sa = (uint32_t)v << 1, sb = (uint32_t)h << 1;
+      while (__builtin_amdgcn_ballot_w64(rem > 0) != 0ull) {
+        const uint32_t d = __builtin_amdgcn_alignbit(pw[1], pw[0], sa) ^ __builtin_amdgcn_alignbit(tw[1], tw[0], sb);
+        const int run16 = d ? (__builtin_ctz(d) >> 1) : 16;
+        const int n = min(run16, max(rem, 0));
+        h += n;
+        rem = (n == 16) ? rem - 16 : 0;
+        ++pw; ++tw;
+      }
+      return h;
+    };
+
+    // score 0
+    int m0, m1 = S_NULL, m2 = S_NULL, m3 = S_NULL;          // M of scores with (s & 3) == 0, 1, 2, 3
+    int i1 = S_NULL, d1 = S_NULL;                           // I and D of the last score
+    {
+      const bool mine = run && k == 0;
+      const int h = extend(0, mine);
+      m0 = mine ? h : S_NULL;
+    }
+    bool fin = !run;                                        // this lane's group has its result (or never ran)
+    int score = -1;
+    {
+      const bool hit = run && k == kend && m0 >= tlen;
+      const unsigned long long bal = __builtin_amdgcn_ballot_w64(hit);
+      if (run && (bal & grp_mask) != 0ull) { fin = true; score = 0; }
+    }
+    int s = 0;
+    // one score: R = s & 3 (compile-time), reads M[s - X] and M[s - OE] from their registers
+    auto step = [&](auto rtag, int& m_out, const int m_x, const int m_o) {
+      ++s;
+      const int ins = max(from_below<L>(m_o, j), from_below<L>(i1, j)) + 1;
+      const int del = max(from_above<L>(m_o, j), from_above<L>(d1, j));
+      const int mis = m_x + 1;
+      // !(h > tlen || v > plen), unsigned so that NULLs fail too (wavefront_compute_affine.c:45-87)
+      const bool i_ok = ((unsigned)ins <= (unsigned)tlen) & ((unsigned)(ins - k) <= (unsigned)plen);
+      const bool d_ok = ((unsigned)del <= (unsigned)tlen) & ((unsigned)(del - k) <= (unsigned)plen);
+      i1 = i_ok ? ins : S_NULL;
+      d1 = d_ok ? del : S_NULL;
+      const int mv = max(max(d1, i1), mis);
+      const bool ok = !fin & ((unsigned)mv <= (unsigned)tlen) & ((unsigned)(mv - k) <= (unsigned)plen);
+      const int h = extend(mv, ok);
+      m_out = ok ? h : S_NULL;
+      const bool hit = ok && k == kend && h >= tlen;
+      const unsigned long long bal = __builtin_amdgcn_ballot_w64(hit);
+      if (!fin) {
+        if ((bal & grp_mask) != 0ull) { fin = true; score = s; }
+        else if (s >= budget) { fin = true; status = WFA_ST_SCORE; }     // (the next score would be past the budget)
+      }
+      (void)rtag;
+    };
+    // (s & 3): 1, 2, 3, 0, ...; M[s - X] sits in register (s - X) & 3, M[s - OE] in (s - OE) & 3
+    int* const mr[4] = {&m0, &m1, &m2, &m3};
+    while (__builtin_amdgcn_ballot_w64(!fin) != 0ull) {
+      step(0, *mr[1], *mr[(1 - X) & 3], *mr[(1 - OE) & 3]);
+      if (__builtin_amdgcn_ballot_w64(!fin) == 0ull) break;
+      step(0, *mr[2], *mr[(2 - X) & 3], *mr[(2 - OE) & 3]);
+      if (__builtin_amdgcn_ballot_w64(!fin) == 0ull) break;
+      step(0, *mr[3], *mr[(3 - X) & 3], *mr[(3 - OE) & 3]);
+      if (__builtin_amdgcn_ballot_w64(!fin) == 0ull) break;
+      step(0, *mr[0], *mr[(0 - X) & 3], *mr[(0 - OE) & 3]);
+    }
+    if (active && j == 0) {
+      p.score[pair] = (status == WFA_ST_DONE) ? score : -1;
+      p.status[pair] = status;
+      const uint32_t cells = (status == WFA_ST_DONE) ? (uint32_t)(max(score, 0) + 1) * (uint32_t)L : 0u;
+      if (p.cells) p.cells[pair] = cells;
+      blk_cells += cells;
+    }
+    __builtin_amdgcn_wave_barrier();                        // (the next pairs overwrite the staged sequences)
+  }
+  // cells of this wavefront (the group leaders counted theirs)
+  for (int d = 32; d > 0; d >>= 1) blk_cells += __shfl_down(blk_cells, d);
+  if (lane == 0 && blk_cells && p.launch_cells) atomicAdd(p.launch_cells, blk_cells);
+}
+
+template <int L, int X, int OE>
+void launch_short(const WfaAlignParams& p, int grid, hipStream_t stream) {
+  const size_t lds = (size_t)(64 / L) * 2 * p.seq_words_cap * 4;
+  hipLaunchKernelGGL((wfa_short_score_kernel<L, X, OE>), dim3(grid), dim3(64), lds, stream, p);
+}
+
+}  // namespace
+
+bool wfa_short_supported(int x, int oe, int e) { return e == 1 && ((x == 2 && oe == 4) || (x == 1 && oe == 3)); }
+
+size_t wfa_short_lds_bytes(const WfaAlignParams& p, int lanes) { return (size_t)(64 / lanes) * 2 * p.seq_words_cap * 4; }
+
+void wfa_launch_short(const WfaAlignParams& p, int lanes, int grid, hipStream_t stream) {
+  if (p.x == 2 && p.oe == 4) { if (lanes == 16) launch_short<16, 2, 4>(p, grid, stream); else launch_short<32, 2, 4>(p, grid, stream); }
+  else { if (lanes == 16) launch_short<16, 1, 3>(p, grid, stream); else launch_short<32, 1, 3>(p, grid, stream); }
+}

@@ -140,3 +140,7 @@ size_t wfa_align_lds_bytes(const WfaAlignParams& p, int tier);
 void wfa_launch_align(const WfaAlignParams& p, int tier, bool with_bt, bool raw, int grid, hipStream_t stream, int wpe = 8);
 int wfa_align_max_blocks_per_cu(int tier, bool with_bt, bool raw, bool banded, size_t lds_bytes, int wpe = 8);
 void wfa_launch_trace(const WfaTraceParams& p, hipStream_t stream);
+// Tier 5 (short_kernel.hip): score-only, 64 / lanes alignments per wavefront (lanes = 16 or 32 diagonals each), rings in registers.
+bool wfa_short_supported(int x, int oe, int e);
+size_t wfa_short_lds_bytes(const WfaAlignParams& p, int lanes);
+void wfa_launch_short(const WfaAlignParams& p, int lanes, int grid, hipStream_t stream);

@@ -393,6 +393,19 @@ bool plan_tier(const wfagpu_amd_ctx* c, WfaAlignParams& p, int max_score, unsign
     return true;
   }
   const int width = window_width(max_score, p.oe - p.e, p.e, max_seq_len);
+  // Short wavefronts, score only (tier 5, short_kernel.hip): when the diagonal window of the budget fits 16 or 32 lanes, four or two
+  // alignments share a wavefront and the rings live in registers (BASELINE configs[1]: 150 bp reads, budgets of ~14 once
+  // they are tuned).  Pairs whose own window is wider (large |tlen - plen|) come back as BAND failures and go on as always.
+  if (!bt && !raw && c->tuning.min_tier == 0 && wfa_short_supported(p.x, p.oe, p.e) && width + 1 <= 32 && max_score <= 30000) {
+    const int lanes = width + 1 <= 16 ? 16 : 32;
+    p.rs = 0;
+    const size_t lds = wfa_short_lds_bytes(p, lanes);
+    if (lds <= 40u << 10) {
+      const int nb = (int)std::min<size_t>(32, c->lds_per_block_max / std::max<size_t>(lds, 1));
+      *out = {5, width, max_score, lds, std::max(nb, 1), lanes};      // (wpe carries the lanes per alignment)
+      return true;
+    }
+  }
   // dm guard cells on each side of a row (see the kernel's lean path); the 16-bit LDS tiers add a chunk of padding
   const int rs_plain = (width + 1 + 2 * p.dm + 1) & ~1;
   p.rs = rs_plain + WFA_RING_ROW_PAD;
@@ -659,7 +672,9 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         ap.only_pending = (unfiltered && round == 0) ? 1 : 0;
         ap.launch_cells = ct + L.ct_cells;
         const int bpc_cap = c->tuning.max_blocks_per_cu > 0 ? c->tuning.max_blocks_per_cu : 1 << 20;     // (occupancy experiments)
-        const int grid = (int)std::min<uint32_t>(std::min<uint32_t>(n_cur, grid_cap), (uint32_t)(c->num_cus * std::min(tp.blocks_per_cu, bpc_cap)));
+        // (tier 5: 64 / lanes alignments per wavefront)
+        const uint32_t units = tp.tier == 5 ? cdiv(n_cur, 64u / (uint32_t)tp.wpe) : n_cur;
+        const int grid = (int)std::min<uint32_t>(std::min<uint32_t>(units, grid_cap), (uint32_t)(c->num_cus * std::min(tp.blocks_per_cu, bpc_cap)));
         // arena refill size: as large as lets every workgroup hold a few chunks -- each refill is a
         // returning atomic on ONE word (~88 per microsecond on this chip), which at 4 KiB refills
         // was the whole kernel time
@@ -668,7 +683,8 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         if (zero_counter(c, L.ct_cells, 2)) return -1;   // (the launch's cell count and, next to it, the length of its failure list)
         HIP_TRY(hipMemsetAsync(c->work_ctr.p, 0, 8 * 64, st));
         HIP_TRY(hipEventRecord(L.e0, st));
-        wfa_launch_align(ap, tp.tier, cigar_now, raw, grid, st, tp.wpe);
+        if (tp.tier == 5) wfa_launch_short(ap, tp.wpe, grid, st);
+        else wfa_launch_align(ap, tp.tier, cigar_now, raw, grid, st, tp.wpe);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(L.e1, st));
         uint32_t* nxt = spare[flip]; flip ^= 1;
@@ -874,8 +890,11 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
     // synchronisation).
     bool unfiltered = false;
     if (!raw && bucket_lo == 0 && bucket_hi >= batch_max_len) {
+      const int w_me = window_width(max_error, pen.o, pen.e, bucket_hi);
+      // (tuned budgets pay where they narrow a wide window -- or, score-only, where they bring it down to what the
+      // several-alignments-per-wavefront tier holds)
       const bool would_tune = n >= 8192 && !c->tuning.no_auto_budget &&
-                              window_width(max_error, pen.o, pen.e, bucket_hi) > 128;
+                              (w_me > 128 || (!compute_cigar && w_me > 15 && wfa_short_supported(pen.x, oe, pen.e) && !c->tuning.min_tier));
       bool inherited = false;
       if (would_tune && c->same_stream)
         for (int i = 0; i < c->n_saved_q; ++i) {
@@ -915,8 +934,9 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       constexpr double budget_q = 0.99;
       constexpr int budget_margin = 100, budget_slack = 2;
       // (with a band requested the sample still runs, exactly: the budgets serve the banded kernels too -- see the band policy below)
+      const int w_me2 = window_width(max_error, pen.o, pen.e, max_len);
       const bool try_budget = !raw && n_pending >= 8192 && !c->tuning.no_auto_budget &&
-                              window_width(max_error, pen.o, pen.e, max_len) > 128;
+                              (w_me2 > 128 || (!compute_cigar && w_me2 > 15 && wfa_short_supported(pen.x, oe, pen.e) && !c->tuning.min_tier));
       int saved_idx = -1;
       if (try_budget && c->same_stream) {
         for (int i = 0; i < c->n_saved_q; ++i) {

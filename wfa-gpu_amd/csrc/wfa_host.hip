@@ -674,7 +674,10 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         const int bpc_cap = c->tuning.max_blocks_per_cu > 0 ? c->tuning.max_blocks_per_cu : 1 << 20;     // (occupancy experiments)
         // (tier 5: 64 / lanes alignments per wavefront)
         const uint32_t units = tp.tier == 5 ? cdiv(n_cur, 64u / (uint32_t)tp.wpe) : n_cur;
-        const int grid = (int)std::min<uint32_t>(std::min<uint32_t>(units, grid_cap), (uint32_t)(c->num_cus * std::min(tp.blocks_per_cu, bpc_cap)));
+        int grid = (int)std::min<uint32_t>(std::min<uint32_t>(units, grid_cap), (uint32_t)(c->num_cus * std::min(tp.blocks_per_cu, bpc_cap)));
+        // (a speculative re-run works on a list whose length only the device knows yet -- a percent of the chain's pairs,
+        // usually: every workgroup beyond the work costs a claim atomic per shard)
+        if (cur_len_dev) grid = std::min(grid, (int)std::max<uint32_t>(4u * (uint32_t)c->num_cus, n_cur / 64u));
         // arena refill size: as large as lets every workgroup hold a few chunks -- each refill is a
         // returning atomic on ONE word (~88 per microsecond on this chip), which at 4 KiB refills
         // was the whole kernel time

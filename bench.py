@@ -141,7 +141,7 @@ def cpu_baseline(buf, meta, compute_cigar, budget_pairs):
     return res
 
 
-def host_to_host(buf, meta, wl, max_error, n_devices=1, reps=8, registered=False, tuning=None):
+def host_to_host(buf, meta, wl, max_error, n_devices=1, reps=8, registered=False, tuning=None, launch_cfg=None):
     """The metric as SURVEY.md section 8(d) defines it: N / wall of launch_alignments*() -- pageable host buffers in,
     host results (CIGAR strings scattered into the caller's wfa_alignment_result_t records) out, PCIe both ways.
     First call = cold (contexts, allocations), later calls = warm (per-device state cached by the library; the arena
@@ -160,7 +160,7 @@ def host_to_host(buf, meta, wl, max_error, n_devices=1, reps=8, registered=False
                          band=band[0] if band else -1, batch_size=n, num_alignments=n,
                          penalties=wfagpu.Penalties(*PEN), compute_cigar=wl["cigar"])
     fn = lib.launch_alignments if wl["cigar"] else lib.launch_alignments_distance
-    wfagpu.configure_launch(num_devices=n_devices, tuning=tuning or {})
+    wfagpu.configure_launch(num_devices=n_devices, tuning=tuning or {}, **(launch_cfg or {}))
     meta = meta.copy()
 
     def timed(k):
@@ -227,6 +227,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU per step (default: the workload's)")
     ap.add_argument("--max-error", type=int, default=0)
     ap.add_argument("--mode", default="ranks", choices=["ranks", "library"])
+    ap.add_argument("--h2h-timing", type=int, default=0, help="stage clocks of the host-to-host calls on stderr (1: per call, 2: per batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-to-host", action="store_true")
     ap.add_argument("--no-inherit-budgets", action="store_true", help="sample the score budgets again in every step")
@@ -415,11 +416,18 @@ def main():
     if rank == 0 and world == 1:
         if not args.no_host_to_host:
             try:
-                h2h = host_to_host(buf, meta, wl, max_error, tuning=tuning)
+                h2h = host_to_host(buf, meta, wl, max_error, tuning=tuning, launch_cfg={"timing": args.h2h_timing} if args.h2h_timing else None)
                 out["host_to_host"] = h2h
                 # the reference's own metric (tools/aligner.c:450-474), PCIe inclusive, next to `value` (resident batch)
                 out["host_to_host_value"] = h2h["pageable"]["warm"]
                 out["host_to_host_ms_per_call"] = h2h["pageable"]["warm_ms"]
+                if h2h["stages_ms"].get("host_packed_batches"):
+                    # the call above packed its sequences on the host (a quarter of the bytes over PCIe); the same call
+                    # with the ASCII going up and the pack kernel running, for comparison
+                    asc = host_to_host(buf, meta, wl, max_error, tuning=tuning, reps=4, launch_cfg={"host_pack": -1})
+                    h2h["ascii_upload"] = {"warm_ms": asc["pageable"]["warm_ms"], "best_ms": asc["pageable"]["best_ms"],
+                                           "cold_ms": asc["pageable"]["cold_ms"], "warm": asc["pageable"]["warm"],
+                                           "stages_ms": asc["stages_ms"]}
             except Exception as ex:
                 out["host_to_host"] = {"error": str(ex)}
         if not args.no_cpu_baseline:

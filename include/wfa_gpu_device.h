@@ -57,6 +57,10 @@ typedef struct {
     size_t num_pairs;
     size_t packed_bytes;                 /* value returned by wfagpu_amd_fill_packed_offsets */
     unsigned int max_seq_len;            /* longest pattern/text in the batch            */
+    const void* d_packed;                /* device, optional: the packed_bytes of 2-bit words the metadata's packed offsets
+                                            describe, already packed by the caller (wfagpu_host_pack_sequence; every byte
+                                            of the batch must be one of ACGT).  Then d_sequences is not read (may be NULL)
+                                            and the pack kernel does not run.  NULL: pack on the device.             */
 } wfagpu_amd_batch_t;
 
 typedef struct {
@@ -111,6 +115,11 @@ void wfagpu_amd_set_tuning(wfagpu_amd_ctx_t* ctx, const wfagpu_amd_tuning_t* tun
  * packed bytes the batch needs.  Each sequence gets ceil(len/16)+1 words. */
 size_t wfagpu_amd_fill_packed_offsets(sequence_pair_t* metadata, size_t n);
 
+/* Host helper: packs src[0, len) into dst[0, ceil(len / 16)] -- the words the pack kernel writes for a sequence (code
+ * (c & 6) >> 1, first base in the low bits, a zero word at the end); returns 1 when a byte outside ACGT was seen. */
+int wfagpu_host_pack_sequence(const char* src, uint32_t len, uint32_t* dst);
+int wfagpu_host_pack_sequence_scalar(const char* src, uint32_t len, uint32_t* dst);   /* (the portable path, for tests) */
+
 /* Stage 1 only: 2-bit packing.  d_packed must hold batch->packed_bytes;
  * d_flags (2 bytes per pair: pattern, text) receives 1 where a byte outside
  * ACGT was seen. */
@@ -146,7 +155,8 @@ typedef struct {
     int num_devices;          /* devices a call is sharded over (0: all visible)                                         */
     int virtual_devices;      /* tests: this many shards -- own threads, contexts, streams -- mapped round-robin onto the
                                  physical devices: exercises the multi-device path on one GPU                            */
-    int lanes_per_device;     /* contexts per device working on alternate batches (0: 2 for big calls, else 1)           */
+    int lanes_per_device;     /* contexts per device working on alternate batches (0: 2 for big calls -- 3 when the
+                                 sequences go up packed, see host_pack --, else 1)                                        */
     int batches_per_device;   /* a single huge batch is cut into this many so that the stages overlap (0: 16)            */
     size_t arena_limit_bytes; /* fixed backtrace-arena cap per lane (0: 4 GiB, growing with use)                         */
     size_t input_pool_bytes;  /* device memory for resident input per device (0: a quarter of the free memory, <= 24 GiB) */
@@ -154,6 +164,11 @@ typedef struct {
                                  1: always (test hook for one-GPU boxes), -1: never                                      */
     int timing;               /* 1: print the stage times of every device on stderr; 2: also a clock line per batch       */
     wfagpu_amd_tuning_t tuning;   /* handed to every context the calls create                                            */
+    int host_pack;            /* 2-bit packing on the host, a quarter of the bytes over PCIe (the call is PCIe-bound when it is not
+                                 GPU-bound).  0: when a device's share of the host threads is >= 4 and the call is big,
+                                 1: always, -1: never (ASCII goes up, the pack kernel runs).  A batch holding a byte outside
+                                 ACGT always goes up as ASCII                                                           */
+    int host_pack_threads;    /* threads packing a batch (0: half of a device's share of the host threads, 2..8)         */
 } wfagpu_amd_launch_config_t;
 
 /* NULL: back to the defaults.  Changing `tuning` or `arena_limit_bytes` drops the cached per-device state. */
@@ -175,6 +190,9 @@ typedef struct {
     double check_ms;        /* -c                                                                     */
     int devices, lanes, batches;
     unsigned host_threads;  /* host cores the call could use (affinity mask capped by the cgroup CPU quota) */
+    double host_pack_ms;    /* 2-bit packing on the host (part of prep_ms)                             */
+    int host_packed_batches;/* batches that went up packed                                            */
+    int host_pack_threads;
 } wfagpu_amd_launch_stats_t;
 void wfagpu_amd_last_launch_stats(wfagpu_amd_launch_stats_t* out);
 

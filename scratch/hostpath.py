@@ -6,6 +6,10 @@ import sys
 import time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "wfa-gpu_amd", "bindings"))
 import numpy as np
+if os.environ.get("IMPORT_TORCH"):
+    import torch
+    if os.environ["IMPORT_TORCH"] == "2":
+        torch.zeros(1, device="cuda")
 import wfagpu
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
@@ -18,8 +22,35 @@ lib = wfagpu.load()
 lanes = int(sys.argv[7]) if len(sys.argv) > 7 else 0
 nbatch = int(sys.argv[8]) if len(sys.argv) > 8 else 0
 bpc = int(sys.argv[9]) if len(sys.argv) > 9 else 0
-wfagpu.configure_launch(timing=int(os.environ.get("TIMING", "0")), lanes_per_device=lanes, batches_per_device=nbatch, tuning={"max_blocks_per_cu": bpc})
+wfagpu.configure_launch(timing=int(os.environ.get("TIMING", "0")), lanes_per_device=lanes, batches_per_device=nbatch, tuning={"max_blocks_per_cu": bpc},
+                        host_pack=int(os.environ.get("HOST_PACK", "0")), host_pack_threads=int(os.environ.get("PACK_THREADS", "0")))
 buf, meta = wfagpu.generate_pairs(n, length, err, seed=int(os.environ.get("SEED", "7")), nthreads=16)
+bl = os.environ.get("BENCHLIKE", "")
+if bl and bl[0] in "tmh":
+    import torch
+    if bl[0] == "t":
+        x = torch.empty(buf.nbytes, dtype=torch.uint8, device="cuda"); x.zero_(); torch.cuda.synchronize(); del x
+    elif bl[0] == "m":
+        x = torch.from_numpy(buf).to("cuda"); torch.cuda.synchronize(); del x
+    else:
+        x = torch.empty(buf.nbytes, dtype=torch.uint8, device="cuda")
+        hip = wfagpu._hiprt()
+        assert hip.hipMemcpy(x.data_ptr(), buf.ctypes.data, buf.nbytes, 1) == 0
+        del x
+    torch.cuda.empty_cache()
+elif bl:
+    import torch
+    al = wfagpu.DeviceAligner(0)
+    if "u" in bl:
+        b = al.upload(buf, meta)
+        if "a" in bl:
+            for _ in range(3):
+                al.align(b, (2, 3, 1), max_error=300, compute_cigar=cigar, fetch=False)
+        del b
+    al.close()
+    torch.cuda.empty_cache()
+    if "f" in bl:
+        buf = buf.copy()
 res = C.POINTER(wfagpu.AlignmentResult)()
 assert lib.initialize_wfa_results(C.byref(res), n, 256)
 opt = wfagpu.Options(max_error=int(length * 0.1 * 3), threads_per_block=64, num_workers=0, band=-1, batch_size=batch,

@@ -357,6 +357,32 @@ def test_budgets_inherited_across_batches_stay_exact_when_the_stream_drifts():
     assert c == co
 
 
+@pytest.mark.parametrize("threads", [1, 3])
+def test_launch_packs_on_the_host(golden_dir, threads):
+    """launch_alignments with the 2-bit packing done on the host (wfagpu_amd_launch_config_t::host_pack; automatic for big
+    calls on hosts with cores to spare): same results as with the pack kernel; a batch that holds a byte outside ACGT goes
+    up as ASCII (its N pairs run the byte-compare kernels), the others packed; more batches than staging buffers."""
+    lib = wfagpu.load()
+    pairs = wfagpu.read_seq_file(os.path.join(golden_dir, "seq1k.seq"))[:290]
+    pairs[130] = (pairs[130][0][:400] + b"N" + pairs[130][0][401:], pairs[130][1])
+    pairs += [(b"", b"ACGT"), (b"ACGTACGTACGTACGTA", b"ACGTACGTACGTACGTT"), (b"G", b"")]
+    buf, meta = wfagpu.layout_pairs(pairs)
+    so, co, _ = oracle_lib.oracle_batch(buf, meta, (2, 3, 1), cigar=True, nthreads=8)
+    batch = 40
+    nb = (len(pairs) + batch - 1) // batch
+    for mode, want_packed in ((1, nb - 1), (-1, 0), (1, nb - 1)):
+        wfagpu.configure_launch(host_pack=mode, host_pack_threads=threads)
+        for cigar in (True, False):
+            s, c = _api_align(pairs, (2, 3, 1), cigar=cigar, batch=batch)
+            assert np.array_equal(s, np.asarray(so))
+            if cigar:
+                assert c == co
+            st = wfagpu.last_launch_stats()
+            assert st["host_packed_batches"] == want_packed and st["batches"] == nb
+    wfagpu.configure_launch()
+    lib.wfagpu_amd_release_cache()
+
+
 @pytest.mark.parametrize("lanes,pool,batch", [(1, 0, 64), (3, 1 << 16, 50), (2, 1 << 16, 37), (4, 0, 25)])
 def test_launch_pipeline_shapes(golden_dir, lanes, pool, batch):
     """The launch pipeline in the shapes the defaults never take on a small call: one, three and four compute lanes, and an

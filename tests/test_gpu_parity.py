@@ -49,6 +49,30 @@ def test_pack_literals_and_random(aligner):
             assert got[nw] == 0  # spare word
 
 
+def test_host_packed_batches(aligner, golden_dir):
+    """wfagpu_amd_batch_t::d_packed: the words utils/host_pack.c writes are the pack kernel's, bit for bit, and a batch
+    that arrives packed (no ASCII on the device at all) aligns to the oracle's scores and CIGARs."""
+    rng = random.Random(17)
+    pairs = [(b"GATTACA", b"GATACA"), (b"ACGT" * 9, b"ACGT" * 9 + b"A"), (b"T" * 33, b"C" * 16), (b"A", b"G"), (b"", b"ACG"), (b"C" * 16, b"")]
+    pairs += _rand_pairs(rng, 300, 400) + wfagpu.read_seq_file(os.path.join(golden_dir, "seq1k.seq"))[:120]
+    buf, meta = wfagpu.layout_pairs(pairs)
+    batch = aligner.upload(buf, meta)
+    dev_words, dev_flags = aligner.pack(batch)
+    for scalar in (False, True):
+        words, flags = wfagpu.host_pack(buf, batch._meta_host, batch.packed_bytes, scalar=scalar)
+        assert not flags.any() and not dev_flags.any()
+        assert np.array_equal(words[:batch.packed_bytes // 4], dev_words[:batch.packed_bytes // 4])
+    pb = aligner.upload_packed(buf, meta)
+    so, co, _ = oracle_lib.oracle_batch(buf, meta, (2, 3, 1), cigar=True, nthreads=8)
+    for cigar in (True, False):
+        s, c = aligner.align(pb, (2, 3, 1), max_error=300, compute_cigar=cigar)
+        assert np.array_equal(s, np.asarray(so))
+        if cigar:
+            assert c == co
+    with pytest.raises(ValueError):
+        aligner.upload_packed(*wfagpu.layout_pairs([(b"ACGN", b"ACGT")]))
+
+
 @pytest.mark.parametrize("tag", ["p0", "p1", "p2", "g231"])
 def test_utest_goldens_cigar(aligner, golden_dir, tag):
     """WFA2's own unit-test goldens (score + CIGAR) for the reference's wfa.utest.seq; -e small on purpose so

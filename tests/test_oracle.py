@@ -116,6 +116,36 @@ def test_oracle_matches_compiled_reference_random(pen):
         assert ok and cost == sc
 
 
+def test_host_packer_writes_the_oracle_packers_words():
+    """utils/host_pack.c (launch_alignments* pack on the host when it has the cores): the vector path and the portable one
+    against the oracle's packer -- every length around the 16- and 32-base steps, the zero word at the end, nothing
+    written beyond it, the flag for bytes outside ACGT."""
+    import ctypes as C
+    lib = wfagpu.load()
+    rng = random.Random(11)
+    o = oracle_lib.oracle()
+    lens = list(range(0, 70)) + [95, 96, 97, 127, 128, 129, 150, 255, 256, 257, 1000, 1023, 1025] + [rng.randint(0, 3000) for _ in range(40)]
+    for fn in (lib.wfagpu_host_pack_sequence, lib.wfagpu_host_pack_sequence_scalar):
+        fn.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p]
+        fn.restype = C.c_int
+        for n in lens:
+            for dirty in (False, True):
+                seq = bytearray(rng.choice(b"ACGT") for _ in range(n))
+                if dirty:
+                    if n == 0:
+                        continue
+                    seq[rng.randrange(n)] = rng.choice(b"NacgtRY-\x00\xff")
+                seq = bytes(seq)
+                nw = (n + 15) // 16
+                want = (C.c_uint32 * (nw + 1))()
+                bad = o.oracle_pack2(seq, n, want)
+                got = (C.c_uint32 * (nw + 3))(*([0xDEADBEEF] * (nw + 3)))
+                assert fn(seq + b"GGGGGGGGGGGGGGGGGGGGGGGGGGGGGGGGG", n, got) == bad == (1 if dirty else 0), (n, dirty)
+                if not bad:
+                    assert list(got)[:nw] == list(want)[:nw], n
+                assert got[nw] == 0 and got[nw + 1] == 0xDEADBEEF and got[nw + 2] == 0xDEADBEEF, n
+
+
 def test_oracle_pack_layout():
     """Bit layout of this build's packing: code=(c&6)>>1 (A0 C1 T2 G3, as tests/test_packing_kernel.cu:31 of the
     reference decodes it), base i in bits 2*(i%16) of word i//16."""

@@ -58,18 +58,21 @@ class Config(C.Structure):  # wfagpu_amd_config_t
 class LaunchConfig(C.Structure):  # wfagpu_amd_launch_config_t: all zero = automatic
     _fields_ = [("num_devices", C.c_int), ("virtual_devices", C.c_int), ("lanes_per_device", C.c_int),
                 ("batches_per_device", C.c_int), ("arena_limit_bytes", C.c_size_t), ("input_pool_bytes", C.c_size_t),
-                ("numa_pin", C.c_int), ("timing", C.c_int), ("tuning", Tuning)]
+                ("numa_pin", C.c_int), ("timing", C.c_int), ("tuning", Tuning), ("host_pack", C.c_int),
+                ("host_pack_threads", C.c_int)]
 
 
 class LaunchStats(C.Structure):  # wfagpu_amd_launch_stats_t
     _fields_ = [(k, C.c_double) for k in ("total_ms", "plan_ms", "acquire_ms", "prep_ms", "upload_ms", "upload_wait_ms",
                                           "device_ms", "device_wait_ms", "d2h_ms", "scatter_ms", "check_ms")] + \
-               [("devices", C.c_int), ("lanes", C.c_int), ("batches", C.c_int), ("host_threads", C.c_uint)]
+               [("devices", C.c_int), ("lanes", C.c_int), ("batches", C.c_int), ("host_threads", C.c_uint),
+                ("host_pack_ms", C.c_double), ("host_packed_batches", C.c_int), ("host_pack_threads", C.c_int)]
 
 
 class Batch(C.Structure):  # wfagpu_amd_batch_t
     _fields_ = [("d_sequences", C.c_void_p), ("sequences_bytes", C.c_size_t), ("d_metadata", C.c_void_p),
-                ("num_pairs", C.c_size_t), ("packed_bytes", C.c_size_t), ("max_seq_len", C.c_uint)]
+                ("num_pairs", C.c_size_t), ("packed_bytes", C.c_size_t), ("max_seq_len", C.c_uint),
+                ("d_packed", C.c_void_p)]
 
 
 class Stats(C.Structure):  # wfagpu_amd_stats_t
@@ -94,6 +97,7 @@ ABI_SYMBOLS = [
     "wfagpu_amd_align_device", "wfagpu_amd_last_stats", "wfagpu_amd_set_num_devices", "wfagpu_amd_release_cache",
     "wfagpu_amd_check_failures", "wfagpu_amd_hint_same_stream", "wfagpu_amd_configure_launch",
     "wfagpu_amd_last_launch_stats", "wfagpu_amd_set_tuning", "wfagpu_amd_stream",
+    "wfagpu_host_pack_sequence", "wfagpu_host_pack_sequence_scalar",
 ]
 
 _lib = None
@@ -299,6 +303,24 @@ def read_seq_file(path, limit=None):
     return pairs
 
 
+def host_pack(buf, meta, packed_bytes, scalar=False):
+    """wfagpu_host_pack_sequence over a batch (meta with its packed offsets filled): (uint32 words incl. four spare ones,
+    uint8 flags[2 n]) -- what DeviceAligner.pack returns from the device."""
+    lib = load()
+    fn = lib.wfagpu_host_pack_sequence_scalar if scalar else lib.wfagpu_host_pack_sequence
+    fn.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    fn.restype = C.c_int
+    buf = np.ascontiguousarray(buf)
+    words = np.zeros(packed_bytes // 4 + 4, dtype=np.uint32)
+    flags = np.zeros(2 * len(meta), dtype=np.uint8)
+    base, out = buf.ctypes.data, words.ctypes.data
+    for i in range(len(meta)):
+        m = meta[i]
+        flags[2 * i] = fn(base + int(m["pattern_offset"]), int(m["pattern_len"]), out + int(m["pattern_offset_packed"]))
+        flags[2 * i + 1] = fn(base + int(m["text_offset"]), int(m["text_len"]), out + int(m["text_offset_packed"]))
+    return words, flags
+
+
 class DeviceAligner:
     """Owns a wfagpu_amd context on one GPU and runs resident batches through the C-ABI."""
 
@@ -352,6 +374,25 @@ class DeviceAligner:
         batch = Batch(d_sequences=d_seq.data_ptr(), sequences_bytes=d_seq.numel(), d_metadata=d_meta.data_ptr(),
                       num_pairs=len(meta), packed_bytes=packed_bytes, max_seq_len=max_len)
         batch._keep = (d_seq, d_meta)
+        batch._meta_host = meta
+        return batch
+
+    def upload_packed(self, buf, meta):
+        """Host layout -> resident batch that carries 2-bit words packed on the host (wfagpu_amd_batch_t::d_packed) and no
+        ASCII at all.  Every byte must be one of ACGT."""
+        torch = self.torch
+        meta = meta.copy()
+        packed_bytes = self.lib.wfagpu_amd_fill_packed_offsets(meta.ctypes.data, len(meta))
+        words, flags = host_pack(buf, meta, packed_bytes)
+        if flags.any():
+            raise ValueError("a sequence holds a byte outside ACGT: such batches go up as ASCII")
+        dev = torch.device("cuda", self.device)
+        d_words = torch.from_numpy(words.view(np.int32)).to(dev)
+        d_meta = torch.from_numpy(meta.view(np.uint8).reshape(-1)).to(dev)
+        max_len = int(max(meta["pattern_len"].max(initial=0), meta["text_len"].max(initial=0))) if len(meta) else 0
+        batch = Batch(d_sequences=None, sequences_bytes=0, d_metadata=d_meta.data_ptr(), num_pairs=len(meta),
+                      packed_bytes=packed_bytes, max_seq_len=max_len, d_packed=d_words.data_ptr())
+        batch._keep = (d_words, d_meta)
         batch._meta_host = meta
         return batch
 

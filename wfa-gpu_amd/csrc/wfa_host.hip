@@ -506,8 +506,12 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   unsigned long long* ct = static_cast<unsigned long long*>(c->counters.p);
 
   // ---- buffers ------------------------------------------------------------
-  if (c->packed.ensure(b->packed_bytes + 16, st)) return -1;
-  if (c->flags.ensure((size_t)2 * n, st)) return -1;
+  // (a batch that arrives packed -- wfagpu_amd_batch_t::d_packed, all ACGT by contract -- needs neither the words nor the flags)
+  const bool prepacked = b->d_packed != nullptr;
+  if (!prepacked) {
+    if (c->packed.ensure(b->packed_bytes + 16, st)) return -1;
+    if (c->flags.ensure((size_t)2 * n, st)) return -1;
+  }
   if (c->status.ensure((size_t)4 * n, st)) return -1;
   if (c->cells.ensure((size_t)4 * n, st)) return -1;
   if (c->list_a.ensure((size_t)4 * n, st)) return -1;
@@ -528,7 +532,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   item_chars = std::max(item_chars, 6);      // (the emit kernels' one-word fast path writes 4 bytes per item)
 
   WfaAlignParams ap{};
-  ap.packed = static_cast<const uint32_t*>(c->packed.p);
+  ap.packed = prepacked ? static_cast<const uint32_t*>(b->d_packed) : static_cast<const uint32_t*>(c->packed.p);
   ap.meta = reinterpret_cast<const WfaSeqPair*>(b->d_metadata);
   ap.x = pen.x; ap.oe = oe; ap.e = pen.e;
   ap.dm = std::max(pen.x, oe) + 1;
@@ -580,9 +584,11 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   HIP_TRY(hipMemsetAsync(c->status.p, 0, (size_t)4 * n, st));
   HIP_TRY(hipMemsetAsync(c->counters.p, 0, CT_N * sizeof(unsigned long long), st));
   HIP_TRY(hipEventRecord(c->ev_start, st));
-  wfa_launch_pack(b->d_sequences, ap.meta, n, static_cast<uint32_t*>(c->packed.p), static_cast<uint8_t*>(c->flags.p), st);
-  LAUNCH_K(k_flag_alphabet, dim3(cdiv(n, 256)), dim3(256), 0, st, static_cast<const uint8_t*>(c->flags.p), n,
-                     static_cast<uint32_t*>(c->status.p), ct + CT_NRAW);
+  if (!prepacked) {
+    wfa_launch_pack(b->d_sequences, ap.meta, n, static_cast<uint32_t*>(c->packed.p), static_cast<uint8_t*>(c->flags.p), st);
+    LAUNCH_K(k_flag_alphabet, dim3(cdiv(n, 256)), dim3(256), 0, st, static_cast<const uint8_t*>(c->flags.p), n,
+                       static_cast<uint32_t*>(c->status.p), ct + CT_NRAW);
+  }
   HIP_TRY(hipEventRecord(c->ev_pack, st));
 
   float align_ms = 0.f, trace_ms = 0.f;

@@ -9,13 +9,15 @@
 // into batches of options.batch_size like the reference does and runs as a
 // pipeline whose stages never wait for each other's buffers:
 //
-//   prep thread      spans + packed offsets of every batch (host only, runs ahead)
+//   prep thread      spans + packed offsets of every batch (host only, runs ahead) and -- when the host has the cores --
+//                    the 2-bit packing of the batch into a staging ring (utils/host_pack.c: the pack kernel's words,
+//                    30 GB/s of ASCII per core), so that a quarter of the bytes cross PCIe
 //   upload thread    ONE stream of back-to-back H2D copies into a pool of input slots -- with 288 GB of HBM the
-//                    whole slice stays resident (1M x 1 kbp pairs: 2 GB), so the copy engine never idles while a
-//                    batch computes: the call is bound by PCIe (2 GB at ~56 GB/s = 36 ms) or by the kernels,
-//                    whichever is longer, plus the tail of the last batch
-//   K compute lanes  contexts (stream, backtrace arena, scratch) that take alternate batches: the host round trips and
-//                    backtrace kernels of one lane are filled by the wavefront kernels of the other
+//                    whole slice stays resident (1M x 1 kbp pairs: 2 GB of ASCII, 0.5 GB packed), so the copy engine never
+//                    idles while a batch computes: the call is bound by PCIe (ASCII: 2 GB at ~56 GB/s = 36 ms) or by
+//                    the kernels, whichever is longer, plus the tail of the last batch
+//   K compute lanes  contexts (stream, backtrace arena, scratch) that each take the next batch nobody has taken: the host
+//                    round trips and backtrace kernels of one lane are filled by the wavefront kernels of the others
 //   K result lanes   D2H of a batch's results into pinned staging -- under the kernels of the lane's NEXT batch: a context
 //                    alternates between two sets of output buffers --, then staging -> the caller's
 //                    wfa_alignment_result_t records (+ the -c check)
@@ -218,7 +220,10 @@ struct Lane {
     int32_t* score = nullptr; size_t n_cap = 0;
   } out[2];
 };
-struct InSlot { char* d_seq = nullptr; size_t seq_cap = 0; sequence_pair_t* d_meta = nullptr; size_t meta_cap = 0; };
+struct InSlot { char* d_seq = nullptr; size_t seq_cap = 0; sequence_pair_t* d_meta = nullptr; size_t meta_cap = 0;
+                uint32_t* d_packed = nullptr; size_t packed_cap = 0; };
+struct HostStage { uint32_t* p = nullptr; size_t cap = 0; };      // host-packed words of a batch on their way up (pageable)
+constexpr int STAGE_RING = 4;
 struct DevState {
   int device = -1;
   // H2D of the batches, in order.  ONE stream: the runtime moves pageable memory in 32 MiB pieces with ~30 us of host
@@ -229,6 +234,7 @@ struct DevState {
   hipStream_t up = nullptr;
   std::vector<hipEvent_t> up_done;             // one per batch of a call: "its copies have landed"
   std::vector<InSlot> in;
+  HostStage stage[STAGE_RING];
   Lane lane[MAX_LANES];
   wfagpu_amd_tuning_t tuning{};                // what the contexts were created with
   size_t arena_limit_cfg = 0;
@@ -239,8 +245,9 @@ std::mutex g_dev_mu[MAX_DEV];   // one per slot: the devices of a call run concu
 void release_dev(DevState& d) {
   if (d.device < 0) return;
   (void)hipSetDevice(d.device);
-  for (auto& in : d.in) { if (in.d_seq) (void)hipFree(in.d_seq); if (in.d_meta) (void)hipFree(in.d_meta); }
+  for (auto& in : d.in) { if (in.d_seq) (void)hipFree(in.d_seq); if (in.d_meta) (void)hipFree(in.d_meta); if (in.d_packed) (void)hipFree(in.d_packed); }
   d.in.clear();
+  for (auto& hs : d.stage) { free(hs.p); hs = HostStage{}; }
   for (auto& e : d.up_done) (void)hipEventDestroy(e);
   d.up_done.clear();
   for (auto& l : d.lane) {
@@ -312,6 +319,7 @@ struct BatchPlan {
   size_t lo = 0, span = 0;  // bytes of the caller's sequence buffer the batch covers: [lo, lo + span)
   size_t packed_bytes = 0;
   unsigned max_len = 0;
+  bool host_packed = false; // the batch goes up as 2-bit words packed on the host (else as ASCII, packed by the kernel)
 };
 
 // One mutex + condition variable for all the per-batch stage flags of a device's pipeline.
@@ -348,6 +356,10 @@ int run_device(const CallArgs& a, Shard& sh) {
   auto add_batches = [&](size_t from, size_t to, size_t step) {
     for (; from < to; from += step) { BatchPlan b{}; b.from = from; b.to = std::min(to, from + step); plan.push_back(b); }
   };
+  // 2-bit packing on the host (a quarter of the bytes over PCIe) when this device's share of the host threads allows
+  const bool host_pack = a.cfg.host_pack > 0 || (a.cfg.host_pack == 0 && sh.host_threads >= 4 && n_all >= ((size_t)1 << 17));
+  const unsigned pack_threads = a.cfg.host_pack_threads > 0 ? (unsigned)a.cfg.host_pack_threads
+                                                            : std::max(2u, std::min(8u, sh.host_threads / 2u));
   if (bs == n_all && n_all >= ((size_t)1 << 17)) {
     const size_t cut = a.cfg.batches_per_device > 0 ? (size_t)a.cfg.batches_per_device : 16;
     bs = (n_all + cut - 1) / cut;
@@ -357,8 +369,10 @@ int run_device(const CallArgs& a, Shard& sh) {
   }
   const int nb = (int)plan.size();
   // Two lanes for big calls: the kernels of one fill the gaps (host round trips between kernel tiers, backtrace tails,
-  // result copies) of the other.
-  int K = a.cfg.lanes_per_device > 0 ? a.cfg.lanes_per_device : (n_all >= ((size_t)1 << 18) ? 2 : 1);
+  // result copies) of the other.  Three when the sequences go up packed: the call is then bound by the kernels, not by
+  // PCIe, and a third lane closes what two leave open (1M x 1 kbp pairs: 36.9 -> 35.3 ms; four lanes: the same).
+  // (smaller first batches -- an earlier start for the kernels -- gain nothing: a small batch is mostly host round trips)
+  int K = a.cfg.lanes_per_device > 0 ? a.cfg.lanes_per_device : (n_all >= ((size_t)1 << 18) ? (host_pack ? 3 : 2) : 1);
   K = std::max(1, std::min({K, MAX_LANES, nb}));
 
   DevState* dp = nullptr;
@@ -376,7 +390,7 @@ int run_device(const CallArgs& a, Shard& sh) {
       size_t free_b = 0, total_b = 0;
       if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
       size_t have = 0;
-      for (const auto& s : d.in) have += s.seq_cap + s.meta_cap * sizeof(sequence_pair_t);
+      for (const auto& s : d.in) have += s.seq_cap + s.packed_cap + s.meta_cap * sizeof(sequence_pair_t);
       pool = std::min<size_t>((size_t)24 << 30, (free_b + have) / 4 / (size_t)std::max(1, sh.sharers));
     }
     // (estimate from the first batch: the pairs of a call are of similar size; the slots grow on demand anyway)
@@ -401,12 +415,13 @@ int run_device(const CallArgs& a, Shard& sh) {
   std::vector<BatchOut> bout(nb);
   struct BatchClock { double up0 = 0, up1 = 0, dev0 = 0, dev1 = 0, d2h1 = 0, sc0 = 0, sc1 = 0; };      // (timing >= 2: ms since the start of the slice)
   std::vector<BatchClock> clk(nb);
-  struct StageTimes { double prep = 0, up = 0, up_wait = 0, dev = 0, dev_wait = 0, d2h = 0, scatter = 0, check = 0; };
+  struct StageTimes { double prep = 0, pack = 0, up = 0, up_wait = 0, dev = 0, dev_wait = 0, d2h = 0, scatter = 0, check = 0; };
   StageTimes t_prep_thread, t_up_thread;
   std::vector<StageTimes> t_lane(K), t_scat(K);
 
   // ---- stage 0: spans and packed offsets (host only) -----------------------------------------------------------------
   std::thread prepper([&] {
+    if (host_pack && hipSetDevice(sh.device) != hipSuccess) { fl.fail(-1); return; }
     for (int i = 0; i < nb; ++i) {
       if (fl.rc.load()) return;
       const double t0 = now_ms();
@@ -428,6 +443,36 @@ int run_device(const CallArgs& a, Shard& sh) {
       // packed offsets: written into the caller's metadata like the reference
       // (lib/align.cu:103-115,363-377), relative to the batch
       b.packed_bytes = wfagpu_amd_fill_packed_offsets(a.meta + b.from, n);
+      if (host_pack) {
+        const double tp0 = now_ms();
+        // (the staging buffer last carried batch i - STAGE_RING: its copy must have left the host)
+        if (i >= STAGE_RING) {
+          if (!fl.wait(uploaded, i - STAGE_RING)) return;
+          if (hipEventSynchronize(d.up_done[i - STAGE_RING]) != hipSuccess) { fl.fail(-1); return; }
+        }
+        HostStage& hs = d.stage[i % STAGE_RING];
+        if (b.packed_bytes + 64 > hs.cap) {
+          free(hs.p);
+          hs.cap = b.packed_bytes + b.packed_bytes / 8 + 64;
+          hs.p = static_cast<uint32_t*>(malloc(hs.cap));
+          if (!hs.p) { hs.cap = 0; LOG_ERROR("Can not allocate the packing buffer"); fl.fail(-1); return; }
+        }
+        std::atomic<int> bad{0};
+        const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(pack_threads, (n + 4095) / 4096));
+        parallel_for(nt, [&](unsigned t) {
+          int bd = 0;
+          const size_t j1 = b.from + n * (t + 1) / nt;
+          for (size_t j = b.from + n * t / nt; j < j1 && !bd; ++j) {
+            const sequence_pair_t& m = a.meta[j];
+            bd |= wfagpu_host_pack_sequence(a.seq + m.pattern_offset, (uint32_t)m.pattern_len, hs.p + (m.pattern_offset_packed >> 2));
+            bd |= wfagpu_host_pack_sequence(a.seq + m.text_offset, (uint32_t)m.text_len, hs.p + (m.text_offset_packed >> 2));
+          }
+          if (bd) bad.store(1);
+        });
+        // (a byte outside ACGT: those pairs need their ASCII on the device, the whole batch goes up as it is)
+        b.host_packed = bad.load() == 0;
+        t_prep_thread.pack += now_ms() - tp0;
+      }
       t_prep_thread.prep += now_ms() - t0;
       fl.set(prepped, i);
     }
@@ -446,7 +491,13 @@ int run_device(const CallArgs& a, Shard& sh) {
       const BatchPlan& b = plan[i];
       const size_t n = b.to - b.from;
       InSlot& in = d.in[i % R];
-      if (b.span + 16 > in.seq_cap) {
+      if (b.host_packed) {
+        if (b.packed_bytes + 64 > in.packed_cap) {
+          if (in.d_packed) (void)hipFree(in.d_packed);
+          in.d_packed = nullptr; in.packed_cap = b.packed_bytes + b.packed_bytes / 8 + 64;
+          if (!ok(hipMalloc(&in.d_packed, in.packed_cap), "hipMalloc(packed sequences)")) return;
+        }
+      } else if (b.span + 16 > in.seq_cap) {
         if (in.d_seq) (void)hipFree(in.d_seq);
         in.d_seq = nullptr; in.seq_cap = b.span + b.span / 8 + 16;
         if (!ok(hipMalloc(&in.d_seq, in.seq_cap), "hipMalloc(sequences)")) return;
@@ -458,7 +509,9 @@ int run_device(const CallArgs& a, Shard& sh) {
       }
       // (the records go up as they are: the kernels see the sequences through a base pointer moved back by b.lo, so the
       // caller's offsets need no rebasing and no host copy)
-      if (b.span && !ok(hipMemcpyAsync(in.d_seq, a.seq + b.lo, b.span, hipMemcpyHostToDevice, d.up), "H2D sequences")) return;
+      if (b.host_packed) {
+        if (b.packed_bytes && !ok(hipMemcpyAsync(in.d_packed, d.stage[i % STAGE_RING].p, b.packed_bytes, hipMemcpyHostToDevice, d.up), "H2D packed sequences")) return;
+      } else if (b.span && !ok(hipMemcpyAsync(in.d_seq, a.seq + b.lo, b.span, hipMemcpyHostToDevice, d.up), "H2D sequences")) return;
       if (!ok(hipMemcpyAsync(in.d_meta, a.meta + b.from, n * sizeof(sequence_pair_t), hipMemcpyHostToDevice, d.up), "H2D metadata")) return;
       // (no synchronisation here: the copies of the next batch follow back to back; the lane that takes this batch
       // waits for the event)
@@ -470,12 +523,24 @@ int run_device(const CallArgs& a, Shard& sh) {
 
   // ---- stage 3: staging -> the caller's records (+ -c), one thread per lane --------------------------------------------
   const unsigned lane_threads = std::max(1u, sh.host_threads / (unsigned)K);
+  // The lanes TAKE batches (the next one that has not been taken) instead of owning every K-th: the kernels of
+  // concurrent lanes do not share the device evenly (1M x 1 kbp pairs, three lanes: one lane went through its batches in
+  // 2.6 ms each while the others took 8 and was idle for the last third of the call).
+  std::atomic<int> next_batch{0};
+  std::vector<std::vector<int>> lane_batches(K);      // what lane k has computed, in order (under fl.mu)
+  std::vector<char> lane_done(K, 0);
   auto scatter_lane = [&](int k) {
     // (this thread issues the D2H copies of its lane: every thread that talks to HIP selects the slice's device first)
     if (hipSetDevice(sh.device) != hipSuccess) { fl.fail(-1); return; }
-    int j = 0;
-    for (int i = k; i < nb; i += K, ++j) {
-      if (!fl.wait(computed, i)) return;
+    for (int j = 0;; ++j) {
+      int i = -1;
+      {
+        std::unique_lock<std::mutex> l(fl.mu);
+        fl.cv.wait(l, [&] { return (int)lane_batches[k].size() > j || lane_done[k] != 0 || fl.rc.load() != 0; });
+        if (fl.rc.load() != 0) return;
+        if ((int)lane_batches[k].size() <= j) break;
+        i = lane_batches[k][j];
+      }
       double t0 = now_ms();
       const BatchPlan& b = plan[i];
       const size_t n = b.to - b.from;
@@ -552,8 +617,11 @@ int run_device(const CallArgs& a, Shard& sh) {
   auto compute_lane = [&](int k) -> int {
     HIP_OK(hipSetDevice(sh.device));
     Lane& L = d.lane[k];
-    int j = 0;
-    for (int i = k; i < nb; i += K, ++j) {
+    std::vector<int> mine;
+    for (int j = 0;; ++j) {
+      const int i = next_batch.fetch_add(1);
+      if (i >= nb) break;
+      mine.push_back(i);
       double t0 = now_ms();
       if (!fl.wait(uploaded, i)) return fl.rc.load();
       HIP_OK(hipEventSynchronize(d.up_done[i]));
@@ -569,9 +637,10 @@ int run_device(const CallArgs& a, Shard& sh) {
         HIP_OK(hipMalloc(&d_sc, L.scores_cap[j & 1] * sizeof(int32_t)));
       }
       // (the output set this batch writes was last used by the lane's batch before last: its download must be over)
-      if (!fl.wait(downloaded, i - 2 * K)) return fl.rc.load();
+      if (j >= 2 && !fl.wait(downloaded, mine[j - 2])) return fl.rc.load();
       wfagpu_amd_batch_t wb{};
-      wb.d_sequences = reinterpret_cast<const char*>(reinterpret_cast<uintptr_t>(in.d_seq) - b.lo);     // [offset of the caller's buffer]
+      if (b.host_packed) wb.d_packed = in.d_packed;
+      else wb.d_sequences = reinterpret_cast<const char*>(reinterpret_cast<uintptr_t>(in.d_seq) - b.lo);     // [offset of the caller's buffer]
       wb.sequences_bytes = b.lo + b.span; wb.d_metadata = in.d_meta; wb.num_pairs = n;
       wb.packed_bytes = b.packed_bytes; wb.max_seq_len = b.max_len;
       BatchOut& bo = bout[i];
@@ -586,15 +655,22 @@ int run_device(const CallArgs& a, Shard& sh) {
       if (a.cigar) { wfagpu_amd_stats_t stt; wfagpu_amd_last_stats(L.ctx, &stt); bo.text_bytes = stt.text_bytes; }
       t_lane[k].dev += now_ms() - t0;
       clk[i].dev1 = now_ms() - t_begin;
-      fl.set(computed, i);
+      { std::lock_guard<std::mutex> l(fl.mu); computed[i] = 1; lane_batches[k].push_back(i); }
+      fl.cv.notify_all();
     }
     return 0;
+  };
+  auto run_lane = [&](int k) {
+    const int c = compute_lane(k);
+    if (c) fl.fail(c);
+    { std::lock_guard<std::mutex> l(fl.mu); lane_done[k] = 1; }
+    fl.cv.notify_all();
   };
 
   std::vector<std::thread> scat, comp;
   for (int k = 0; k < K; ++k) scat.emplace_back(scatter_lane, k);
-  for (int k = 1; k < K; ++k) comp.emplace_back([&, k] { const int c = compute_lane(k); if (c) fl.fail(c); });
-  { const int c = compute_lane(0); if (c) fl.fail(c); }
+  for (int k = 1; k < K; ++k) comp.emplace_back(run_lane, k);
+  run_lane(0);
   for (auto& t : comp) t.join();
   prepper.join();
   uploader.join();
@@ -609,6 +685,8 @@ int run_device(const CallArgs& a, Shard& sh) {
     st.scatter_ms += t_scat[k].scatter; st.check_ms += t_scat[k].check;
   }
   st.lanes = K; st.batches = nb;
+  st.host_pack_ms = t_prep_thread.pack; st.host_pack_threads = host_pack ? (int)pack_threads : 0;
+  for (const auto& b : plan) st.host_packed_batches += b.host_packed ? 1 : 0;
   if (a.cfg.timing)
     fprintf(stderr, "[wfagpu timing] device %d (slot %d): %d batches, %d lanes, %d input slots; acquire %.1f ms, prep %.1f, upload %.1f (+%.1f waiting), "
             "device %.1f (+%.1f waiting), d2h %.1f, scatter %.1f, check %.1f; total %.1f\n",

@@ -26,7 +26,18 @@ wfagpu.configure_launch(timing=int(os.environ.get("TIMING", "0")), lanes_per_dev
                         host_pack=int(os.environ.get("HOST_PACK", "0")), host_pack_threads=int(os.environ.get("PACK_THREADS", "0")))
 buf, meta = wfagpu.generate_pairs(n, length, err, seed=int(os.environ.get("SEED", "7")), nthreads=16)
 bl = os.environ.get("BENCHLIKE", "")
-if bl and bl[0] in "tmh":
+if bl and bl[0] == "x":
+    hip = wfagpu._hiprt()
+    ptr = C.c_void_p()
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipFree.argtypes = [C.c_void_p]
+    hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    assert hip.hipMalloc(C.byref(ptr), buf.nbytes) == 0
+    assert hip.hipMemset(ptr, 0, buf.nbytes) == 0
+    hip.hipDeviceSynchronize()
+    if bl != "xk":
+        assert hip.hipFree(ptr) == 0
+elif bl and bl[0] in "tmh":
     import torch
     if bl[0] == "t":
         x = torch.empty(buf.nbytes, dtype=torch.uint8, device="cuda"); x.zero_(); torch.cuda.synchronize(); del x

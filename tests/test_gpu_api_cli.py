@@ -357,28 +357,32 @@ def test_budgets_inherited_across_batches_stay_exact_when_the_stream_drifts():
     assert c == co
 
 
-@pytest.mark.parametrize("threads", [1, 3])
-def test_launch_packs_on_the_host(golden_dir, threads):
+@pytest.mark.parametrize("threads,slots", [(1, 0), (3, 0), (2, 3)])
+def test_launch_packs_on_the_host(golden_dir, threads, slots):
     """launch_alignments with the 2-bit packing done on the host (wfagpu_amd_launch_config_t::host_pack; automatic for big
     calls on hosts with cores to spare): same results as with the pack kernel; a batch that holds a byte outside ACGT goes
-    up as ASCII (its N pairs run the byte-compare kernels), the others packed; more batches than staging buffers."""
+    up as ASCII (its N pairs run the byte-compare kernels), the others packed; more batches than staging buffers; the call
+    sharded over several device slots."""
     lib = wfagpu.load()
     pairs = wfagpu.read_seq_file(os.path.join(golden_dir, "seq1k.seq"))[:290]
     pairs[130] = (pairs[130][0][:400] + b"N" + pairs[130][0][401:], pairs[130][1])
     pairs += [(b"", b"ACGT"), (b"ACGTACGTACGTACGTA", b"ACGTACGTACGTACGTT"), (b"G", b"")]
     buf, meta = wfagpu.layout_pairs(pairs)
     so, co, _ = oracle_lib.oracle_batch(buf, meta, (2, 3, 1), cigar=True, nthreads=8)
-    batch = 40
+    batch = 40 if not slots else 15
     nb = (len(pairs) + batch - 1) // batch
     for mode, want_packed in ((1, nb - 1), (-1, 0), (1, nb - 1)):
-        wfagpu.configure_launch(host_pack=mode, host_pack_threads=threads)
+        wfagpu.configure_launch(host_pack=mode, host_pack_threads=threads, virtual_devices=slots)
         for cigar in (True, False):
             s, c = _api_align(pairs, (2, 3, 1), cigar=cigar, batch=batch)
             assert np.array_equal(s, np.asarray(so))
             if cigar:
                 assert c == co
-            st = wfagpu.last_launch_stats()
-            assert st["host_packed_batches"] == want_packed and st["batches"] == nb
+            st = wfagpu.last_launch_stats()      # (of the busiest device slot)
+            if not slots:
+                assert st["host_packed_batches"] == want_packed and st["batches"] == nb
+            else:
+                assert (st["host_packed_batches"] > 0) == (mode > 0) and st["devices"] == slots
     wfagpu.configure_launch()
     lib.wfagpu_amd_release_cache()
 

@@ -356,12 +356,24 @@ int run_device(const CallArgs& a, Shard& sh) {
   auto add_batches = [&](size_t from, size_t to, size_t step) {
     for (; from < to; from += step) { BatchPlan b{}; b.from = from; b.to = std::min(to, from + step); plan.push_back(b); }
   };
+  // "big" = worth a pipeline: many pairs, or many bytes (long reads: 16k x 10 kbp pairs are 330 MB)
+  size_t slice_bytes = 0;
+  {
+    const sequence_pair_t& m0 = a.meta[sh.from];
+    const sequence_pair_t& m1 = a.meta[sh.to - 1];
+    const size_t lo0 = std::min(m0.pattern_offset, m0.text_offset), hi0 = std::max(m1.pattern_offset + m1.pattern_len, m1.text_offset + m1.text_len);
+    slice_bytes = hi0 > lo0 ? hi0 - lo0 : 0;      // (an estimate: the records of a call are laid out in order by every known caller)
+  }
+  const bool big = n_all >= ((size_t)1 << 17) || (slice_bytes >= ((size_t)128 << 20) && n_all >= 256);
   // 2-bit packing on the host (a quarter of the bytes over PCIe) when this device's share of the host threads allows
-  const bool host_pack = a.cfg.host_pack > 0 || (a.cfg.host_pack == 0 && sh.host_threads >= 4 && n_all >= ((size_t)1 << 17));
+  const bool host_pack = a.cfg.host_pack > 0 || (a.cfg.host_pack == 0 && sh.host_threads >= 4 && big);
   const unsigned pack_threads = a.cfg.host_pack_threads > 0 ? (unsigned)a.cfg.host_pack_threads
                                                             : std::max(2u, std::min(8u, sh.host_threads / 2u));
-  if (bs == n_all && n_all >= ((size_t)1 << 17)) {
-    const size_t cut = a.cfg.batches_per_device > 0 ? (size_t)a.cfg.batches_per_device : 16;
+  if (bs == n_all && big) {
+    // (few long pairs: batches of >= 32 MB and >= 8192 pairs -- smaller ones tune no score budgets, csrc/wfa_host.hip, and
+    // run twice as long: 16k x 10 kbp pairs, host to host: one batch 25.1 ms, two 22.0, four 43.7)
+    const size_t cut = a.cfg.batches_per_device > 0 ? (size_t)a.cfg.batches_per_device
+                     : n_all >= ((size_t)1 << 17) ? 16 : std::max<size_t>(1, std::min<size_t>(16, std::min(slice_bytes >> 25, n_all >> 13)));
     bs = (n_all + cut - 1) / cut;
     add_batches(sh.from, sh.to, bs);
   } else {
@@ -372,7 +384,7 @@ int run_device(const CallArgs& a, Shard& sh) {
   // result copies) of the other.  Three when the sequences go up packed: the call is then bound by the kernels, not by
   // PCIe, and a third lane closes what two leave open (1M x 1 kbp pairs: 36.9 -> 35.3 ms; four lanes: the same).
   // (smaller first batches -- an earlier start for the kernels -- gain nothing: a small batch is mostly host round trips)
-  int K = a.cfg.lanes_per_device > 0 ? a.cfg.lanes_per_device : (n_all >= ((size_t)1 << 18) ? (host_pack ? 3 : 2) : 1);
+  int K = a.cfg.lanes_per_device > 0 ? a.cfg.lanes_per_device : ((n_all >= ((size_t)1 << 18) || (big && slice_bytes >= ((size_t)256 << 20))) ? (host_pack ? 3 : 2) : 1);
   K = std::max(1, std::min({K, MAX_LANES, nb}));
 
   DevState* dp = nullptr;
@@ -458,7 +470,7 @@ int run_device(const CallArgs& a, Shard& sh) {
           if (!hs.p) { hs.cap = 0; LOG_ERROR("Can not allocate the packing buffer"); fl.fail(-1); return; }
         }
         std::atomic<int> bad{0};
-        const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(pack_threads, (n + 4095) / 4096));
+        const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)pack_threads, n, (b.span >> 22) + 1}));     // (>= 4 MB of ASCII per thread)
         parallel_for(nt, [&](unsigned t) {
           int bd = 0;
           const size_t j1 = b.from + n * (t + 1) / nt;

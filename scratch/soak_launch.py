@@ -21,7 +21,14 @@ for it in range(iters):
     batch = rng.choice([n, n, max(1, n // 3), max(1, n // 7), 37, 1000])
     cfg = dict(lanes_per_device=rng.choice([0, 1, 2, 3, 4]), virtual_devices=rng.choice([0, 0, 2, 3, 8]),
                input_pool_bytes=rng.choice([0, 0, 1 << 16, 1 << 24]), arena_limit_bytes=rng.choice([0, 0, 64 << 20]),
-               batches_per_device=rng.choice([0, 0, 4, 24]), numa_pin=rng.choice([0, 1]))
+               batches_per_device=rng.choice([0, 0, 4, 24]), numa_pin=rng.choice([0, 1]),
+               host_pack=rng.choice([0, 1, 1, -1]), host_pack_threads=rng.choice([0, 1, 3, 8]))
+    if rng.random() < 0.3:
+        # a few bytes outside ACGT: their batches go up as ASCII, their pairs run the byte-compare kernels
+        for _ in range(rng.choice([1, 3, 40])):
+            m = meta[rng.randrange(n)]
+            if int(m["pattern_len"]):
+                buf[int(m["pattern_offset"]) + rng.randrange(int(m["pattern_len"]))] = ord("N")
     wfagpu.configure_launch(**cfg)
     so, co, _ = oracle_lib.oracle_batch(buf, meta, pen, cigar=cigar, nthreads=16)
     res = C.POINTER(wfagpu.AlignmentResult)()

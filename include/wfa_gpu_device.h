@@ -119,6 +119,11 @@ size_t wfagpu_amd_fill_packed_offsets(sequence_pair_t* metadata, size_t n);
  * (c & 6) >> 1, first base in the low bits, a zero word at the end); returns 1 when a byte outside ACGT was seen. */
 int wfagpu_host_pack_sequence(const char* src, uint32_t len, uint32_t* dst);
 int wfagpu_host_pack_sequence_scalar(const char* src, uint32_t len, uint32_t* dst);   /* (the portable path, for tests) */
+/* A strip of n records of a batch: assigns their packed offsets from first_off on (what wfagpu_amd_fill_packed_offsets does,
+ * strip by strip) and, with a staging buffer (the batch's packed words, NULL: offsets only), packs their sequences into it;
+ * sequences_bytes: size of the caller's buffer (bytes that may be read).  Returns 1 when a byte outside ACGT was seen. */
+int wfagpu_host_pack_strip(const char* sequences, size_t sequences_bytes, sequence_pair_t* metadata, size_t n,
+                           size_t first_off, uint32_t* stage);
 
 /* Stage 1 only: 2-bit packing.  d_packed must hold batch->packed_bytes;
  * d_flags (2 bytes per pair: pattern, text) receives 1 where a byte outside
@@ -168,7 +173,7 @@ typedef struct {
                                  GPU-bound).  0: when a device's share of the host threads is >= 4 and the call is big,
                                  1: always, -1: never (ASCII goes up, the pack kernel runs).  A batch holding a byte outside
                                  ACGT always goes up as ASCII                                                           */
-    int host_pack_threads;    /* threads packing a batch (0: half of a device's share of the host threads, 2..8)         */
+    int host_pack_threads;    /* threads packing a batch (0: three quarters of a device's share of the host threads, 2..12)         */
 } wfagpu_amd_launch_config_t;
 
 /* NULL: back to the defaults.  Changing `tuning` or `arena_limit_bytes` drops the cached per-device state. */

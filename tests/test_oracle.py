@@ -146,6 +146,53 @@ def test_host_packer_writes_the_oracle_packers_words():
                 assert got[nw] == 0 and got[nw + 1] == 0xDEADBEEF and got[nw + 2] == 0xDEADBEEF, n
 
 
+def test_host_pack_strip_offsets_and_words():
+    """wfagpu_host_pack_strip (what launch_alignments* run per strip of a batch): the offsets of
+    wfagpu_amd_fill_packed_offsets, the oracle packer's words -- partial last 32 bytes through the vector path where the
+    caller's buffer goes on that far, through the scalar one at its very end --, offsets only without a staging buffer, the
+    flag (and no further packing) from the first byte outside ACGT on."""
+    import ctypes as C
+    lib = wfagpu.load()
+    lib.wfagpu_host_pack_strip.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
+    lib.wfagpu_host_pack_strip.restype = C.c_int
+    rng = random.Random(23)
+    pairs = [(bytes(rng.choice(b"ACGT") for _ in range(rng.choice([0, 1, 15, 16, 17, 31, 32, 33, 47, 63, 64, 65, 150, 151, 1000, rng.randint(0, 400)]))),
+              bytes(rng.choice(b"ACGT") for _ in range(rng.choice([0, 5, 16, 30, 32, 149, 150, rng.randint(0, 400)])))) for _ in range(300)]
+    pairs.append((b"ACGTACGTACGTACGTACGTA", b"TTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTG"))      # (the end of the buffer)
+    buf, meta = wfagpu.layout_pairs(pairs)
+    last = meta[-1]
+    buf = np.ascontiguousarray(buf[:int(last["text_offset"]) + int(last["text_len"])])      # nothing readable after the last base
+    want_meta = meta.copy()
+    total = lib.wfagpu_amd_fill_packed_offsets(want_meta.ctypes.data, len(want_meta))
+    o = oracle_lib.oracle()
+    for first, n0 in ((0, 0), (64, 7)):
+        got_meta = meta.copy()
+        words = np.full(total // 4 + first // 4 + 8, 0xDEADBEEF, dtype=np.uint32)
+        sub = got_meta[n0:]
+        assert lib.wfagpu_host_pack_strip(buf.ctypes.data, buf.nbytes, sub.ctypes.data, len(sub), first, words.ctypes.data) == 0
+        base = int(want_meta[n0]["pattern_offset_packed"]) - first
+        for i in range(n0, len(pairs)):
+            for seq, key in zip(pairs[i], ("pattern_offset_packed", "text_offset_packed")):
+                off = int(got_meta[i][key])
+                assert off == int(want_meta[i][key]) - base
+                nw = (len(seq) + 15) // 16
+                want = (C.c_uint32 * (nw + 1))()
+                assert o.oracle_pack2(seq, len(seq), want) == 0
+                assert list(words[off // 4: off // 4 + nw]) == list(want)[:nw], (i, key)
+                assert words[off // 4 + nw] == 0
+        assert words[(total - base) // 4] == 0xDEADBEEF if n0 == 0 else True
+    only = meta.copy()
+    assert lib.wfagpu_host_pack_strip(buf.ctypes.data, buf.nbytes, only.ctypes.data, len(only), 0, None) == 0
+    assert np.array_equal(only["pattern_offset_packed"], want_meta["pattern_offset_packed"]) and np.array_equal(only["text_offset_packed"], want_meta["text_offset_packed"])
+    dirty = bytearray(buf.tobytes())
+    dirty[int(meta[100]["text_offset"]) + 3] = ord("N")
+    dbuf = np.frombuffer(bytes(dirty), dtype=np.uint8)
+    m3 = meta.copy()
+    words = np.zeros(total // 4 + 8, dtype=np.uint32)
+    assert lib.wfagpu_host_pack_strip(dbuf.ctypes.data, dbuf.nbytes, m3.ctypes.data, len(m3), 0, words.ctypes.data) == 1
+    assert np.array_equal(m3["text_offset_packed"], want_meta["text_offset_packed"])      # (the offsets are assigned to the end)
+
+
 def test_oracle_pack_layout():
     """Bit layout of this build's packing: code=(c&6)>>1 (A0 C1 T2 G3, as tests/test_packing_kernel.cu:31 of the
     reference decodes it), base i in bits 2*(i%16) of word i//16."""

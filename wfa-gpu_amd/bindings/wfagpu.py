@@ -97,7 +97,7 @@ ABI_SYMBOLS = [
     "wfagpu_amd_align_device", "wfagpu_amd_last_stats", "wfagpu_amd_set_num_devices", "wfagpu_amd_release_cache",
     "wfagpu_amd_check_failures", "wfagpu_amd_hint_same_stream", "wfagpu_amd_configure_launch",
     "wfagpu_amd_last_launch_stats", "wfagpu_amd_set_tuning", "wfagpu_amd_stream",
-    "wfagpu_host_pack_sequence", "wfagpu_host_pack_sequence_scalar",
+    "wfagpu_host_pack_sequence", "wfagpu_host_pack_sequence_scalar", "wfagpu_host_pack_strip",
 ]
 
 _lib = None

@@ -368,7 +368,8 @@ int run_device(const CallArgs& a, Shard& sh) {
   // 2-bit packing on the host (a quarter of the bytes over PCIe) when this device's share of the host threads allows
   const bool host_pack = a.cfg.host_pack > 0 || (a.cfg.host_pack == 0 && sh.host_threads >= 4 && big);
   const unsigned pack_threads = a.cfg.host_pack_threads > 0 ? (unsigned)a.cfg.host_pack_threads
-                                                            : std::max(2u, std::min(8u, sh.host_threads / 2u));
+                                                            : std::max(2u, std::min(12u, sh.host_threads * 3u / 4u));
+  const unsigned prep_threads = host_pack ? pack_threads : std::max(1u, std::min(8u, sh.host_threads / 2u));
   if (bs == n_all && big) {
     // (few long pairs: batches of >= 32 MB and >= 8192 pairs -- smaller ones tune no score budgets, csrc/wfa_host.hip, and
     // run twice as long: 16k x 10 kbp pairs, host to host: one batch 25.1 ms, two 22.0, four 43.7)
@@ -439,24 +440,43 @@ int run_device(const CallArgs& a, Shard& sh) {
       const double t0 = now_ms();
       BatchPlan& b = plan[i];
       const size_t n = b.to - b.from;
-      // span of the batch inside the caller's buffer (lib/align.cu:80-93 takes it from the first/last
-      // record; scanning is robust to any record order)
-      size_t lo = SIZE_MAX, hi = 0;
+      // Two parallel sweeps over the records (10M short reads: 30 ms on one thread -- more than their kernels take):
+      // (1) per strip: span of the batch inside the caller's buffer (lib/align.cu:80-93 takes it from the first/last record;
+      // scanning is robust to any record order), longest sequence, packed bytes; (2) per strip, from the prefix of those
+      // sizes: the packed offsets, written into the caller's metadata like the reference (lib/align.cu:103-115,363-377),
+      // relative to the batch -- wfagpu_amd_fill_packed_offsets' assignment -- and, when the batch is packed on the host,
+      // the words themselves.
+      const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)prep_threads, n, std::max(n >> 15, slice_bytes / std::max<size_t>(1, n_all) * n >> 22) + 1}));
+      struct Strip { size_t lo = SIZE_MAX, hi = 0, bytes = 0; unsigned max_len = 0; };
+      std::vector<Strip> strip(nt);
+      auto words = [](size_t len) { return (len + 15) / 16 + 1; };
+      parallel_for(nt, [&](unsigned t) {
+        Strip st;
+        const size_t j1 = b.from + n * (t + 1) / nt;
+        for (size_t j = b.from + n * t / nt; j < j1; ++j) {
+          const sequence_pair_t& m = a.meta[j];
+          st.lo = std::min(st.lo, std::min(m.pattern_offset, m.text_offset));
+          st.hi = std::max(st.hi, std::max(m.pattern_offset + m.pattern_len, m.text_offset + m.text_len));
+          st.max_len = std::max(st.max_len, (unsigned)std::max(m.pattern_len, m.text_len));
+          st.bytes += 4 * (words(m.pattern_len) + words(m.text_len));
+        }
+        strip[t] = st;
+      });
+      size_t lo = SIZE_MAX, hi = 0, packed_bytes = 0;
       unsigned max_len = 0;
-      for (size_t j = b.from; j < b.to; ++j) {
-        const sequence_pair_t& m = a.meta[j];
-        lo = std::min(lo, std::min(m.pattern_offset, m.text_offset));
-        hi = std::max(hi, std::max(m.pattern_offset + m.pattern_len, m.text_offset + m.text_len));
-        max_len = std::max(max_len, std::max(m.pattern_len, m.text_len));
+      std::vector<size_t> strip_off(nt);
+      for (unsigned t = 0; t < nt; ++t) {
+        lo = std::min(lo, strip[t].lo); hi = std::max(hi, strip[t].hi); max_len = std::max(max_len, strip[t].max_len);
+        strip_off[t] = packed_bytes; packed_bytes += strip[t].bytes;
       }
       lo &= ~(size_t)3;
       hi = std::min(a.seq_bytes, (hi + 4) & ~(size_t)3);
       b.lo = lo; b.span = hi > lo ? hi - lo : 0; b.max_len = max_len;
-      // packed offsets: written into the caller's metadata like the reference
-      // (lib/align.cu:103-115,363-377), relative to the batch
-      b.packed_bytes = wfagpu_amd_fill_packed_offsets(a.meta + b.from, n);
+      b.packed_bytes = packed_bytes;
+      uint32_t* stage = nullptr;
+      double tp0 = 0;
       if (host_pack) {
-        const double tp0 = now_ms();
+        tp0 = now_ms();
         // (the staging buffer last carried batch i - STAGE_RING: its copy must have left the host)
         if (i >= STAGE_RING) {
           if (!fl.wait(uploaded, i - STAGE_RING)) return;
@@ -469,18 +489,14 @@ int run_device(const CallArgs& a, Shard& sh) {
           hs.p = static_cast<uint32_t*>(malloc(hs.cap));
           if (!hs.p) { hs.cap = 0; LOG_ERROR("Can not allocate the packing buffer"); fl.fail(-1); return; }
         }
-        std::atomic<int> bad{0};
-        const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)pack_threads, n, (b.span >> 22) + 1}));     // (>= 4 MB of ASCII per thread)
-        parallel_for(nt, [&](unsigned t) {
-          int bd = 0;
-          const size_t j1 = b.from + n * (t + 1) / nt;
-          for (size_t j = b.from + n * t / nt; j < j1 && !bd; ++j) {
-            const sequence_pair_t& m = a.meta[j];
-            bd |= wfagpu_host_pack_sequence(a.seq + m.pattern_offset, (uint32_t)m.pattern_len, hs.p + (m.pattern_offset_packed >> 2));
-            bd |= wfagpu_host_pack_sequence(a.seq + m.text_offset, (uint32_t)m.text_len, hs.p + (m.text_offset_packed >> 2));
-          }
-          if (bd) bad.store(1);
-        });
+        stage = hs.p;
+      }
+      std::atomic<int> bad{0};
+      parallel_for(nt, [&](unsigned t) {
+        const size_t j0 = b.from + n * t / nt, j1 = b.from + n * (t + 1) / nt;
+        if (wfagpu_host_pack_strip(a.seq, a.seq_bytes, a.meta + j0, j1 - j0, strip_off[t], stage)) bad.store(1);
+      });
+      if (host_pack) {
         // (a byte outside ACGT: those pairs need their ASCII on the device, the whole batch goes up as it is)
         b.host_packed = bad.load() == 0;
         t_prep_thread.pack += now_ms() - tp0;
@@ -615,7 +631,7 @@ int run_device(const CallArgs& a, Shard& sh) {
         }
       };
       // strips of consecutive pairs per thread
-      const unsigned nt = a.cigar ? (unsigned)std::min<size_t>(std::min(8u, lane_threads), (n + 8191) / 8192) : 1u;
+      const unsigned nt = (unsigned)std::min<size_t>(std::min(8u, lane_threads), a.cigar ? (n + 8191) / 8192 : (n + 131071) / 131072);
       parallel_for(std::max(1u, nt), [&](unsigned t) { work(n * t / std::max(1u, nt), n * (t + 1) / std::max(1u, nt)); });
       t_scat[k].scatter += now_ms() - t0;
       if (bad.load()) { fl.fail(-1); return; }

@@ -63,8 +63,10 @@ static int pack_scalar(const unsigned char* src, uint32_t from, uint32_t len, ui
 }
 
 #if defined(__x86_64__)
+/* `avail` >= len: bytes that may be READ from src (the caller's buffer goes on that far): lets the last, partial 32 bytes
+ * go through the vector path too -- short reads are mostly tail */
 __attribute__((target("avx2")))
-static int pack_avx2(const unsigned char* src, uint32_t len, uint32_t* dst) {
+static int pack_avx2(const unsigned char* src, uint32_t len, size_t avail, uint32_t* dst) {
     const __m256i table = _mm256_setr_epi8('A', 'C', 'T', 'G', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
                                            'A', 'C', 'T', 'G', 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
     const __m256i three = _mm256_set1_epi8(3);
@@ -84,20 +86,77 @@ static int pack_avx2(const unsigned char* src, uint32_t len, uint32_t* dst) {
         dst[(i >> 4)] = (uint32_t)_mm256_cvtsi256_si32(g);
         dst[(i >> 4) + 1] = (uint32_t)_mm256_extract_epi32(g, 4);
     }
+    const uint32_t r = len - full;
+    if (r != 0 && avail >= (size_t)full + 32) {
+        /* the bytes past the end count as 'A' */
+        static const unsigned char keep_tab[64] = {0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF,
+                                                   0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF, 0xFF};
+        const __m256i keep = _mm256_loadu_si256((const __m256i*)(keep_tab + 32 - r));
+        const __m256i x = _mm256_blendv_epi8(_mm256_set1_epi8('A'), _mm256_loadu_si256((const __m256i*)(src + full)), keep);
+        const __m256i c = _mm256_and_si256(_mm256_srli_epi16(x, 1), three);
+        ok = _mm256_and_si256(ok, _mm256_cmpeq_epi8(_mm256_shuffle_epi8(table, c), x));
+        const __m256i g = _mm256_shuffle_epi8(_mm256_madd_epi16(_mm256_maddubs_epi16(c, mul1), mul2), gather);
+        uint32_t* out = dst + (full >> 4);
+        out[0] = (uint32_t)_mm256_cvtsi256_si32(g);
+        if (r > 16) { out[1] = (uint32_t)_mm256_extract_epi32(g, 4); out[2] = 0; }
+        else out[1] = 0;
+        return _mm256_movemask_epi8(ok) != -1;
+    }
     int bad = _mm256_movemask_epi8(ok) != -1;
     return bad | pack_scalar(src, full, len, dst);
 }
 #endif
 
-int wfagpu_host_pack_sequence(const char* src, uint32_t len, uint32_t* dst) {
+static int have_avx2(void) {
 #if defined(__x86_64__)
     static int have = -1;
-    if (have < 0) have = __builtin_cpu_supports("avx2");
-    if (have) return pack_avx2((const unsigned char*)src, len, dst);
+    if (have < 0) have = __builtin_cpu_supports("avx2") ? 1 : 0;
+    return have;
+#else
+    return 0;
+#endif
+}
+
+int wfagpu_host_pack_sequence(const char* src, uint32_t len, uint32_t* dst) {
+#if defined(__x86_64__)
+    if (have_avx2()) return pack_avx2((const unsigned char*)src, len, len, dst);
 #endif
     return pack_scalar((const unsigned char*)src, 0, len, dst);
 }
 
 int wfagpu_host_pack_sequence_scalar(const char* src, uint32_t len, uint32_t* dst) {
     return pack_scalar((const unsigned char*)src, 0, len, dst);
+}
+
+/* A strip of records: assigns the packed offsets from first_off on (wfagpu_amd_fill_packed_offsets' assignment) and, with a
+ * staging buffer, packs the sequences there (until the first byte outside ACGT: the batch then goes up as ASCII). */
+int wfagpu_host_pack_strip(const char* seq, size_t seq_bytes, sequence_pair_t* meta, size_t n, size_t first_off, uint32_t* stage) {
+    int bad = 0;
+    size_t off = first_off;
+    const int vec = have_avx2();
+    for (size_t j = 0; j < n; ++j) {
+        sequence_pair_t* m = &meta[j];
+        const size_t po = m->pattern_offset, to = m->text_offset;
+        const uint32_t pl = (uint32_t)m->pattern_len, tl = (uint32_t)m->text_len;
+        m->pattern_offset_packed = off;
+        if (stage && !bad) {
+#if defined(__x86_64__)
+            if (vec) bad |= pack_avx2((const unsigned char*)seq + po, pl, po <= seq_bytes ? seq_bytes - po : pl, stage + (off >> 2));
+            else
+#endif
+                bad |= pack_scalar((const unsigned char*)seq + po, 0, pl, stage + (off >> 2));
+        }
+        off += 4 * (((size_t)pl + 15) / 16 + 1);
+        m->text_offset_packed = off;
+        if (stage && !bad) {
+#if defined(__x86_64__)
+            if (vec) bad |= pack_avx2((const unsigned char*)seq + to, tl, to <= seq_bytes ? seq_bytes - to : tl, stage + (off >> 2));
+            else
+#endif
+                bad |= pack_scalar((const unsigned char*)seq + to, 0, tl, stage + (off >> 2));
+        }
+        off += 4 * (((size_t)tl + 15) / 16 + 1);
+    }
+    (void)vec;
+    return bad;
 }

@@ -238,6 +238,7 @@ struct DevState {
   Lane lane[MAX_LANES];
   wfagpu_amd_tuning_t tuning{};                // what the contexts were created with
   size_t arena_limit_cfg = 0;
+  size_t free_at_creation = 0, total_mem = 0;  // device memory when the slot was set up (the lanes' arena caps are shares of it)
 };
 DevState g_dev[MAX_DEV];
 std::mutex g_dev_mu[MAX_DEV];   // one per slot: the devices of a call run concurrently
@@ -267,8 +268,8 @@ void release_dev(DevState& d) {
   d.device = -1;
 }
 
-// The cached state of `slot`, with at least `lanes` compute lanes, for `device`.
-int acquire_dev(int slot, int device, int lanes, int sharers, const wfagpu_amd_launch_config_t& cfg, DevState** out) {
+// The cached state of `slot` for `device` (its lanes are created by the threads that run them: make_lane).
+int acquire_dev(int slot, int device, const wfagpu_amd_launch_config_t& cfg, DevState** out) {
   if (slot < 0 || slot >= MAX_DEV) return -1;
   DevState& d = g_dev[slot];
   if (d.device >= 0 && (d.device != device || memcmp(&d.tuning, &cfg.tuning, sizeof(d.tuning)) != 0 || d.arena_limit_cfg != cfg.arena_limit_bytes))
@@ -279,31 +280,35 @@ int acquire_dev(int slot, int device, int lanes, int sharers, const wfagpu_amd_l
     d.tuning = cfg.tuning;
     d.arena_limit_cfg = cfg.arena_limit_bytes;
     HIP_OK(hipStreamCreateWithFlags(&d.up, hipStreamNonBlocking));
-  }
-  for (int k = 0; k < lanes; ++k) {
-    Lane& l = d.lane[k];
-    if (l.ctx) continue;
-    wfagpu_amd_config_t c{};
-    c.device = device;
-    c.tuning = cfg.tuning;
-    // The backtrace arena is kept between calls.  Its cap starts at 4 GiB -- fresh device memory costs ~33 ms per GiB at
-    // first touch, and a batch that needs more simply runs in several passes -- and grows after every call that needed
-    // several passes (a long-lived process ends up with one pass per call).  All lanes of all slots of a device
-    // together never claim more than half of the memory that is free when they are created.
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)16 << 30;
-    const size_t share = free_b / 2 / (size_t)std::max(1, sharers * lanes);
-    if (cfg.arena_limit_bytes) {
-      c.arena_limit_bytes = cfg.arena_limit_bytes;      // fixed cap
-      c.arena_limit_max_bytes = 0;
-    } else {
-      c.arena_limit_bytes = std::min<size_t>((size_t)4 << 30, std::max<size_t>(share, (size_t)64 << 20));
-      c.arena_limit_max_bytes = std::max<size_t>(c.arena_limit_bytes, std::min<size_t>((size_t)32 << 30, share));
-    }
-    if (wfagpu_amd_create(&l.ctx, &c)) return -1;
-    HIP_OK(hipStreamCreateWithFlags(&l.down, hipStreamNonBlocking));
+    if (hipMemGetInfo(&d.free_at_creation, &d.total_mem) != hipSuccess) d.free_at_creation = (size_t)16 << 30;
   }
   *out = &d;
+  return 0;
+}
+
+// Lane k of a device, created on first use by the thread that is about to run it -- a lane is three HSA queues' worth of
+// streams, ~15 ms; a cold call's lanes come up side by side, under the packing and the upload of the first batches, and
+// the first one that is ready takes the first batch.
+int make_lane(DevState& d, int k, int lanes, int sharers, const wfagpu_amd_launch_config_t& cfg) {
+  Lane& l = d.lane[k];
+  if (l.ctx) return 0;
+  wfagpu_amd_config_t c{};
+  c.device = d.device;
+  c.tuning = cfg.tuning;
+  // The backtrace arena is kept between calls.  Its cap starts at 4 GiB -- fresh device memory costs ~33 ms per GiB at
+  // first touch, and a batch that needs more simply runs in several passes -- and grows after every call that needed
+  // several passes (a long-lived process ends up with one pass per call).  All lanes of all slots of a device
+  // together never claim more than half of the memory that was free when the slot was created.
+  const size_t share = d.free_at_creation / 2 / (size_t)std::max(1, sharers * std::max(lanes, MAX_LANES - 1));
+  if (cfg.arena_limit_bytes) {
+    c.arena_limit_bytes = cfg.arena_limit_bytes;      // fixed cap
+    c.arena_limit_max_bytes = 0;
+  } else {
+    c.arena_limit_bytes = std::min<size_t>((size_t)4 << 30, std::max<size_t>(share, (size_t)64 << 20));
+    c.arena_limit_max_bytes = std::max<size_t>(c.arena_limit_bytes, std::min<size_t>((size_t)32 << 30, share));
+  }
+  if (wfagpu_amd_create(&l.ctx, &c)) return -1;
+  HIP_OK(hipStreamCreateWithFlags(&l.down, hipStreamNonBlocking));
   return 0;
 }
 
@@ -389,7 +394,7 @@ int run_device(const CallArgs& a, Shard& sh) {
   K = std::max(1, std::min({K, MAX_LANES, nb}));
 
   DevState* dp = nullptr;
-  if (acquire_dev(sh.slot, sh.device, K, sh.sharers, a.cfg, &dp)) return -1;
+  if (acquire_dev(sh.slot, sh.device, a.cfg, &dp)) return -1;
   DevState& d = *dp;
   HIP_OK(hipSetDevice(sh.device));
   const double t_created = now_ms();
@@ -644,6 +649,7 @@ int run_device(const CallArgs& a, Shard& sh) {
   // ---- stage 2: the kernels + D2H, K lanes on alternate batches ----------------------------------------------------------
   auto compute_lane = [&](int k) -> int {
     HIP_OK(hipSetDevice(sh.device));
+    if (make_lane(d, k, K, sh.sharers, a.cfg)) return -1;
     Lane& L = d.lane[k];
     std::vector<int> mine;
     for (int j = 0;; ++j) {

@@ -41,3 +41,23 @@ if cp:
     by = collections.Counter(); byb = collections.Counter()
     for s, e, dr, sz in c2: by[dr] += e - s; byb[dr] += sz
     for k in by: print("  copies %s: %.2f ms busy, %.1f MB" % (k, by[k] / 1e6, byb[k] / 1e6))
+# how much of the backtrace (walk / emit / compact / wave-trace kernels) ran UNDER a wavefront kernel of another batch
+def union(iv):
+    iv = sorted(iv); out = []
+    for s, e in iv:
+        if out and s <= out[-1][1]: out[-1][1] = max(out[-1][1], e)
+        else: out.append([s, e])
+    return out
+def inter(a, b):
+    i = j = 0; tot = 0
+    while i < len(a) and j < len(b):
+        s = max(a[i][0], b[j][0]); e = min(a[i][1], b[j][1])
+        if e > s: tot += e - s
+        if a[i][1] < b[j][1]: i += 1
+        else: j += 1
+    return tot
+al = union([(s, e) for s, e, k, _ in sel if "wfa_align_kernel" in k or "wfa_short" in k])
+tr = union([(s, e) for s, e, k, _ in sel if any(t in k for t in ("wfa_walk", "wfa_emit", "wfa_text_compact", "wfa_trace"))])
+tr_tot = sum(e - s for s, e in tr)
+if tr_tot:
+    print("backtrace kernels busy (union) %.2f ms, of which %.2f ms (%.0f %%) under a wavefront kernel of another batch" % (tr_tot / 1e6, inter(al, tr) / 1e6, 100.0 * inter(al, tr) / tr_tot))

@@ -56,6 +56,29 @@ def _cigar(text, off, ln, i):
     return text[o:o + int(ln[i])].decode()
 
 
+def _launch(buf, meta, max_error, **launch_cfg):
+    """launch_alignments() on host buffers (one batch = the whole call, as the CLI's default): scores, CIGAR strings, stats."""
+    import ctypes as C
+    lib = wfagpu.load()
+    n = len(meta)
+    res = C.POINTER(wfagpu.AlignmentResult)()
+    assert lib.initialize_wfa_results(C.byref(res), n, 256)
+    opt = wfagpu.Options(max_error=max_error, threads_per_block=64, num_workers=0, band=-1, batch_size=n, num_alignments=n,
+                         penalties=wfagpu.Penalties(*PEN), compute_cigar=True)
+    wfagpu.configure_launch(**launch_cfg)
+    m2 = meta.copy()
+    try:
+        lib.launch_alignments(buf.ctypes.data, buf.nbytes, m2.ctypes.data, res, opt, False)
+        st = wfagpu.last_launch_stats()
+        scores = np.array([res[i].error for i in range(n)], dtype=np.int64)
+        cigars = [C.string_at(res[i].cigar.buffer).decode() for i in range(n)]
+    finally:
+        lib.destroy_wfa_results(res, n)
+        wfagpu.configure_launch()
+        lib.wfagpu_amd_release_cache()
+    return scores, cigars, st
+
+
 @pytest.mark.parametrize("arena_limit_gib", [0, 2])
 def test_cfg3_full_size_every_budget_miss_and_every_pass(arena_limit_gib):
     n = 1_000_000
@@ -111,6 +134,14 @@ def test_cfg4_full_size_scores_and_cigars(band):
     for i in range(n):
         ok, cost = oracle_lib.check_cigar(pairs[i][0], pairs[i][1], _cigar(text, off, ln, i), PEN)
         assert ok and cost == scores[i], i
+    if band is None:
+        # the same pairs host to host: a call of few long reads (330 MB) is pipelined in batches of >= 8192 pairs, with the
+        # sequences packed on the host or going up as ASCII -- every score and every CIGAR string as from the resident batch
+        for host_pack in (1, -1):
+            s2, c2, lst = _launch(buf, meta, 3000, host_pack=host_pack)
+            assert lst["batches"] == 2 and lst["host_packed_batches"] == (2 if host_pack > 0 else 0)
+            assert np.array_equal(s2, scores)
+            assert c2 == [_cigar(text, off, ln, i) for i in range(n)]
 
 
 def test_cfg5_full_size_scores_and_cigars():

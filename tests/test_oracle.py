@@ -193,6 +193,26 @@ def test_host_pack_strip_offsets_and_words():
     assert np.array_equal(m3["text_offset_packed"], want_meta["text_offset_packed"])      # (the offsets are assigned to the end)
 
 
+def test_host_packer_under_address_sanitizer(tmp_path):
+    """utils/host_pack.c built with -fsanitize=address,undefined (CPU build: the GPU pool has no sanitizers) against
+    tests/host_pack_asan.c: records in heap buffers of exactly the bytes they need, so the vector path's 32-byte loads near
+    the end of the caller's buffer and the stores around every sequence's last word land in red zones if they stray."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "host_pack_asan")
+    cc = subprocess.run(["gcc", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-I", os.path.join(root, "include"),
+                         os.path.join(root, "tests", "host_pack_asan.c"), os.path.join(root, "wfa-gpu_amd", "utils", "host_pack.c"), "-o", exe],
+                        capture_output=True, text=True)
+    if cc.returncode != 0 and "sanitize" in cc.stderr:
+        pytest.skip("this gcc has no sanitizer runtime")
+    assert cc.returncode == 0, cc.stderr
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0 and "host_pack_asan ok" in run.stdout, run.stdout + run.stderr
+
+
 def test_oracle_pack_layout():
     """Bit layout of this build's packing: code=(c&6)>>1 (A0 C1 T2 G3, as tests/test_packing_kernel.cu:31 of the
     reference decodes it), base i in bits 2*(i%16) of word i//16."""

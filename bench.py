@@ -413,6 +413,7 @@ def main():
     al.close()
     del batch
     torch.cuda.empty_cache()
+    torch.cuda.synchronize()      # (the resident leg's device memory is back with the driver before the host-to-host leg starts)
     if rank == 0 and world == 1:
         if not args.no_host_to_host:
             try:

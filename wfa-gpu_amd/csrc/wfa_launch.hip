@@ -268,6 +268,17 @@ void release_dev(DevState& d) {
   d.device = -1;
 }
 
+// The copy streams (one up per device, one down per lane) are created with the highest priority the device offers: the
+// runtime keeps a pool of hardware queues per priority level and maps the streams of a level onto its few queues round
+// robin -- seven streams of one level had two compute lanes sharing a queue (their kernels then run one after the other), and
+// which two depended on what else the process had created before (torch's streams: bench.py saw 37.5 ms where a fresh
+// process saw 35.0).  With the copies in a pool of their own the lanes' streams get a queue each.
+hipError_t copy_stream(hipStream_t* s) {
+  int least = 0, greatest = 0;
+  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || greatest == least) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+  return hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest);
+}
+
 // The cached state of `slot` for `device` (its lanes are created by the threads that run them: make_lane).
 int acquire_dev(int slot, int device, const wfagpu_amd_launch_config_t& cfg, DevState** out) {
   if (slot < 0 || slot >= MAX_DEV) return -1;
@@ -279,7 +290,7 @@ int acquire_dev(int slot, int device, const wfagpu_amd_launch_config_t& cfg, Dev
     d.device = device;
     d.tuning = cfg.tuning;
     d.arena_limit_cfg = cfg.arena_limit_bytes;
-    HIP_OK(hipStreamCreateWithFlags(&d.up, hipStreamNonBlocking));
+    HIP_OK(copy_stream(&d.up));
     if (hipMemGetInfo(&d.free_at_creation, &d.total_mem) != hipSuccess) d.free_at_creation = (size_t)16 << 30;
   }
   *out = &d;
@@ -308,7 +319,7 @@ int make_lane(DevState& d, int k, int lanes, int sharers, const wfagpu_amd_launc
     c.arena_limit_max_bytes = std::max<size_t>(c.arena_limit_bytes, std::min<size_t>((size_t)32 << 30, share));
   }
   if (wfagpu_amd_create(&l.ctx, &c)) return -1;
-  HIP_OK(hipStreamCreateWithFlags(&l.down, hipStreamNonBlocking));
+  HIP_OK(copy_stream(&l.down));
   return 0;
 }
 

@@ -191,6 +191,10 @@ def test_host_pack_strip_offsets_and_words():
     words = np.zeros(total // 4 + 8, dtype=np.uint32)
     assert lib.wfagpu_host_pack_strip(dbuf.ctypes.data, dbuf.nbytes, m3.ctypes.data, len(m3), 0, words.ctypes.data) == 1
     assert np.array_equal(m3["text_offset_packed"], want_meta["text_offset_packed"])      # (the offsets are assigned to the end)
+    # a record that points outside the caller's buffer is flagged, not read
+    m4 = meta.copy()
+    m4[5]["text_offset"] = buf.nbytes + 1000
+    assert lib.wfagpu_host_pack_strip(buf.ctypes.data, buf.nbytes, m4.ctypes.data, len(m4), 0, words.ctypes.data) == 1
 
 
 def test_host_packer_under_address_sanitizer(tmp_path):

@@ -139,6 +139,8 @@ int wfagpu_host_pack_strip(const char* seq, size_t seq_bytes, sequence_pair_t* m
         const size_t po = m->pattern_offset, to = m->text_offset;
         const uint32_t pl = (uint32_t)m->pattern_len, tl = (uint32_t)m->text_len;
         m->pattern_offset_packed = off;
+        /* (a record that points outside the caller's buffer is not touched here: the batch goes up as it is) */
+        if (po > seq_bytes || pl > seq_bytes - po || to > seq_bytes || tl > seq_bytes - to) bad = 1;
         if (stage && !bad) {
 #if defined(__x86_64__)
             if (vec) bad |= pack_avx2((const unsigned char*)seq + po, pl, po <= seq_bytes ? seq_bytes - po : pl, stage + (off >> 2));

@@ -104,6 +104,16 @@ typedef struct {
 int wfagpu_amd_create(wfagpu_amd_ctx_t** ctx, const wfagpu_amd_config_t* cfg);
 void wfagpu_amd_destroy(wfagpu_amd_ctx_t* ctx);
 
+/* Device buffers a context outgrows DURING a call are kept aside instead of freed there (hipFree waits for the whole
+ * device to go idle: with other contexts' kernels running it stalls the caller for milliseconds); they are freed by
+ * wfagpu_amd_destroy, by a later call once they add up to 1 GiB, or here -- call it when the device is idle. */
+void wfagpu_amd_trim(wfagpu_amd_ctx_t* ctx);
+
+/* Loads the code objects of every kernel family on the context's device (one empty launch each on its stream; the
+ * runtime loads a code object at the first launch of any of its kernels, 5-25 ms): a cold caller does this while it
+ * waits for its first upload.  Returns without synchronising.  0 on success. */
+int wfagpu_amd_prime(wfagpu_amd_ctx_t* ctx);
+
 /* The HIP stream (hipStream_t) the context runs on -- its own, or the one given at creation. */
 void* wfagpu_amd_stream(const wfagpu_amd_ctx_t* ctx);
 
@@ -174,6 +184,10 @@ typedef struct {
                                  1: always, -1: never (ASCII goes up, the pack kernel runs).  A batch holding a byte outside
                                  ACGT always goes up as ASCII                                                           */
     int host_pack_threads;    /* threads packing a batch (0: three quarters of a device's share of the host threads, 2..12)         */
+    int bring_up;             /* 0: the first device query of the process (get_num_cuda_devices, get_cuda_SM_count -- what the CLI
+                                 and wfagpu_set_default_options call before any alignment) starts bringing the devices up in
+                                 a background thread: streams, lanes, code objects (wfagpu_amd_warmup); -1: never -- set it
+                                 before the first query                                                                  */
 } wfagpu_amd_launch_config_t;
 
 /* NULL: back to the defaults.  Changing `tuning` or `arena_limit_bytes` drops the cached per-device state. */
@@ -208,6 +222,12 @@ void wfagpu_amd_set_num_devices(int n);
  * of its batch lines, summed).  The reference only prints them (lib/align.cu:318-326); the CLI turns a non-zero value
  * into a non-zero exit code. */
 long wfagpu_amd_check_failures(void);
+
+/* Starts bringing every visible device up in the background (upload/download streams, three lanes, code objects: what a
+ * cold launch_alignments* call otherwise does under its first batches, ~100 ms): returns at once, a call that follows
+ * waits only for what is still missing.  Called by the first device query of the process unless
+ * wfagpu_amd_launch_config_t::bring_up is -1. */
+void wfagpu_amd_warmup(void);
 
 /* launch_alignments* keep their per-device state (context, backtrace arena,
  * input buffers, pinned result staging) for the next call of the process:

@@ -125,6 +125,31 @@ def test_reference_examples_compile_unchanged(lib, src, cc):
     assert os.path.exists(exe)
 
 
+@pytest.mark.skipif(not os.path.isdir("/root/reference/tools"), reason="reference tree absent")
+def test_reference_cli_links_against_this_library(lib, tmp_path):
+    """INTEGRATION.md section B as a test: the reference's OWN CLI objects -- tools/aligner.c, utils/sequence_reader.c,
+    utils/arg_handler.c, read where they lie, compiled with the reference's own headers -- link against libwfagpu.so with
+    nothing left undefined, and every symbol they import from it is one include/wfa_gpu_abi.h declares.  (The same link is
+    what oracle/Makefile keeps as oracle/_ref/ref.wfa.affine.gpu for the GPU suite to run.)"""
+    pkg = os.path.dirname(wfagpu.LIB_PATH)
+    exe = str(tmp_path / "ref_cli")
+    ref = "/root/reference"
+    subprocess.run(["gcc", "-O1", "-fopenmp", "-w", f"-I{ref}", f"-I{ref}/lib", f"{ref}/tools/aligner.c", f"{ref}/utils/sequence_reader.c",
+                    f"{ref}/utils/arg_handler.c", "-o", exe, f"-L{pkg}", "-lwfagpu", f"-Wl,-rpath,{pkg}", "-Wl,--no-undefined", "-lm"], check=True)
+    und = subprocess.run(["nm", "-D", "--undefined-only", exe], capture_output=True, text=True, check=True).stdout.split()
+    exported = set(subprocess.run(["nm", "-D", "--defined-only", wfagpu.LIB_PATH], capture_output=True, text=True, check=True).stdout.split())
+    from_lib = sorted(sym for sym in und if sym in exported and not sym.startswith("_"))
+    assert set(from_lib) == {"launch_alignments", "launch_alignments_distance", "get_num_cuda_devices", "get_cuda_dev_name",
+                             "get_cuda_capability", "get_cuda_SM_count", "initialize_wfa_results", "destroy_wfa_results"}, from_lib
+    abi = open(os.path.join(ROOT, "include", "wfa_gpu_abi.h")).read()
+    assert all(sym in abi for sym in from_lib)
+    # it starts, asks this library for the devices and (no GPU here) leaves the way the reference does
+    r = subprocess.run([exe, "-i", os.path.join(ROOT, "tests", "golden", "wfa.utest.seq")], capture_output=True, text=True, timeout=120)
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and "No CUDA devices detected" in r.stderr
+
+
 def test_device_header_structs_match_the_python_mirrors():
     """include/wfa_gpu_device.h as the C compiler sees it against the ctypes mirrors in bindings/wfagpu.py: a field added on
     one side only would shift everything behind it (tuning switches, launch configuration, stage times, statistics)."""

@@ -107,6 +107,44 @@ def test_cli_cigar_check_and_fasta(golden_dir, tmp_path):
     assert open(out1).read() == open(out2).read() == open(os.path.join(golden_dir, "hifi.g231.alg")).read()
 
 
+REF_CLI = os.path.join(os.path.dirname(PKG), "oracle", "_ref", "ref.wfa.affine.gpu")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_CLI), reason="oracle/_ref/ref.wfa.affine.gpu was not built (reference tree absent at build time)")
+def test_reference_cli_binary_runs_on_this_library(golden_dir, tmp_path):
+    """The reference's own CLI (tools/aligner.c + utils/sequence_reader.c + utils/arg_handler.c of the reference, unmodified,
+    compiled with the reference's headers by oracle/Makefile) running on libwfagpu.so: tests/test-aligner.sh's command
+    lines against the reference's golden score files, -x against WFA2's score + CIGAR goldens, paired FASTA with -c (its
+    own test-fasta.sh), multi-batch, and the same output as this build's CLI."""
+    def ref_cli(args):
+        r = subprocess.run([REF_CLI] + args, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return r
+    seq = os.path.join(golden_dir, "wfa.utest.seq")
+    for tag, pen in (("p0", "1,2,1"), ("p1", "3,1,4"), ("p2", "5,3,2")):
+        out = tmp_path / f"ref_{tag}.out"
+        r = ref_cli(["-i", seq, "-g", pen, "-e", "10000", "-b", "100", "-o", str(out)])
+        assert "Alignment computed. Wall time:" in r.stdout
+        assert [ln.split("\t")[0] for ln in open(out).read().splitlines()] == open(os.path.join(golden_dir, f"utest.score.affine.{tag}.alg")).read().split()
+        outx, mine = tmp_path / f"ref_{tag}.x.out", tmp_path / f"mine_{tag}.x.out"
+        ref_cli(["-i", seq, "-g", pen, "-e", "10000", "-x", "-o", str(outx)])
+        assert open(outx).read() == open(os.path.join(golden_dir, f"utest.affine.{tag}.alg")).read()
+        _run_cli(["-i", seq, "-g", pen, "-e", "10000", "-x", "-o", str(mine)])
+        assert open(outx).read() == open(mine).read()
+    # long reads from paired FASTA files, -x -c, batches of 5 (the reference's tests/test-fasta.sh greps the same line)
+    pairs = wfagpu.read_seq_file(os.path.join(golden_dir, "hifi.seq"))
+    q, t = _fasta_files(tmp_path, pairs)
+    # (no -o: in FASTA mode the reference's writer reads the unused .seq reader's arrays and crashes -- SURVEY.md Appendix C,
+    # tools/aligner.c:497-501; its own test-fasta.sh runs without -o too.  The scores and CIGARs it was handed are checked by -c.)
+    for extra in (["-x", "-c", "-b", "5"], ["-c"], ["-g", "5,2,5", "-b", "11", "-c"]):
+        r = ref_cli(["-Q", str(q), "-T", str(t)] + extra)
+        counts = [(int(c), int(b)) for c, b in __import__("re").findall(r"correct=(\d+) Incorrect=(\d+)", r.stderr)]
+        assert counts and sum(c for c, _ in counts) == len(pairs) and all(b == 0 for _, b in counts), r.stderr[-800:]
+    out2 = tmp_path / "ref_hifi.out"
+    ref_cli(["-i", os.path.join(golden_dir, "hifi.seq"), "-x", "-o", str(out2)])
+    assert open(out2).read() == open(os.path.join(golden_dir, "hifi.g231.alg")).read()
+
+
 def test_examples_run():
     subprocess.run(["make", "-C", os.path.join(PKG, "examples")], check=True, capture_output=True)
     out = subprocess.run([os.path.join(PKG, "examples", "quickstart")], capture_output=True, text=True, check=True).stdout

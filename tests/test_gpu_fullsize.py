@@ -1,5 +1,8 @@
-"""BASELINE.json configs[2], [3] and [4] at FULL size through the C-ABI (wfagpu_amd_align_device), compared with the
+"""BASELINE.json configs[1], [2], [3] and [4] at FULL size through the C-ABI (wfagpu_amd_align_device), compared with the
 reference's WFA2 (oracle/_ref, or the C restatement when that is not there):
+
+  configs[1]  100k x 150 bp @ 2 %, SCORE-ONLY, max_error 45 -- exactly what `bench.py --workload cfg2` times: the
+              several-alignments-per-wavefront tier (short_kernel.hip), every one of the 100 000 scores;
 
   configs[2]  1M x 1 kbp @ 5 %: scores AND CIGAR strings on a 100k-pair stratified sample that contains EVERY pair that
               missed its auto-tuned budget (the re-run path) -- once with the arena the library picks, once with an arena
@@ -77,6 +80,34 @@ def _launch(buf, meta, max_error, **launch_cfg):
         wfagpu.configure_launch()
         lib.wfagpu_amd_release_cache()
     return scores, cigars, st
+
+
+def test_cfg2_full_size_score_only_as_benched():
+    """configs[1] in its own mode at its own size: score-only, max_error 45 (the CLI's automatic value for 150 bp reads),
+    budgets tuned on the strided sample, the whole batch on tier 5, then a second call of the same stream that inherits
+    the budgets (what the timed steps of bench.py do).  ALL scores against the checker."""
+    n = 100_000
+    buf, meta = wfagpu.generate_pairs(n, 150, 0.02, seed=1000, nthreads=_threads())
+    so, _ = _truth(buf, meta, cigar=False)
+    al = wfagpu.DeviceAligner(0)
+    try:
+        batch = al.upload(buf, meta)
+        for call in range(2):
+            d_scores, _ = al.align(batch, PEN, max_error=45, compute_cigar=False, fetch=False)
+            st = al.stats()
+            scores = d_scores.cpu().numpy()
+            assert np.array_equal(scores, so), call
+            assert st.auto_budget > 0
+            # first call: the 4096-pair sample the budgets are tuned on keeps its alignments (one-wave tier), everybody else
+            # runs on tier 5; second call (budgets inherited, the timed steps of bench.py): everybody -- but for budget
+            # misses, which the one-wave tier re-runs
+            assert st.pairs_tier[5] + st.pairs_tier[0] == n, list(st.pairs_tier)
+            assert st.pairs_tier[0] <= (4096 if call == 0 else 0) + st.pairs_budget_missed, list(st.pairs_tier)
+            assert st.pairs_tier[5] >= (n - 4096 if call == 0 else 0.99 * n), list(st.pairs_tier)
+            assert st.main_launch_tier == 5
+            al.hint_same_stream(True)
+    finally:
+        al.close()
 
 
 @pytest.mark.parametrize("arena_limit_gib", [0, 2])

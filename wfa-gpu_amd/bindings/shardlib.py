@@ -22,7 +22,10 @@ def init_distributed(backend, device=None):
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
-    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")     # (one node: the host group of rank0_exclusive needs no name lookup)
+    # (one node: the host group of rank0_exclusive needs no name lookup -- only when the rendezvous itself is on loopback:
+    # a multi-node launch must keep gloo on a routable interface)
+    if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost", "::1"):
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
     kw = {}
     if device is not None:
         kw["device_id"] = device

@@ -59,7 +59,7 @@ class LaunchConfig(C.Structure):  # wfagpu_amd_launch_config_t: all zero = autom
     _fields_ = [("num_devices", C.c_int), ("virtual_devices", C.c_int), ("lanes_per_device", C.c_int),
                 ("batches_per_device", C.c_int), ("arena_limit_bytes", C.c_size_t), ("input_pool_bytes", C.c_size_t),
                 ("numa_pin", C.c_int), ("timing", C.c_int), ("tuning", Tuning), ("host_pack", C.c_int),
-                ("host_pack_threads", C.c_int)]
+                ("host_pack_threads", C.c_int), ("bring_up", C.c_int)]
 
 
 class LaunchStats(C.Structure):  # wfagpu_amd_launch_stats_t
@@ -96,7 +96,8 @@ ABI_SYMBOLS = [
     "wfagpu_amd_create", "wfagpu_amd_destroy", "wfagpu_amd_fill_packed_offsets", "wfagpu_amd_pack_device",
     "wfagpu_amd_align_device", "wfagpu_amd_last_stats", "wfagpu_amd_set_num_devices", "wfagpu_amd_release_cache",
     "wfagpu_amd_check_failures", "wfagpu_amd_hint_same_stream", "wfagpu_amd_configure_launch",
-    "wfagpu_amd_last_launch_stats", "wfagpu_amd_set_tuning", "wfagpu_amd_stream",
+    "wfagpu_amd_last_launch_stats", "wfagpu_amd_set_tuning", "wfagpu_amd_stream", "wfagpu_amd_trim", "wfagpu_amd_prime",
+    "wfagpu_amd_warmup",
     "wfagpu_host_pack_sequence", "wfagpu_host_pack_sequence_scalar", "wfagpu_host_pack_strip",
 ]
 

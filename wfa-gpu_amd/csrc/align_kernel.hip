@@ -1449,3 +1449,8 @@ int wfa_align_max_blocks_per_cu(int tier, bool with_bt, bool raw, bool banded, s
   if (with_bt) return raw ? occ_tier<true, true>(tier, lds, wpe) : occ_tier<true, false>(tier, lds, wpe);
   return raw ? occ_tier<false, true>(tier, lds, wpe) : occ_tier<false, false>(tier, lds, wpe);
 }
+
+// Loads this translation unit's code object on the current device (the runtime loads a code object at the first launch of
+// any of its kernels: 5-25 ms each): launch_alignments* call it while a cold call waits for its first upload.
+namespace { __global__ void k_prime_align() {} }
+void wfa_prime_align(hipStream_t stream) { hipLaunchKernelGGL(k_prime_align, dim3(1), dim3(64), 0, stream); }

@@ -97,3 +97,8 @@ void wfa_launch_pack(const char* d_ascii, const WfaSeqPair* d_meta, uint32_t n_p
   hipLaunchKernelGGL(wfa_pack_kernel, dim3(grid), dim3(PACK_WAVES * 64), 0, stream,
                      d_ascii, d_meta, n_pairs, d_packed, d_flags);
 }
+
+// Loads this translation unit's code object on the current device (the runtime loads a code object at the first launch of
+// any of its kernels: 5-25 ms each): launch_alignments* call it while a cold call waits for its first upload.
+namespace { __global__ void k_prime_pack() {} }
+void wfa_prime_pack(hipStream_t stream) { hipLaunchKernelGGL(k_prime_pack, dim3(1), dim3(64), 0, stream); }

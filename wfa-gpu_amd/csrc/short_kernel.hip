@@ -193,3 +193,8 @@ void wfa_launch_short(const WfaAlignParams& p, int lanes, int grid, hipStream_t 
   if (p.x == 2 && p.oe == 4) { if (lanes == 16) launch_short<16, 2, 4>(p, grid, stream); else launch_short<32, 2, 4>(p, grid, stream); }
   else { if (lanes == 16) launch_short<16, 1, 3>(p, grid, stream); else launch_short<32, 1, 3>(p, grid, stream); }
 }
+
+// Loads this translation unit's code object on the current device (the runtime loads a code object at the first launch of
+// any of its kernels: 5-25 ms each): launch_alignments* call it while a cold call waits for its first upload.
+namespace { __global__ void k_prime_short() {} }
+void wfa_prime_short(hipStream_t stream) { hipLaunchKernelGGL(k_prime_short, dim3(1), dim3(64), 0, stream); }

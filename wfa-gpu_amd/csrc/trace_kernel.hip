@@ -809,3 +809,8 @@ void wfa_launch_trace(const WfaTraceParams& p, hipStream_t stream) {
   hipLaunchKernelGGL(wfa_emit_kernel<true>, dim3(grid), dim3(TRACE_THREADS), lds, stream, p);
   if (p.text_scratch) hipLaunchKernelGGL(wfa_text_compact_kernel, dim3(grid), dim3(TRACE_THREADS), 0, stream, p);
 }
+
+// Loads this translation unit's code object on the current device (the runtime loads a code object at the first launch of
+// any of its kernels: 5-25 ms each): launch_alignments* call it while a cold call waits for its first upload.
+namespace { __global__ void k_prime_trace() {} }
+void wfa_prime_trace(hipStream_t stream) { hipLaunchKernelGGL(k_prime_trace, dim3(1), dim3(64), 0, stream); }

@@ -144,3 +144,8 @@ void wfa_launch_trace(const WfaTraceParams& p, hipStream_t stream);
 bool wfa_short_supported(int x, int oe, int e);
 size_t wfa_short_lds_bytes(const WfaAlignParams& p, int lanes);
 void wfa_launch_short(const WfaAlignParams& p, int lanes, int grid, hipStream_t stream);
+// Code-object priming: one empty launch per kernel translation unit (see the definitions).
+void wfa_prime_pack(hipStream_t stream);
+void wfa_prime_align(hipStream_t stream);
+void wfa_prime_short(hipStream_t stream);
+void wfa_prime_trace(hipStream_t stream);

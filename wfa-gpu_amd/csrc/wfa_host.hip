@@ -46,6 +46,13 @@ static_assert(sizeof(sequence_pair_t) == sizeof(WfaSeqPair), "ABI mirror");
 
 namespace {
 
+// hipFree waits for the whole device to go idle: inside a call -- other lanes' kernels running -- a buffer that has to grow
+// would stall its lane for 4-8 ms per free (a cold call grows a dozen buffers: first the sample's sizes, then the batch's).
+// Buffers that are outgrown during a call are RETIRED instead (the context's list, named by this thread-local while a call
+// runs) and freed by wfagpu_amd_trim / wfagpu_amd_destroy, or at the start of a later call once they add up to 1 GiB.
+struct Retired { void* p; size_t bytes; };
+thread_local std::vector<Retired>* t_retire = nullptr;
+
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
@@ -71,7 +78,8 @@ struct DevBuf {
         hipFree(np);
         return -1;
       }
-      hipFree(p);
+      // (big ones -- a backtrace arena that grows between passes -- go back at once: their memory is needed)
+      if (t_retire && cap < ((size_t)256 << 20)) t_retire->push_back({p, cap}); else hipFree(p);
     }
     p = np; cap = ncap;
     return 0;
@@ -259,6 +267,10 @@ struct wfagpu_amd_ctx {
   struct SavedQ { unsigned bucket_hi; int q; int x, o, e, max_error; } saved_q[8] = {};
   static unsigned length_class(unsigned len) { unsigned c = 1; while (c < len && c < (1u << 31)) c <<= 1; return c; }
   int n_saved_q = 0;
+  std::vector<Retired> retired;      // outgrown device buffers waiting for a moment when hipFree does not stall anybody
+  size_t retired_bytes() const { size_t b = 0; for (const auto& r : retired) b += r.bytes; return b; }
+  void free_retired() { for (auto& r : retired) hipFree(r.p); retired.clear(); }
+  bool primed = false;
 };
 
 extern "C" {
@@ -311,6 +323,7 @@ void wfagpu_amd_destroy(wfagpu_amd_ctx_t* c) {
   if (!c) return;
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
+  c->free_retired();
   for (DevBuf* b : {&c->packed, &c->flags, &c->status, &c->cells, &c->bt_final, &c->list_a, &c->list_b, &c->list_c, &c->list_d, &c->list_e, &c->work_ctr, &c->sample, &c->ratio, &c->budget,
                     &c->counters, &c->arena, &c->ops, &c->text[0], &c->text[1], &c->text_scratch, &c->cig_off[0], &c->cig_off[1], &c->cig_len[0], &c->cig_len[1], &c->gring})
     b->release();
@@ -343,6 +356,27 @@ int wfagpu_amd_pack_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_batch_t* b, voi
 }
 
 void* wfagpu_amd_stream(const wfagpu_amd_ctx_t* c) { return c ? static_cast<void*>(c->stream) : nullptr; }
+
+void wfagpu_amd_trim(wfagpu_amd_ctx_t* c) {
+  if (!c || c->retired.empty()) return;
+  hipSetDevice(c->device);
+  c->free_retired();
+}
+
+int wfagpu_amd_prime(wfagpu_amd_ctx_t* c) {
+  if (!c) return -1;
+  if (c->primed) return 0;
+  HIP_TRY(hipSetDevice(c->device));
+  // one empty launch per kernel translation unit: the runtime loads a code object at the first launch of any of its kernels
+  wfa_prime_align(c->stream);
+  wfa_prime_trace(c->stream);
+  wfa_prime_pack(c->stream);
+  wfa_prime_short(c->stream);
+  LAUNCH_K(k_iota, dim3(1), dim3(64), 0, c->stream, static_cast<uint32_t*>(nullptr), 0u, 0u);      // (this file's)
+  HIP_TRY(hipGetLastError());
+  c->primed = true;
+  return 0;
+}
 
 void wfagpu_amd_set_tuning(wfagpu_amd_ctx_t* c, const wfagpu_amd_tuning_t* tuning) {
   if (c) c->tuning = tuning ? *tuning : wfagpu_amd_tuning_t{};
@@ -495,6 +529,9 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
     }
   }
   HIP_TRY(hipSetDevice(c->device));
+  // (buffers outgrown during this call are retired, not freed: see DevBuf)
+  if (c->retired_bytes() > ((size_t)1 << 30)) c->free_retired();
+  struct RetireScope { RetireScope(std::vector<Retired>* r) { t_retire = r; } ~RetireScope() { t_retire = nullptr; } } retire_scope(&c->retired);
   const uint32_t n = (uint32_t)b->num_pairs;
   c->stats = wfagpu_amd_stats_t{};
   if (d_text) *d_text = nullptr;
@@ -745,7 +782,10 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         const unsigned long long ops_bound = (unsigned long long)n_chain * (((unsigned long long)std::max<long long>(s_hi, 0) + 3ull) & ~3ull);
         const unsigned long long text_bound = (unsigned long long)n_chain *
             ((unsigned long long)item_chars * (2ull * (unsigned long long)(std::max<long long>(s_hi, 0) / std::min(pen.x, pen.e)) + 1ull) + 1ull);
-        const bool by_bound = !tp.wave_kernel && s_hi >= 0 && s_hi <= 30000 && text_bound <= ((unsigned long long)6 << 30);
+        // (the bound is sized by the chain's largest budget -- the caller's max_error once a re-run link follows -- for EVERY pair:
+        // fine for the batches of a pipelined call, whose round trips it saves (62 500 x 1 kbp pairs: 225 MB), too generous for a
+        // big resident batch (1M pairs at max_error 300: 3.6 GB of fresh device memory per buffer to save one counter read)
+        const bool by_bound = !tp.wave_kernel && s_hi >= 0 && s_hi <= 30000 && text_bound <= ((unsigned long long)768 << 20);
         unsigned long long ops_need, text_sum;
         if (by_bound) { ops_need = ops_bound + 256; text_sum = text_bound; }
         else {

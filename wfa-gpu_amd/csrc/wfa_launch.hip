@@ -212,7 +212,6 @@ int check_batch(const CallArgs& a, size_t from, size_t to, int batch_idx, unsign
 // single-threaded by contract (lib/aligner.h of the reference is not re-entrant); a mutex per slot guards the cache anyway.
 struct Lane {
   wfagpu_amd_ctx_t* ctx = nullptr;
-  hipStream_t down = nullptr;                  // D2H of this lane's results, beside the context's stream
   int32_t* d_scores[2] = {nullptr, nullptr}; size_t scores_cap[2] = {0, 0};      // (alternate like the context's CIGAR buffers)
   struct Out {
     char* text = nullptr; size_t text_cap = 0;
@@ -232,8 +231,19 @@ struct DevState {
   // 1 kbp pairs: 51 ms instead of 43), two halves of every batch on two streams: upload 38.6 -> 37.2 ms, call 43.2 -> 45.0
   // (five busy host threads on a 16-core quota).
   hipStream_t up = nullptr;
-  std::vector<hipEvent_t> up_done;             // one per batch of a call: "its copies have landed"
+  hipStream_t down = nullptr;                  // D2H of every lane's results (one stream: the copies share one PCIe direction anyway, and
+                                               // every stream of a new priority level is a hardware queue to create: ~11 ms, serialised)
+  std::vector<hipEvent_t> up_done, down_done;  // one per batch of a call: "its copies have landed"
   std::vector<InSlot> in;
+  void* d_scratch = nullptr; void* h_scratch = nullptr;      // (a few KiB each: targets of the copies that warm the copy paths up)
+  // ---- bring-up (see bring_up_fn): who creates what, in which order
+  std::mutex bring_mu;
+  std::condition_variable bring_cv;
+  std::thread bring_thread;
+  bool bring_active = false;                   // (under bring_mu)
+  std::atomic<int> prime_state{0};             // 0: code objects not loaded, 1: somebody is at it, 2: done
+  int sharers = 1;                             // slots sharing the physical device when the lanes were created (their arena caps are shares)
+  double bring_clock[MAX_LANES + 3] = {0};     // (timing: when the bring-up thread had the upload stream, lane k, the download stream: now_ms())
   HostStage stage[STAGE_RING];
   Lane lane[MAX_LANES];
   wfagpu_amd_tuning_t tuning{};                // what the contexts were created with
@@ -243,7 +253,10 @@ struct DevState {
 DevState g_dev[MAX_DEV];
 std::mutex g_dev_mu[MAX_DEV];   // one per slot: the devices of a call run concurrently
 
+void join_bring(DevState& d) { if (d.bring_thread.joinable()) d.bring_thread.join(); }
+
 void release_dev(DevState& d) {
+  join_bring(d);
   if (d.device < 0) return;
   (void)hipSetDevice(d.device);
   for (auto& in : d.in) { if (in.d_seq) (void)hipFree(in.d_seq); if (in.d_meta) (void)hipFree(in.d_meta); if (in.d_packed) (void)hipFree(in.d_packed); }
@@ -251,9 +264,14 @@ void release_dev(DevState& d) {
   for (auto& hs : d.stage) { free(hs.p); hs = HostStage{}; }
   for (auto& e : d.up_done) (void)hipEventDestroy(e);
   d.up_done.clear();
+  for (auto& e : d.down_done) (void)hipEventDestroy(e);
+  d.down_done.clear();
+  if (d.d_scratch) (void)hipFree(d.d_scratch);
+  if (d.h_scratch) (void)hipHostFree(d.h_scratch);
+  d.d_scratch = d.h_scratch = nullptr;
+  d.prime_state.store(0);
   for (auto& l : d.lane) {
     for (auto& ds : l.d_scores) if (ds) (void)hipFree(ds);
-    if (l.down) (void)hipStreamDestroy(l.down);
     for (auto& o : l.out) {
       if (o.text) (void)hipHostFree(o.text);
       if (o.off) (void)hipHostFree(o.off);
@@ -264,7 +282,8 @@ void release_dev(DevState& d) {
     l = Lane{};
   }
   if (d.up) (void)hipStreamDestroy(d.up);
-  d.up = nullptr;
+  if (d.down) (void)hipStreamDestroy(d.down);
+  d.up = d.down = nullptr;
   d.device = -1;
 }
 
@@ -279,30 +298,30 @@ hipError_t copy_stream(hipStream_t* s) {
   return hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest);
 }
 
-// The cached state of `slot` for `device` (its lanes are created by the threads that run them: make_lane).
-int acquire_dev(int slot, int device, const wfagpu_amd_launch_config_t& cfg, DevState** out) {
+// The cached state of `slot` for `device`.  Streams and lanes come up through bring_up_fn / ensure_item below.
+int acquire_dev(int slot, int device, int sharers, const wfagpu_amd_launch_config_t& cfg, DevState** out) {
   if (slot < 0 || slot >= MAX_DEV) return -1;
   DevState& d = g_dev[slot];
-  if (d.device >= 0 && (d.device != device || memcmp(&d.tuning, &cfg.tuning, sizeof(d.tuning)) != 0 || d.arena_limit_cfg != cfg.arena_limit_bytes))
+  if (d.device >= 0 && (d.device != device || d.sharers != sharers || memcmp(&d.tuning, &cfg.tuning, sizeof(d.tuning)) != 0 ||
+                        d.arena_limit_cfg != cfg.arena_limit_bytes))
     release_dev(d);
   HIP_OK(hipSetDevice(device));
   if (d.device < 0) {
     d.device = device;
+    d.sharers = sharers;
     d.tuning = cfg.tuning;
     d.arena_limit_cfg = cfg.arena_limit_bytes;
-    HIP_OK(copy_stream(&d.up));
     if (hipMemGetInfo(&d.free_at_creation, &d.total_mem) != hipSuccess) d.free_at_creation = (size_t)16 << 30;
   }
   *out = &d;
   return 0;
 }
 
-// Lane k of a device, created on first use by the thread that is about to run it -- a lane is three HSA queues' worth of
-// streams, ~15 ms; a cold call's lanes come up side by side, under the packing and the upload of the first batches, and
-// the first one that is ready takes the first batch.
-int make_lane(DevState& d, int k, int lanes, int sharers, const wfagpu_amd_launch_config_t& cfg) {
+// Lane k of a device: a context (stream, events, counters).
+int make_lane(DevState& d, int k, const wfagpu_amd_launch_config_t& cfg) {
   Lane& l = d.lane[k];
   if (l.ctx) return 0;
+  const int lanes = MAX_LANES, sharers = d.sharers;      // (every lane the slot can ever have: the caps do not depend on the call)
   wfagpu_amd_config_t c{};
   c.device = d.device;
   c.tuning = cfg.tuning;
@@ -319,8 +338,78 @@ int make_lane(DevState& d, int k, int lanes, int sharers, const wfagpu_amd_launc
     c.arena_limit_max_bytes = std::max<size_t>(c.arena_limit_bytes, std::min<size_t>((size_t)32 << 30, share));
   }
   if (wfagpu_amd_create(&l.ctx, &c)) return -1;
-  HIP_OK(copy_stream(&l.down));
   return 0;
+}
+
+// ---- bringing a device up ------------------------------------------------------------------------------------------------
+// What a cold call pays for, measured with rocprofv3 --hip-trace on the CLI (profiles/r04/coldtrace.txt): every stream of a
+// process is a hardware queue to create -- 9-35 ms each, and the creations of concurrent threads SERIALISE in the driver
+// (round 3: seven streams, 190 ms of queue creation spread over the first 90 ms of a 145 ms call) --, the first copy in
+// each direction sets the copy path up (~15 ms), the first launch from each code object loads it (~23 ms for the wavefront
+// kernels').  So (1) one D2H stream per device instead of one per lane: five queues, not seven; (2) ONE thread creates them,
+// in the order they are needed -- upload stream, lane 0, the other lanes, download stream -- while the pipeline's threads
+// wait for exactly their item (ensure_item) and the first batch is being packed; (3) the first lane that is ready loads the
+// code objects while it waits for the first upload; (4) the same thread is started in the BACKGROUND the first time the
+// process asks this library about its devices (get_num_cuda_devices & co.: the CLI does before it reads its input,
+// wfagpu_set_default_options does for the API -- the moment the reference creates its CUDA context, cudaGetDeviceCount):
+// a call that comes later finds the device up.  wfagpu_amd_release_cache() (and bench.py's cold leg) undo all of it.
+int create_up(DevState& d) {
+  if (d.up) return 0;
+  HIP_OK(copy_stream(&d.up));
+  // (the first pageable copy of a process pays ~15 ms of set-up: a small one now, not the first batch later)
+  static char warm_src[1 << 16];
+  if (!d.d_scratch) HIP_OK(hipMalloc(&d.d_scratch, sizeof(warm_src)));
+  HIP_OK(hipMemcpyAsync(d.d_scratch, warm_src, sizeof(warm_src), hipMemcpyHostToDevice, d.up));
+  return 0;
+}
+int create_down(DevState& d) {
+  if (d.down) return 0;
+  HIP_OK(copy_stream(&d.down));
+  if (!d.h_scratch) HIP_OK(hipHostMalloc(&d.h_scratch, 4096, hipHostMallocDefault));
+  if (!d.d_scratch) HIP_OK(hipMalloc(&d.d_scratch, 1 << 16));
+  HIP_OK(hipMemcpyAsync(d.h_scratch, d.d_scratch, 4096, hipMemcpyDeviceToHost, d.down));
+  return 0;
+}
+// code objects: whoever gets here first loads them (on lane k's stream), the others go on (a launch that needs a code
+// object that is still loading waits inside the runtime)
+void prime_once(DevState& d, int k) {
+  int expect = 0;
+  if (!d.lane[k].ctx || !d.prime_state.compare_exchange_strong(expect, 1)) return;
+  (void)wfagpu_amd_prime(d.lane[k].ctx);
+  d.prime_state.store(2);
+}
+// An item of the device state, created by the bring-up thread if it gets there first -- the caller then waits for exactly
+// that item --, else by the caller.
+template <typename Ready, typename Create> int ensure_item(DevState& d, Ready ready, Create create) {
+  std::unique_lock<std::mutex> l(d.bring_mu);
+  d.bring_cv.wait(l, [&] { return ready() || !d.bring_active; });
+  if (ready()) return 0;
+  return create();
+}
+void bring_up_fn(DevState* dp, wfagpu_amd_launch_config_t cfg, int lanes, bool prime) {
+  DevState& d = *dp;
+  bool ok = hipSetDevice(d.device) == hipSuccess;
+  auto step = [&](auto create) {
+    if (ok) { std::lock_guard<std::mutex> l(d.bring_mu); ok = create() == 0; }
+    d.bring_cv.notify_all();
+  };
+  step([&] { return create_up(d); });
+  d.bring_clock[0] = now_ms();
+  for (int k = 0; k < lanes; ++k) { step([&] { return make_lane(d, k, cfg); }); d.bring_clock[1 + k] = now_ms(); }
+  step([&] { return create_down(d); });
+  d.bring_clock[1 + MAX_LANES] = now_ms();
+  if (ok && prime) prime_once(d, 0);      // (background bring-up: no compute lane is waiting to do it)
+  { std::lock_guard<std::mutex> l(d.bring_mu); d.bring_active = false; }
+  d.bring_cv.notify_all();
+}
+// Starts the bring-up thread of a slot unless everything `lanes` lanes need is there already.  (g_dev_mu[slot] held.)
+void start_bring(DevState& d, const wfagpu_amd_launch_config_t& cfg, int lanes, bool prime) {
+  join_bring(d);
+  bool complete = d.up && d.down;
+  for (int k = 0; k < lanes; ++k) complete = complete && d.lane[k].ctx;
+  if (complete) return;
+  d.bring_active = true;
+  d.bring_thread = std::thread(bring_up_fn, &d, cfg, lanes, prime);
 }
 
 template <typename T> int grow_pinned(T** p, size_t want_elems) {
@@ -405,9 +494,11 @@ int run_device(const CallArgs& a, Shard& sh) {
   K = std::max(1, std::min({K, MAX_LANES, nb}));
 
   DevState* dp = nullptr;
-  if (acquire_dev(sh.slot, sh.device, a.cfg, &dp)) return -1;
+  if (acquire_dev(sh.slot, sh.device, sh.sharers, a.cfg, &dp)) return -1;
   DevState& d = *dp;
   HIP_OK(hipSetDevice(sh.device));
+  // streams and lanes that are not there yet come up in the order they are needed, under the packing of the first batch
+  start_bring(d, a.cfg, K, false);
   const double t_created = now_ms();
 
   // ---- input slots ---------------------------------------------------------------------------------------------------
@@ -435,6 +526,11 @@ int run_device(const CallArgs& a, Shard& sh) {
     HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     d.up_done.push_back(e);
   }
+  while ((int)d.down_done.size() < nb) {
+    hipEvent_t e = nullptr;
+    HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    d.down_done.push_back(e);
+  }
 
   Flags fl;
   std::vector<char> prepped(nb, 0), uploaded(nb, 0), computed(nb, 0), downloaded(nb, 0), scattered(nb, 0);
@@ -442,7 +538,7 @@ int run_device(const CallArgs& a, Shard& sh) {
   struct BatchOut { const int32_t* d_scores = nullptr; const char* d_text = nullptr; const unsigned long long* d_off = nullptr;
                     const unsigned int* d_len = nullptr; unsigned long long text_bytes = 0; };
   std::vector<BatchOut> bout(nb);
-  struct BatchClock { double up0 = 0, up1 = 0, dev0 = 0, dev1 = 0, d2h1 = 0, sc0 = 0, sc1 = 0; };      // (timing >= 2: ms since the start of the slice)
+  struct BatchClock { double prep0 = 0, prep1 = 0, up0 = 0, up1 = 0, dev0 = 0, dev1 = 0, d2h1 = 0, sc0 = 0, sc1 = 0; };      // (timing >= 2: ms since the start of the slice)
   std::vector<BatchClock> clk(nb);
   struct StageTimes { double prep = 0, pack = 0, up = 0, up_wait = 0, dev = 0, dev_wait = 0, d2h = 0, scatter = 0, check = 0; };
   StageTimes t_prep_thread, t_up_thread;
@@ -463,7 +559,7 @@ int run_device(const CallArgs& a, Shard& sh) {
       // relative to the batch -- wfagpu_amd_fill_packed_offsets' assignment -- and, when the batch is packed on the host,
       // the words themselves.
       const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)prep_threads, n, std::max(n >> 15, slice_bytes / std::max<size_t>(1, n_all) * n >> 22) + 1}));
-      struct Strip { size_t lo = SIZE_MAX, hi = 0, bytes = 0; unsigned max_len = 0; };
+      struct Strip { size_t lo = SIZE_MAX, hi = 0, bytes = 0; unsigned max_len = 0; size_t outside = SIZE_MAX; };
       std::vector<Strip> strip(nt);
       auto words = [](size_t len) { return (len + 15) / 16 + 1; };
       parallel_for(nt, [&](unsigned t) {
@@ -471,6 +567,10 @@ int run_device(const CallArgs& a, Shard& sh) {
         const size_t j1 = b.from + n * (t + 1) / nt;
         for (size_t j = b.from + n * t / nt; j < j1; ++j) {
           const sequence_pair_t& m = a.meta[j];
+          // (a record that points outside [0, sequences_buffer_size) would be an out-of-bounds read on the device -- pack
+          // kernel, byte-compare tiers -- and in the -c checker: the call fails below instead)
+          if (st.outside == SIZE_MAX && (m.pattern_offset > a.seq_bytes || m.pattern_len > a.seq_bytes - m.pattern_offset ||
+                                         m.text_offset > a.seq_bytes || m.text_len > a.seq_bytes - m.text_offset)) st.outside = j;
           st.lo = std::min(st.lo, std::min(m.pattern_offset, m.text_offset));
           st.hi = std::max(st.hi, std::max(m.pattern_offset + m.pattern_len, m.text_offset + m.text_len));
           st.max_len = std::max(st.max_len, (unsigned)std::max(m.pattern_len, m.text_len));
@@ -484,6 +584,11 @@ int run_device(const CallArgs& a, Shard& sh) {
       for (unsigned t = 0; t < nt; ++t) {
         lo = std::min(lo, strip[t].lo); hi = std::max(hi, strip[t].hi); max_len = std::max(max_len, strip[t].max_len);
         strip_off[t] = packed_bytes; packed_bytes += strip[t].bytes;
+        if (strip[t].outside != SIZE_MAX) {
+          LOG_ERROR("Sequence record %zu points outside the sequence buffer (%zu bytes).", strip[t].outside, a.seq_bytes);
+          fl.fail(-1);
+          return;
+        }
       }
       lo &= ~(size_t)3;
       hi = std::min(a.seq_bytes, (hi + 4) & ~(size_t)3);
@@ -518,6 +623,7 @@ int run_device(const CallArgs& a, Shard& sh) {
         t_prep_thread.pack += now_ms() - tp0;
       }
       t_prep_thread.prep += now_ms() - t0;
+      clk[i].prep0 = t0 - t_begin; clk[i].prep1 = now_ms() - t_begin;
       fl.set(prepped, i);
     }
   });
@@ -526,6 +632,7 @@ int run_device(const CallArgs& a, Shard& sh) {
   std::thread uploader([&] {
     if (hipSetDevice(sh.device) != hipSuccess) { fl.fail(-1); return; }
     auto ok = [&](hipError_t e, const char* what) { if (e != hipSuccess) { LOG_ERROR("HIP call %s failed: %s", what, hipGetErrorString(e)); fl.fail(-1); return false; } return true; };
+    if (ensure_item(d, [&] { return d.up != nullptr; }, [&] { return create_up(d); })) { fl.fail(-1); return; }
     for (int i = 0; i < nb; ++i) {
       double t0 = now_ms();
       if (!fl.wait(prepped, i)) return;
@@ -576,6 +683,16 @@ int run_device(const CallArgs& a, Shard& sh) {
   auto scatter_lane = [&](int k) {
     // (this thread issues the D2H copies of its lane: every thread that talks to HIP selects the slice's device first)
     if (hipSetDevice(sh.device) != hipSuccess) { fl.fail(-1); return; }
+    if (ensure_item(d, [&] { return d.down != nullptr; }, [&] { return create_down(d); })) { fl.fail(-1); return; }
+    {
+      // pinned staging for the fixed-size results of both output sets, before the first batch is through (pinned
+      // memory costs ~0.2 ms per MiB: not on the first results' way home)
+      const size_t n0 = plan[0].to - plan[0].from, cap = n0 + n0 / 8;
+      for (auto& o : d.lane[k].out) {
+        if (n0 > o.n_cap) { if (grow_pinned(&o.score, cap)) { fl.fail(-1); return; } o.n_cap = cap; }
+        if (a.cigar && n0 > o.cig_cap) { if (grow_pinned(&o.off, cap) || grow_pinned(&o.len, cap)) { fl.fail(-1); return; } o.cig_cap = cap; }
+      }
+    }
     for (int j = 0;; ++j) {
       int i = -1;
       {
@@ -604,18 +721,20 @@ int run_device(const CallArgs& a, Shard& sh) {
           if (grow_pinned(&o.off, cap) || grow_pinned(&o.len, cap)) { fl.fail(-1); return; }
           o.cig_cap = cap;
         }
-        if (!okh(hipMemcpyAsync(o.score, bo.d_scores, n * sizeof(int32_t), hipMemcpyDeviceToHost, L.down), "D2H scores")) return;
+        if (!okh(hipMemcpyAsync(o.score, bo.d_scores, n * sizeof(int32_t), hipMemcpyDeviceToHost, d.down), "D2H scores")) return;
         if (a.cigar) {
           if (bo.text_bytes + 1 > o.text_cap) {
             const size_t cap = (size_t)bo.text_bytes + (size_t)bo.text_bytes / 8 + 4096;
             if (grow_pinned(&o.text, cap)) { fl.fail(-1); return; }
             o.text_cap = cap;
           }
-          if (!okh(hipMemcpyAsync(o.off, bo.d_off, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, L.down), "D2H offsets")) return;
-          if (!okh(hipMemcpyAsync(o.len, bo.d_len, n * sizeof(unsigned int), hipMemcpyDeviceToHost, L.down), "D2H lengths")) return;
-          if (bo.text_bytes && !okh(hipMemcpyAsync(o.text, bo.d_text, bo.text_bytes, hipMemcpyDeviceToHost, L.down), "D2H text")) return;
+          if (!okh(hipMemcpyAsync(o.off, bo.d_off, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, d.down), "D2H offsets")) return;
+          if (!okh(hipMemcpyAsync(o.len, bo.d_len, n * sizeof(unsigned int), hipMemcpyDeviceToHost, d.down), "D2H lengths")) return;
+          if (bo.text_bytes && !okh(hipMemcpyAsync(o.text, bo.d_text, bo.text_bytes, hipMemcpyDeviceToHost, d.down), "D2H text")) return;
         }
-        if (!okh(hipStreamSynchronize(L.down), "D2H sync")) return;
+        // (the device's one download stream: this batch's copies -- and whatever other lanes queued before them -- have landed)
+        if (!okh(hipEventRecord(d.down_done[i], d.down), "D2H event")) return;
+        if (!okh(hipEventSynchronize(d.down_done[i]), "D2H sync")) return;
         t_scat[k].d2h += now_ms() - t0;
         clk[i].d2h1 = now_ms() - t_begin;
         fl.set(downloaded, i);
@@ -660,7 +779,8 @@ int run_device(const CallArgs& a, Shard& sh) {
   // ---- stage 2: the kernels + D2H, K lanes on alternate batches ----------------------------------------------------------
   auto compute_lane = [&](int k) -> int {
     HIP_OK(hipSetDevice(sh.device));
-    if (make_lane(d, k, K, sh.sharers, a.cfg)) return -1;
+    if (ensure_item(d, [&] { return d.lane[k].ctx != nullptr; }, [&] { return make_lane(d, k, a.cfg); })) return -1;
+    prime_once(d, k);      // (code objects: the first lane that is up loads them while the first batch is on its way)
     Lane& L = d.lane[k];
     std::vector<int> mine;
     for (int j = 0;; ++j) {
@@ -676,13 +796,14 @@ int run_device(const CallArgs& a, Shard& sh) {
       const size_t n = b.to - b.from;
       const InSlot& in = d.in[i % R];
       int32_t*& d_sc = L.d_scores[j & 1];
+      // (the output set this batch writes -- score buffer included -- was last used by the lane's batch before last: its
+      // download must be over before the buffer is written or, when it has to grow, freed)
+      if (j >= 2 && !fl.wait(downloaded, mine[j - 2])) return fl.rc.load();
       if (n > L.scores_cap[j & 1]) {
         if (d_sc) (void)hipFree(d_sc);
         d_sc = nullptr; L.scores_cap[j & 1] = n + n / 8;
         HIP_OK(hipMalloc(&d_sc, L.scores_cap[j & 1] * sizeof(int32_t)));
       }
-      // (the output set this batch writes was last used by the lane's batch before last: its download must be over)
-      if (j >= 2 && !fl.wait(downloaded, mine[j - 2])) return fl.rc.load();
       wfagpu_amd_batch_t wb{};
       if (b.host_packed) wb.d_packed = in.d_packed;
       else wb.d_sequences = reinterpret_cast<const char*>(reinterpret_cast<uintptr_t>(in.d_seq) - b.lo);     // [offset of the caller's buffer]
@@ -720,6 +841,9 @@ int run_device(const CallArgs& a, Shard& sh) {
   prepper.join();
   uploader.join();
   for (auto& t : scat) t.join();
+  join_bring(d);
+  // (the device is idle: what the lanes' contexts outgrew during the call can go without stalling anybody)
+  for (int k = 0; k < K; ++k) if (d.lane[k].ctx) wfagpu_amd_trim(d.lane[k].ctx);
 
   wfagpu_amd_launch_stats_t& st = sh.st;
   st.total_ms = now_ms() - t_begin;
@@ -737,10 +861,16 @@ int run_device(const CallArgs& a, Shard& sh) {
             "device %.1f (+%.1f waiting), d2h %.1f, scatter %.1f, check %.1f; total %.1f\n",
             sh.device, sh.slot, nb, K, R, st.acquire_ms, st.prep_ms, st.upload_ms, st.upload_wait_ms, st.device_ms, st.device_wait_ms,
             st.d2h_ms, st.scatter_ms, st.check_ms, st.total_ms);
-  if (a.cfg.timing >= 2)
+  if (a.cfg.timing >= 2) {
+    if (d.bring_clock[0] > t_begin) {
+      fprintf(stderr, "[wfagpu timing]   bring-up: upload stream %.2f", d.bring_clock[0] - t_begin);
+      for (int k = 0; k < K; ++k) fprintf(stderr, ", lane %d %.2f", k, d.bring_clock[1 + k] - t_begin);
+      fprintf(stderr, ", download stream %.2f\n", d.bring_clock[1 + MAX_LANES] - t_begin);
+    }
     for (int i = 0; i < nb; ++i)
-      fprintf(stderr, "[wfagpu timing]   batch %2d (%zu pairs): upload issued %.2f, landed <= %.2f | device %.2f - %.2f | d2h done %.2f | scatter %.2f - %.2f\n",
-              i, plan[i].to - plan[i].from, clk[i].up0, clk[i].up1, clk[i].dev0, clk[i].dev1, clk[i].d2h1, clk[i].sc0, clk[i].sc1);
+      fprintf(stderr, "[wfagpu timing]   batch %2d (%zu pairs): prep %.2f - %.2f | upload issued %.2f, landed <= %.2f | device %.2f - %.2f | d2h done %.2f | scatter %.2f - %.2f\n",
+              i, plan[i].to - plan[i].from, clk[i].prep0, clk[i].prep1, clk[i].up0, clk[i].up1, clk[i].dev0, clk[i].dev1, clk[i].d2h1, clk[i].sc0, clk[i].sc1);
+  }
   return fl.rc.load();
 }
 
@@ -867,9 +997,35 @@ void launch_alignments_distance(char* sequences_buffer, const size_t sequences_b
               check_correctness, false);
 }
 
+void wfagpu_amd_warmup(void) {
+  wfagpu_amd_launch_config_t cfg;
+  { std::lock_guard<std::mutex> l(g_cfg_mu); cfg = g_cfg; }
+  if (cfg.bring_up < 0 || cfg.virtual_devices > 0) return;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return;
+  if (cfg.num_devices > 0) ndev = std::min(ndev, cfg.num_devices);
+  // (a process that ends while a device is still coming up must not tear the runtime down under that thread)
+  static std::once_flag at_exit;
+  std::call_once(at_exit, [] { atexit([] { for (int i = 0; i < MAX_DEV; ++i) join_bring(g_dev[i]); }); });
+  for (int dev = 0; dev < std::min(ndev, MAX_DEV); ++dev) {
+    std::lock_guard<std::mutex> guard(g_dev_mu[dev]);
+    DevState* d = nullptr;
+    if (acquire_dev(dev, dev, 1, cfg, &d)) return;
+    start_bring(*d, cfg, MAX_LANES - 1, true);
+  }
+}
+
+// The first time the process asks about its devices (the CLI: tools/aligner.c:189-204 of the reference, before it reads its
+// input; the API: wfagpu_set_default_options -> get_cuda_SM_count) the devices start coming up in the background.
+static void first_device_query() {
+  static std::once_flag once;
+  std::call_once(once, [] { wfagpu_amd_warmup(); });
+}
+
 void get_num_cuda_devices(int* n) {
   if (!n) return;
   if (hipGetDeviceCount(n) != hipSuccess) *n = 0;
+  if (*n > 0) first_device_query();
 }
 
 char* get_cuda_dev_name(int dev) {
@@ -881,6 +1037,7 @@ char* get_cuda_dev_name(int dev) {
 int get_cuda_SM_count(int dev) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+  first_device_query();
   return prop.multiProcessorCount;
 }
 

@@ -16,10 +16,14 @@ torch.distributed.run` child, before anything here touches the GPU) and relays t
 with N*P pairs sharded inside the library over N devices (what a user of the reference API gets).
 
 Besides the contract fields the line carries
-  roofline      the dominant kernel's main launch against the HBM roofline (SURVEY.md 8d algorithmic bytes) and, from the
-                committed PMC pass of the same command, against the instruction-issue limit that really binds it
+  roofline      the dominant kernel's main launch against the resource that binds it -- vector instruction issue, from the
+                hardware busy counters of the committed PMC pass of the same command -- with the HBM figures (SURVEY.md 8d
+                algorithmic bytes, the bytes the design moves, the bytes the counters saw) as flat hbm_* keys beside it
   cpu_baseline  the reference's WFA2 (oracle/_ref) on this box's host cores, bounded sample, N=1 only
   host_to_host  the reference's own metric: wall of launch_alignments from a pageable host buffer to host CIGAR buffers
+  cli_wall      bin/wfa.affine.gpu as a fresh process on the same workload from a .seq file: the "Wall time" it prints
+  configs       short legs of the other BASELINE GPU configurations (cfg2, cfg4 by policy and with the band forced, cfg5):
+                value, kernel time, issue fraction, parity sample, host-to-host rate, CPU baseline each (N=1, default command)
 """
 import argparse
 import hashlib
@@ -55,7 +59,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 def kernel_source_hash():
     """Identifies the kernels a PMC summary was taken with (profiles/*/..._pmc_counters.csv carry it in a '#' line)."""
     h = hashlib.sha1()
-    for f in ("align_kernel.hip", "trace_kernel.hip", "pack_kernel.hip", "wfa_device.h"):
+    for f in ("align_kernel.hip", "short_kernel.hip", "trace_kernel.hip", "pack_kernel.hip", "wfa_device.h"):
         h.update(open(os.path.join(ROOT, "wfa-gpu_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -79,7 +83,8 @@ def _pmc_main_launch(workload, counters, optional=()):
     lines = open(src).read().splitlines()
     tag = [ln for ln in lines if ln.startswith("#") and "kernel_sha1=" in ln]
     stale = (not tag) or (tag[0].split("kernel_sha1=")[1].split()[0] != kernel_source_hash())
-    rows = [r for r in csv.DictReader(ln for ln in lines if not ln.startswith("#")) if "wfa_align_kernel" in r["kernel"]]
+    rows = [r for r in csv.DictReader(ln for ln in lines if not ln.startswith("#"))
+            if "wfa_align_kernel" in r["kernel"] or "wfa_short_score_kernel" in r["kernel"]]
     out = {}
     for c in counters:
         vals = [float(r["value"]) for r in rows if r["counter"] == c]
@@ -200,6 +205,7 @@ def host_to_host(buf, meta, wl, max_error, n_devices=1, reps=8, registered=False
     out["first_result"] = int(res[0].error)
     lib.destroy_wfa_results(res, n)
     wfagpu.configure_launch()
+    lib.wfagpu_amd_release_cache()      # (lanes, arenas, input slots: back to the driver before the next leg)
     return out
 
 
@@ -218,6 +224,228 @@ def self_spawn(args):
     sys.exit(r.returncode)
 
 
+def build_roofline(workload, st, main_ms, launches_per_step, all_ms, compute_cigar, use_pmc):
+    """`roofline` of the dominant kernel (wfa_align_kernel / wfa_short_score_kernel), MAIN launch of a step.  Flat on
+    purpose (scalars only).  What binds these kernels is vector instruction issue, so `frac` is the VALU-busy fraction:
+    SQ_ACTIVE_INST_VALU (quad-cycles the vector pipe spent on instructions, summed over the chip) of the committed PMC pass
+    of this same command, x 4 cycles / 1024 SIMDs, over the LIVE launch duration at the clock the PMC pass ran at.  The HBM
+    figures sit beside it: hbm_algorithmic_* is SURVEY.md 8(d) (6 B per cell = three 16-bit offsets), hbm_design_* what this
+    design moves (1 origin byte per cell + 8 B per score row + packed sequences + records/results), hbm_counter_* what the
+    TCC counters saw; without a PMC pass for the workload the line falls back to bound = "hbm" on the algorithmic bytes."""
+    pairs, cells, seqb = int(st.main_launch_pairs), int(st.main_launch_cells), int(st.main_launch_seq_bytes)
+    alg = algorithmic_bytes(seqb, pairs, cells, compute_cigar)
+    # what the design moves: packed sequences + record + result per pair and, with CIGARs, the backtrace arena it fills -- one
+    # origin byte per cell in 16-byte units + 8 B per score of row table (arena_units: of the call, i.e. the main launch + its re-runs)
+    design = int(seqb + 68 * pairs + (16 * int(st.arena_units) if compute_cigar else 0))
+    secs = main_ms * 1e-3
+    hw = ["SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_LDS", "GRBM_GUI_ACTIVE", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES",
+          "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS"]
+    pmc, pmc_src, pmc_stale = _pmc_main_launch(workload, ["FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_INSTS_SALU"] + hw, optional=hw) \
+        if use_pmc else (None, None, None)
+    # HBM bytes of the main launch: (FETCH_SIZE*2 + WRITE_SIZE) KB -- FETCH_SIZE counts half of a wide coalesced read on
+    # gfx950 (MI355X_MICROARCH.md, HBM section)
+    traffic = int((2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024) if pmc else None
+    r = {"kernel": "wfa_short_score_kernel (main launch of a step)" if int(st.main_launch_tier) == 5 else "wfa_align_kernel (main launch of a step)",
+         "kernel_ms": round(main_ms, 4), "tier": int(st.main_launch_tier), "pairs_per_launch": pairs, "cells_per_launch": cells,
+         "cells_per_s": round(cells / secs, 1) if secs > 0 else None,
+         "launches_per_step": launches_per_step, "all_launches_ms_per_step": round(all_ms, 4), "cells_per_step": int(st.cells),
+         "traffic": traffic, "traffic_source": pmc_src, "pmc_stale": pmc_stale,
+         "hbm_peak_GBps": HBM_PEAK_GBS,
+         "hbm_algorithmic_bytes": alg, "hbm_algorithmic_GBps": round(alg / secs / 1e9, 2) if secs > 0 else None,
+         "hbm_algorithmic_frac": round(alg / secs / 1e9 / HBM_PEAK_GBS, 5) if secs > 0 else None,
+         "hbm_design_bytes": design, "hbm_counter_bytes": traffic,
+         "hbm_counter_GBps": round(traffic / secs / 1e9, 2) if traffic and secs > 0 else None,
+         "hbm_frac_of_peak": round(traffic / secs / 1e9 / HBM_PEAK_GBS, 5) if traffic and secs > 0 else None}
+    if pmc and secs > 0 and pmc.get("SQ_ACTIVE_INST_VALU") and pmc.get("GRBM_GUI_ACTIVE") and pmc.get("_ms_GRBM_GUI_ACTIVE"):
+        simds, xcds = 1024, 8
+        cyc = pmc["GRBM_GUI_ACTIVE"] / xcds                                  # shader cycles of the launch under the PMC pass
+        clock = cyc / (pmc["_ms_GRBM_GUI_ACTIVE"] * 1e-3)                    # Hz during that pass
+        busy = pmc["SQ_ACTIVE_INST_VALU"] * 4.0                              # VALU-busy SIMD-cycles of the launch (work-invariant)
+        peak = simds * clock / 1e9                                           # G SIMD-cycles per second the chip has
+        ach = busy / secs / 1e9
+        r.update({"bound": "valu-issue", "unit": "G VALU-busy SIMD-cycles/s", "achieved": round(ach, 2), "peak": round(peak, 2),
+                  "frac": round(ach / peak, 4),
+                  "frac_formula": "SQ_ACTIVE_INST_VALU x 4 / live kernel seconds / (1024 SIMDs x clock of the PMC pass)",
+                  "clock_ghz_pmc_pass": round(clock / 1e9, 3), "pmc_kernel_ms": round(pmc["_ms_GRBM_GUI_ACTIVE"], 4),
+                  "valu_busy_pmc_pass": round(busy / simds / cyc, 4),
+                  "salu_busy_pmc_pass": round(pmc["SQ_ACTIVE_INST_SCA"] * 4 / simds / cyc, 4) if pmc.get("SQ_ACTIVE_INST_SCA") else None,
+                  "lds_busy_pmc_pass": round(pmc["SQ_ACTIVE_INST_LDS"] * 4 / simds / cyc, 4) if pmc.get("SQ_ACTIVE_INST_LDS") else None,
+                  "valu_insts_per_launch": int(pmc["SQ_INSTS_VALU"]), "salu_insts_per_launch": int(pmc["SQ_INSTS_SALU"]),
+                  "valu_insts_per_cell": round(pmc["SQ_INSTS_VALU"] * 64 / max(cells, 1), 3)})
+        if pmc.get("SQ_WAVE_CYCLES"):
+            for k, c in (("wave_cycles_issuing", "SQ_ACTIVE_INST_ANY"), ("wave_cycles_stalled_at_issue", "SQ_WAIT_INST_ANY"),
+                         ("wave_cycles_parked_waitcnt_or_barrier", "SQ_WAIT_ANY")):
+                if c in pmc:
+                    r[k] = round(pmc[c] / pmc["SQ_WAVE_CYCLES"], 3)
+    else:
+        r.update({"bound": "hbm", "unit": "GB/s", "achieved": r["hbm_algorithmic_GBps"], "peak": HBM_PEAK_GBS, "frac": r["hbm_algorithmic_frac"],
+                  "frac_formula": "SURVEY 8(d) algorithmic bytes / live kernel seconds / 8 TB/s (no PMC pass committed for this command: "
+                                  "the kernel is issue-bound, see DESIGN.md)"})
+    return r
+
+
+def parity_sample(buf, meta, wl, n_pairs, d_scores, ptrs, st, band):
+    """Parity spot check OUTSIDE the timed region: a sample of the last timed step's outputs against the checker."""
+    import oracle_lib
+    import wfagpu
+    try:
+        k = min(2000 if wl["length"] <= 1000 else (64 if wl["length"] <= 10000 else 8), n_pairs)
+        scores = d_scores[:k].cpu().numpy()
+        if oracle_lib.have_ref():
+            so, co = oracle_lib.ref_batch(buf, meta[:k], PEN, cigar=wl["cigar"], memory_mode=0, nthreads=min(16, usable_cores()))
+        else:
+            so, co, _ = oracle_lib.oracle_batch(buf, meta[:k], PEN, cigar=wl["cigar"], nthreads=min(8, usable_cores()))
+        cg = wfagpu.fetch_cigars(ptrs[0], ptrs[1], ptrs[2], n_pairs, st.text_bytes)[:k] if wl["cigar"] else None
+        if band:
+            # the adaptive band is a heuristic: valid alignments, cost == score >= optimum; recall reported
+            pairs = wfagpu.pairs_from_layout(buf, meta[:k])
+            chk = [oracle_lib.check_cigar(p, t, c, PEN) for (p, t), c in zip(pairs, cg)]
+            ok = all(o and cost == s for (o, cost), s in zip(chk, scores)) and bool((scores >= so).all())
+            return {"pairs": k, "valid_and_cost_equals_score": ok, "recall": float((scores == so).mean())}
+        return {"pairs": k, "bit_exact_vs_oracle": bool(np.array_equal(scores, so)) and (not wl["cigar"] or cg == co)}
+    except Exception as ex:  # the checker is optional for the measurement itself
+        return {"error": str(ex)}
+
+
+def make_pairs(name, n_pairs, seed):
+    import wfagpu
+    wl = WORKLOADS[name]
+    return wfagpu.generate_pairs(n_pairs, wl["length"], wl["error"], seed=seed, nthreads=min(16, usable_cores()))
+
+
+def settle(seconds=3.0):
+    """Device memory that a process (or an earlier leg of this one) has released is wiped by the kernel driver in the
+    background before it can be handed out again (KFD: wipe on release, ~20 GB/s); a large hipMalloc that follows a large free
+    stalls behind that -- seen as single hipMalloc calls of 1.3-2.9 s in the FIRST launch_alignments call after a 20-60 GB free
+    (profiles/r04/cold_long.txt), which is what round 3's driver run billed to the cold call.  The cold legs are measured on
+    a device that has been left alone for a moment, like a freshly started CLI would find it."""
+    time.sleep(seconds)
+
+
+def resident_leg(name, n_pairs, max_error, steps, warmup, device, seed, tuning, inherit_budgets, dist=None, use_pmc=True, data=None):
+    """One workload, resident in HBM: W warm-up steps, K timed steps (barrier + device sync on both sides, max over ranks).
+    Returns (record, buf, meta): the measurements of this rank's run (+ the parity sample, taken from the last timed step)."""
+    import torch
+    import shardlib
+    import wfagpu
+    wl = WORKLOADS[name]
+    buf, meta = data if data is not None else make_pairs(name, n_pairs, seed)
+    al = wfagpu.DeviceAligner(device, **tuning)
+    batch = al.upload(buf, meta)
+    dptt = int((meta["pattern_len"].astype(np.int64) * meta["text_len"].astype(np.int64)).sum())
+    acc = {"align_ms": 0.0, "pack_ms": 0.0, "trace_ms": 0.0, "launches": 0, "main_ms": 0.0}
+    last = {}
+    band = wl["band"]
+
+    def step():
+        last["out"] = al.align(batch, PEN, max_error=max_error, compute_cigar=wl["cigar"], band=band[0] if band else -1,
+                               band_width=band[1] if band else 0, fetch=False)
+        st = al.stats()
+        acc["align_ms"] += st.align_ms
+        acc["pack_ms"] += st.pack_ms
+        acc["trace_ms"] += st.trace_ms
+        acc["launches"] += st.align_launches
+        acc["main_ms"] += st.main_launch_ms
+
+    for _ in range(warmup):
+        step()
+    # The steps of a run are batches of one stream of reads: like launch_alignments* does for the batches of a call, the
+    # score budgets tuned on a sample during the warm-up are tried again without sampling (results stay exact: a pair that
+    # misses its budget is re-run, and the parity sample is taken from the last timed step).
+    inherit = warmup > 0 and inherit_budgets
+    if inherit:
+        al.hint_same_stream(True)
+    for k in acc:
+        acc[k] = 0
+    elapsed, per_rank = shardlib.timed_steps(step, steps, 0, dist=dist, sync=torch.cuda.synchronize, device="cuda", per_rank=True)
+    d_scores, ptrs = last["out"]
+    st = al.stats()
+    main_ms = acc["main_ms"] / steps
+    rec = {"elapsed": elapsed, "per_rank_elapsed": per_rank, "dptt": dptt, "inherit": inherit, "n_pairs": n_pairs, "steps": steps,
+           "ms_per_step": elapsed / steps * 1e3,
+           "stage_ms_per_step": {"pack": round(acc["pack_ms"] / steps, 3), "align": round(acc["align_ms"] / steps, 3),
+                                 "trace": round(acc["trace_ms"] / steps, 3)},
+           "tiers": {"lds_bytes_first": int(st.lds_bytes_tier0), "blocks_per_cu_first": int(st.blocks_per_cu_tier0), "waves_per_simd_first": int(st.waves_per_simd_tier0),
+                     "pairs_per_tier": [int(v) for v in st.pairs_tier], "pairs_retried": int(st.pairs_retried),
+                     "pairs_banded": int(st.pairs_banded), "auto_budget": int(st.auto_budget),
+                     "pairs_budget_missed": int(st.pairs_budget_missed), "passes": int(st.sub_batches),
+                     "arena_gb": round(st.arena_units * 16 / 1e9, 2)},
+           "roofline": build_roofline(name, st, main_ms, acc["launches"] / steps, acc["align_ms"] / steps, wl["cigar"], use_pmc),
+           "parity_sample": parity_sample(buf, meta, wl, n_pairs, d_scores, ptrs, st, band)}
+    al.close()
+    del batch
+    torch.cuda.empty_cache()
+    torch.cuda.synchronize()      # (the resident leg's device memory is back with the driver before a host-to-host leg starts)
+    return rec, buf, meta
+
+
+def cli_wall(n_pairs=1_000_000, length=1000, error=0.05, max_error=300, runs=2):
+    """The CLI as a user runs it: bin/wfa.affine.gpu -i <file> -x in a FRESH process per run (every CLI invocation is a cold
+    launch_alignments call).  The number is the "Wall time" the tool prints (tools/aligner.c:450-474 of the reference: the
+    launch_alignments call alone -- file reading and output writing are outside it)."""
+    import re
+    import tempfile
+    pkg = os.path.join(ROOT, "wfa-gpu_amd")
+    cli, gen = os.path.join(pkg, "bin", "wfa.affine.gpu"), os.path.join(pkg, "bin", "generate_dataset")
+    if not (os.path.exists(cli) and os.path.exists(gen)):
+        return {"error": "bin/wfa.affine.gpu or bin/generate_dataset not built"}
+    with tempfile.TemporaryDirectory(prefix="wfagpu_cli_") as tmp:
+        seq = os.path.join(tmp, "cfg3.seq")
+        t0 = time.perf_counter()
+        subprocess.run([gen, "-n", str(n_pairs), "-l", str(length), "-e", str(error), "-s", "9", "-t", str(min(16, usable_cores())), "-o", seq],
+                       check=True, timeout=600, capture_output=True)
+        gen_s = time.perf_counter() - t0
+        walls, proc = [], []
+        for _ in range(runs):
+            t0 = time.perf_counter()
+            r = subprocess.run([cli, "-i", seq, "-x", "-e", str(max_error)], capture_output=True, text=True, timeout=600)
+            proc.append(round(time.perf_counter() - t0, 3))
+            m = re.search(r"Wall time: ([0-9.]+)s \(([0-9.]+) alignments per second\)", r.stdout)
+            if r.returncode != 0 or not m:
+                return {"error": f"exit code {r.returncode}: {(r.stderr or r.stdout)[-300:]}"}
+            walls.append((float(m.group(1)), float(m.group(2))))
+    best = min(walls)
+    return {"what": "bin/wfa.affine.gpu -i <1M x 1 kbp @ 5 % .seq> -x -e 300, fresh process per run: the 'Wall time' line it prints",
+            "unit": "alignments/s", "pairs": n_pairs, "value": round(max(w[1] for w in walls), 1), "wall_s": [w[0] for w in walls],
+            "alignments_per_s": [w[1] for w in walls], "best_wall_ms": round(best[0] * 1e3, 1), "process_s": proc, "generate_s": round(gen_s, 2)}
+
+
+def extra_config(name, force_band, steps, warmup):
+    """A short leg of another BASELINE configuration on this GPU, everything the headline carries in small: resident value,
+    kernel time + issue fraction, parity sample, host-to-host rate, CPU baseline."""
+    wl = WORKLOADS[name]
+    tuning = {"force_band": 1} if force_band else {}
+    t0 = time.perf_counter()
+    n = wl["pairs"]
+    buf, meta = make_pairs(name, n, 1000)
+    # (host to host FIRST, on a device nobody has just released tens of GB on: see settle())
+    settle(2.0)
+    h2h_out = {}
+    try:
+        h2h = host_to_host(buf, meta, wl, wl["max_error"], tuning=tuning, reps=3)
+        h2h_out = {"host_to_host_value": h2h["pageable"]["warm"], "host_to_host_ms_per_call": h2h["pageable"]["warm_ms"],
+                   "host_to_host_cold_ms": h2h["pageable"]["cold_ms"], "host_to_host_calls_ms": h2h["pageable"]["calls_ms"]}
+    except Exception as ex:
+        h2h_out = {"host_to_host_value": None, "host_to_host_error": str(ex)}
+    rec, buf, meta = resident_leg(name, n, wl["max_error"], steps, warmup, 0, 1000, tuning, True, use_pmc=not force_band, data=(buf, meta))
+    rf = rec["roofline"]
+    out = {"workload": wl["desc"] + (" [band forced]" if force_band else ""), "pairs": n, "steps": steps, "warmup": warmup,
+           "value": round(n * steps / rec["elapsed"], 1), "unit": "alignments/s", "ms_per_step": round(rec["ms_per_step"], 3),
+           "gcups": round(rec["dptt"] * steps / rec["elapsed"] / 1e9, 2),
+           "kernel_ms": rf["kernel_ms"], "tier": rf["tier"], "roofline_bound": rf["bound"], "roofline_frac": rf["frac"],
+           "roofline_source": rf["traffic_source"], "pmc_stale": rf["pmc_stale"],
+           "stage_ms_per_step": rec["stage_ms_per_step"], "pairs_per_tier": rec["tiers"]["pairs_per_tier"],
+           "pairs_banded": rec["tiers"]["pairs_banded"], "auto_budget": rec["tiers"]["auto_budget"],
+           "parity_sample": rec["parity_sample"]}
+    out.update(h2h_out)
+    if not force_band:
+        per_pair_us = 2.0 if wl["length"] <= 200 else 95.0 * (wl["length"] / 1000.0) ** 2
+        cb = cpu_baseline(buf, meta, wl["cigar"], int(max(16, min(n, 4e6 / per_pair_us))))
+        out["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample")}
+    out["leg_s"] = round(time.perf_counter() - t0, 1)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -230,6 +458,7 @@ def main():
     ap.add_argument("--h2h-timing", type=int, default=0, help="stage clocks of the host-to-host calls on stderr (1: per call, 2: per batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-to-host", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the short legs of the other BASELINE configurations and the CLI leg")
     ap.add_argument("--no-inherit-budgets", action="store_true", help="sample the score budgets again in every step")
     ap.add_argument("--force-band", action="store_true", help="banded workloads: always run the banded kernels (tuning.force_band)")
     ap.add_argument("--tuning", action="append", default=[], metavar="KEY=INT",
@@ -272,99 +501,53 @@ def main():
         host_grp = shardlib.host_group(dist)
 
     # synthetic data (seeded; every rank its own shard), resident in HBM before the clock starts
-    buf, meta = wfagpu.generate_pairs(n_pairs, wl["length"], wl["error"], seed=shardlib.shard_seed(1000, rank),
-                                      nthreads=min(16, usable_cores()))
     tuning = {"force_band": 1} if args.force_band else {}
     tuning.update({kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.tuning})
-    al = wfagpu.DeviceAligner(local_rank, **tuning)
-    batch = al.upload(buf, meta)
-    dptt = int((meta["pattern_len"].astype(np.int64) * meta["text_len"].astype(np.int64)).sum())
-    acc = {"align_ms": 0.0, "pack_ms": 0.0, "trace_ms": 0.0, "launches": 0, "main_ms": 0.0}
-    last = {}
+    # (the committed counters belong to the default command: not to other sizes, and not to runs with the A/B switches set)
+    default_cmd = not args.pairs and not args.max_error and not tuning
+    data = make_pairs(args.workload, n_pairs, shardlib.shard_seed(1000, rank))
+    pre = {}
+    if rank == 0 and world == 1:
+        # The legs that measure COLD calls come first, before this process has allocated (and released) anything big:
+        # the CLI as a fresh process, then launch_alignments* from this one (see settle()).
+        # (the HIP runtime itself is initialised here, as the CLI's device query does before its clock starts: ~60-90 ms)
+        ndev = __import__("ctypes").c_int(0)
+        wfagpu.load().get_num_cuda_devices(__import__("ctypes").byref(ndev))
+        settle(3.0)
+        if default_cmd and args.workload == "cfg3" and not args.no_configs:
+            try:
+                pre["cli_wall"] = cli_wall()
+                pre["cli_wall_value"] = pre["cli_wall"].get("value")
+            except Exception as ex:
+                pre["cli_wall"] = {"error": str(ex)}
+            settle(2.0)
+        if not args.no_host_to_host:
+            try:
+                h2h = host_to_host(data[0], data[1], wl, max_error, tuning=tuning, launch_cfg={"timing": args.h2h_timing} if args.h2h_timing else None)
+                pre["host_to_host"] = h2h
+                # the reference's own metric (tools/aligner.c:450-474), PCIe inclusive, next to `value` (resident batch)
+                pre["host_to_host_value"] = h2h["pageable"]["warm"]
+                pre["host_to_host_ms_per_call"] = h2h["pageable"]["warm_ms"]
+                pre["host_to_host_cold_ms"] = h2h["pageable"]["cold_ms"]
+                if h2h["stages_ms"].get("host_packed_batches"):
+                    # the call above packed its sequences on the host (a quarter of the bytes over PCIe); the same call
+                    # with the ASCII going up and the pack kernel running, for comparison
+                    asc = host_to_host(data[0], data[1], wl, max_error, tuning=tuning, reps=4, launch_cfg={"host_pack": -1})
+                    h2h["ascii_upload"] = {"warm_ms": asc["pageable"]["warm_ms"], "best_ms": asc["pageable"]["best_ms"],
+                                           "cold_ms": asc["pageable"]["cold_ms"], "warm": asc["pageable"]["warm"],
+                                           "stages_ms": asc["stages_ms"]}
+            except Exception as ex:
+                pre["host_to_host"] = {"error": str(ex)}
+    rec, buf, meta = resident_leg(args.workload, n_pairs, max_error, steps, args.warmup, local_rank, shardlib.shard_seed(1000, rank), tuning,
+                                  not args.no_inherit_budgets, dist=dist, use_pmc=default_cmd, data=data)
+    elapsed = rec["elapsed"]
     band = wl["band"]
-
-    def step():
-        last["out"] = al.align(batch, PEN, max_error=max_error, compute_cigar=wl["cigar"], band=band[0] if band else -1,
-                               band_width=band[1] if band else 0, fetch=False)
-        st = al.stats()
-        acc["align_ms"] += st.align_ms
-        acc["pack_ms"] += st.pack_ms
-        acc["trace_ms"] += st.trace_ms
-        acc["launches"] += st.align_launches
-        acc["main_ms"] += st.main_launch_ms
-
-    for _ in range(args.warmup):
-        step()
-    # The steps of a run are batches of one stream of reads: like launch_alignments* does for the batches of a call, the
-    # score budgets tuned on a sample during the warm-up are tried again without sampling (results stay exact: a pair that
-    # misses its budget is re-run, and the parity sample below is taken from the last timed step).
-    inherit = args.warmup > 0 and not args.no_inherit_budgets
-    if inherit:
-        al.hint_same_stream(True)
-    for k in acc:
-        acc[k] = 0
-    elapsed = shardlib.timed_steps(step, steps, 0, dist=dist, sync=torch.cuda.synchronize, device="cuda")
-    d_scores, ptrs = last["out"]
-
-    st = al.stats()
     total_pairs = n_pairs * steps * world
     value = total_pairs / elapsed
-    gcups = dptt * steps * world / elapsed / 1e9
+    gcups = rec["dptt"] * steps * world / elapsed / 1e9
 
     out = None
     if rank == 0:
-        # Dominant kernel = wfa_align_kernel; its MAIN launch (a step also has the short launches of the auto-budget
-        # sample and of re-runs).  Duration: HIP events on the stream the kernel is launched on (csrc/wfa_host.hip),
-        # averaged over the timed steps.
-        main_ms = acc["main_ms"] / steps
-        alg = algorithmic_bytes(int(st.main_launch_seq_bytes), int(st.main_launch_pairs), int(st.main_launch_cells), wl["cigar"])
-        achieved = alg / (main_ms * 1e-3) / 1e9 if main_ms > 0 else 0.0
-        # (the committed counters belong to the default command: not to other sizes, and not to runs with the A/B switches set)
-        default_cmd = not args.pairs and not args.max_error and not tuning
-        hw = ["SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_LDS", "GRBM_GUI_ACTIVE", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES",
-              "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS"]
-        pmc, pmc_src, pmc_stale = _pmc_main_launch(args.workload, ["FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_INSTS_SALU"] + hw, optional=hw) \
-            if default_cmd else (None, None, None)
-        # HBM bytes of the main launch: (FETCH_SIZE*2 + WRITE_SIZE) KB -- FETCH_SIZE counts half of a wide coalesced
-        # read on gfx950 (MI355X_MICROARCH.md, HBM section)
-        traffic = int((2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024) if pmc else None
-        roofline = {"bound": "valu-issue", "kernel": "wfa_align_kernel (main launch of a step)",
-                    "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": pmc_src,
-                    "pmc_stale": pmc_stale,
-                    "algorithmic_bytes_per_launch": alg, "kernel_ms": round(main_ms, 4),
-                    "launch": {"tier": int(st.main_launch_tier), "pairs": int(st.main_launch_pairs),
-                               "cells": int(st.main_launch_cells)},
-                    "launches_per_step": acc["launches"] / steps,
-                    "all_launches_ms_per_step": round(acc["align_ms"] / steps, 4),
-                    "cells_per_step": int(st.cells),
-                    "cells_per_s": round(st.main_launch_cells / (main_ms * 1e-3), 1) if main_ms > 0 else None,
-                    "note": "achieved/peak/frac: SURVEY 8(d) algorithmic bytes of the main launch / its HIP-event duration "
-                            "vs HBM peak.  The kernel keeps its wavefronts in LDS and stores 1 B per cell, so HBM is not "
-                            "what binds it: see `issue` (instruction issue, from the committed PMC pass) and DESIGN.md"}
-        if pmc and main_ms > 0:
-            # What this kernel really saturates: instruction issue.  A SIMD issues at most one vector and one scalar
-            # instruction per 4 cycles (profiles/r02/valu_rate.txt: 4.0-4.2 cycles per integer wave64 op); 1024 SIMDs, 2.4 GHz.
-            peak = 1024 * 0.25 * 2.4e9 / 1e9
-            roofline["issue"] = {"unit": "G wave-instr/s", "peak_per_pipe": round(peak, 1), "source": pmc_src, "stale": pmc_stale}
-            for pipe, key in (("valu", "SQ_INSTS_VALU"), ("salu", "SQ_INSTS_SALU")):
-                ach = pmc[key] / (main_ms * 1e-3) / 1e9
-                roofline["issue"][pipe] = {"achieved": round(ach, 1), "frac": round(ach / peak, 3), "insts": int(pmc[key])}
-            if "SQ_ACTIVE_INST_VALU" in pmc and pmc.get("GRBM_GUI_ACTIVE"):
-                # The same from the hardware's own busy counters (the gfx9 VALUBusy / SALUBusy formulas): SQ_ACTIVE_INST_*
-                # count quad-cycles a pipe spent on instructions, summed over the chip; GRBM_GUI_ACTIVE is summed over the 8
-                # XCDs.  No microbenchmark in the denominator.
-                simds, xcds = 1024, 8
-                cyc = pmc["GRBM_GUI_ACTIVE"] / xcds
-                roofline["issue"]["hw_counters"] = {
-                    "valu_busy": round(pmc["SQ_ACTIVE_INST_VALU"] * 4 / simds / cyc, 3),
-                    "salu_busy": round(pmc["SQ_ACTIVE_INST_SCA"] * 4 / simds / cyc, 3),
-                    "lds_busy": round(pmc.get("SQ_ACTIVE_INST_LDS", 0) * 4 / simds / cyc, 3),
-                    "wave_cycles_split": {k: round(pmc[c] / pmc["SQ_WAVE_CYCLES"], 3) for k, c in
-                                          (("issuing", "SQ_ACTIVE_INST_ANY"), ("stalled_at_issue", "SQ_WAIT_INST_ANY"), ("parked_waitcnt_or_barrier", "SQ_WAIT_ANY"))
-                                          if pmc.get("SQ_WAVE_CYCLES") and c in pmc},
-                    "clock_ghz_during_launch": round(cyc / (pmc["_ms_GRBM_GUI_ACTIVE"] * 1e-3) / 1e9, 3) if pmc.get("_ms_GRBM_GUI_ACTIVE") else None,
-                    "formula": "SQ_ACTIVE_INST_{VALU,SCA,LDS} * 4 / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs)"}
         out = {
             "metric": "alignments_per_sec", "value": round(value, 1), "unit": "alignments/s",
             "n_gpus": world, "steps": steps, "warmup": args.warmup,
@@ -373,69 +556,40 @@ def main():
             "config": {"workload": f"{args.workload}: {wl['desc']}", "pairs_per_gpu_per_step": n_pairs, "length": wl["length"],
                        "error": wl["error"], "penalties": "x=2,o=3,e=1", "max_error": max_error,
                        "compute_cigar": wl["cigar"],
-                       "budgets": "tuned on a sample in the warm-up, inherited by the timed steps (same stream of reads)" if inherit
+                       "budgets": "tuned on a sample in the warm-up, inherited by the timed steps (same stream of reads)" if rec["inherit"]
                                   else "tuned on a sample in every step",
                        "band": {"period": band[0], "width": band[1], "forced": bool(args.force_band),
                                 "policy": "the band is used only where the sampled score budgets leave the exact wavefronts wider "
                                           "than 2.5 bands (tiers.pairs_banded counts the pairs it finished)"} if band else None,
                        "sharding": f"batch-sharded x{world}, no collective", "mode": "ranks"},
             "gcups": round(gcups, 2),
-            "stage_ms_per_step": {"pack": round(acc["pack_ms"] / steps, 3), "align": round(acc["align_ms"] / steps, 3),
-                                  "trace": round(acc["trace_ms"] / steps, 3)},
-            "tiers": {"lds_bytes_first": int(st.lds_bytes_tier0), "blocks_per_cu_first": int(st.blocks_per_cu_tier0), "waves_per_simd_first": int(st.waves_per_simd_tier0),
-                      "pairs_per_tier": [int(v) for v in st.pairs_tier], "pairs_retried": int(st.pairs_retried),
-                      "pairs_banded": int(st.pairs_banded), "auto_budget": int(st.auto_budget),
-                      "pairs_budget_missed": int(st.pairs_budget_missed), "passes": int(st.sub_batches),
-                      "arena_gb": round(st.arena_units * 16 / 1e9, 2)},
-            "roofline": roofline,
+            # every rank's own clock over the same K steps (the aggregate above uses the slowest: max over ranks)
+            "per_rank": [{"rank": r, "ms_per_step": round(e / steps * 1e3, 3), "value": round(n_pairs * steps / e, 1)}
+                         for r, e in enumerate(rec["per_rank_elapsed"])],
+            "stage_ms_per_step": rec["stage_ms_per_step"],
+            "tiers": rec["tiers"],
+            "roofline": rec["roofline"],
+            "parity_sample": rec["parity_sample"],
         }
-        # parity spot check outside the timed region: a sample against the checker
-        try:
-            import oracle_lib
-            k = min(2000 if wl["length"] <= 1000 else (64 if wl["length"] <= 10000 else 8), n_pairs)
-            scores = d_scores[:k].cpu().numpy()
-            if oracle_lib.have_ref():
-                so, co = oracle_lib.ref_batch(buf, meta[:k], PEN, cigar=wl["cigar"], memory_mode=0, nthreads=min(16, usable_cores()))
-            else:
-                so, co, _ = oracle_lib.oracle_batch(buf, meta[:k], PEN, cigar=wl["cigar"], nthreads=min(8, usable_cores()))
-            cg = wfagpu.fetch_cigars(ptrs[0], ptrs[1], ptrs[2], n_pairs, st.text_bytes)[:k] if wl["cigar"] else None
-            if band:
-                # the adaptive band is a heuristic: valid alignments, cost == score >= optimum; recall reported
-                pairs = wfagpu.pairs_from_layout(buf, meta[:k])
-                chk = [oracle_lib.check_cigar(p, t, c, PEN) for (p, t), c in zip(pairs, cg)]
-                ok = all(o and cost == s for (o, cost), s in zip(chk, scores)) and bool((scores >= so).all())
-                out["parity_sample"] = {"pairs": k, "valid_and_cost_equals_score": ok, "recall": float((scores == so).mean())}
-            else:
-                ok = bool(np.array_equal(scores, so)) and (not wl["cigar"] or cg == co)
-                out["parity_sample"] = {"pairs": k, "bit_exact_vs_oracle": ok}
-        except Exception as ex:  # the checker is optional for the measurement itself
-            out["parity_sample"] = {"error": str(ex)}
-    al.close()
-    del batch
-    torch.cuda.empty_cache()
-    torch.cuda.synchronize()      # (the resident leg's device memory is back with the driver before the host-to-host leg starts)
     if rank == 0 and world == 1:
-        if not args.no_host_to_host:
-            try:
-                h2h = host_to_host(buf, meta, wl, max_error, tuning=tuning, launch_cfg={"timing": args.h2h_timing} if args.h2h_timing else None)
-                out["host_to_host"] = h2h
-                # the reference's own metric (tools/aligner.c:450-474), PCIe inclusive, next to `value` (resident batch)
-                out["host_to_host_value"] = h2h["pageable"]["warm"]
-                out["host_to_host_ms_per_call"] = h2h["pageable"]["warm_ms"]
-                if h2h["stages_ms"].get("host_packed_batches"):
-                    # the call above packed its sequences on the host (a quarter of the bytes over PCIe); the same call
-                    # with the ASCII going up and the pack kernel running, for comparison
-                    asc = host_to_host(buf, meta, wl, max_error, tuning=tuning, reps=4, launch_cfg={"host_pack": -1})
-                    h2h["ascii_upload"] = {"warm_ms": asc["pageable"]["warm_ms"], "best_ms": asc["pageable"]["best_ms"],
-                                           "cold_ms": asc["pageable"]["cold_ms"], "warm": asc["pageable"]["warm"],
-                                           "stages_ms": asc["stages_ms"]}
-            except Exception as ex:
-                out["host_to_host"] = {"error": str(ex)}
+        out.update(pre)
         if not args.no_cpu_baseline:
             # ~10-30 s of CPU work: bounded sample of the same workload
             per_pair_us = 2.0 if wl["length"] <= 200 else 95.0 * (wl["length"] / 1000.0) ** 2
             budget = int(max(16, min(n_pairs, 20e6 / per_pair_us)))
             out["cpu_baseline"] = cpu_baseline(buf, meta, wl["cigar"], budget)
+        if default_cmd and args.workload == "cfg3" and not args.no_configs:
+            del buf, meta, data
+            # the other BASELINE GPU configurations, short legs (~60 s together)
+            out["configs"] = {}
+            for key, name, forced, k, w in (("cfg2", "cfg2", False, 400, 5), ("cfg4", "cfg4", False, 8, 3), ("cfg4_band_forced", "cfg4", True, 8, 3),
+                                            ("cfg5", "cfg5", False, 4, 2)):
+                try:
+                    out["configs"][key] = extra_config(name, forced, k, w)
+                except Exception as ex:
+                    out["configs"][key] = {"error": str(ex)}
+            for key, leg in out["configs"].items():      # (flat copies: the driver's record keeps top-level scalars)
+                out[f"{key}_value"] = leg.get("value")
     if dist is not None:
         # N > 1: the ranks above never share anything but the barrier.  The reference's user calls launch_alignments()
         # ONCE and the library shards the call over the N devices from one process: host RAM bandwidth, the PCIe root and
@@ -498,6 +652,12 @@ def library_mode(args, wl, n_pairs, max_error, steps):
         fn(buf.ctypes.data, buf.nbytes, meta.ctypes.data, res, opt, False)
     elapsed = time.perf_counter() - t0
     stages = wfagpu.last_launch_stats()
+    per_dev = [{"slot": i, "device": d["devices"], "wall_ms": round(d["total_ms"], 2), "host_threads": d["host_threads"], "lanes": d["lanes"],
+                "batches": d["batches"], "sequences": "packed on the host" if d["host_packed_batches"] == d["batches"] else
+                ("ASCII, packed by the kernel" if d["host_packed_batches"] == 0 else f"{d['host_packed_batches']} of {d['batches']} batches packed on the host"),
+                "host_pack_threads": d["host_pack_threads"], "upload_ms": round(d["upload_ms"], 2), "device_ms": round(d["device_ms"], 2),
+                "device_wait_ms": round(d["device_wait_ms"], 2), "scatter_ms": round(d["scatter_ms"], 2)}
+               for i, d in enumerate(wfagpu.last_launch_stats_per_device())]
     dptt = int((meta["pattern_len"].astype(np.int64) * meta["text_len"].astype(np.int64)).sum())
     out = {"metric": "alignments_per_sec", "value": round(n * steps / elapsed, 1), "unit": "alignments/s",
            "n_gpus": args.gpus, "steps": steps, "warmup": max(1, args.warmup), "ms_per_step": round(elapsed / steps * 1e3, 3),
@@ -507,7 +667,7 @@ def library_mode(args, wl, n_pairs, max_error, steps):
                       "sharding": f"one launch_alignments() call sharded in-library over {args.gpus} devices, no collective",
                       "mode": "library (host buffer -> host results, PCIe inclusive)"},
            "gcups": round(dptt * steps / elapsed / 1e9, 2), "first_result": int(res[0].error),
-           "virtual_devices": args.virtual_devices,
+           "virtual_devices": args.virtual_devices, "per_device_last_call": per_dev,
            "stages_ms_last_call": {k: (round(v, 2) if isinstance(v, float) else v) for k, v in stages.items()}}
     lib.destroy_wfa_results(res, n)
     print(json.dumps(out))
@@ -527,7 +687,7 @@ def cpu_harness(args, rank, world, n_pairs, steps):
     def step():
         state["s"], _, _ = oracle_lib.oracle_batch(buf, meta, PEN, cigar=False)
 
-    elapsed = shardlib.timed_steps(step, steps, args.warmup, dist=dist)
+    elapsed, per_rank = shardlib.timed_steps(step, steps, args.warmup, dist=dist, per_rank=True)
     excl = None
     if dist is not None:
         # the rank-0-alone leg of the GPU run (the in-library sharded call), with a stand-in for the call
@@ -538,7 +698,8 @@ def cpu_harness(args, rank, world, n_pairs, steps):
     if rank == 0:
         print(json.dumps({"metric": "alignments_per_sec", "harness_only": True, "n_gpus": world, "steps": steps,
                           "warmup": args.warmup, "value": n * steps * world / elapsed, "unit": "alignments/s",
-                          "ms_per_step": elapsed / steps * 1e3, "scaling": "weak", "library_call": excl}))
+                          "ms_per_step": elapsed / steps * 1e3, "scaling": "weak", "library_call": excl,
+                          "per_rank": [{"rank": r, "ms_per_step": e / steps * 1e3, "value": n * steps / e} for r, e in enumerate(per_rank)]}))
 
 
 if __name__ == "__main__":

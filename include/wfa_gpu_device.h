@@ -214,6 +214,9 @@ typedef struct {
     int host_pack_threads;
 } wfagpu_amd_launch_stats_t;
 void wfagpu_amd_last_launch_stats(wfagpu_amd_launch_stats_t* out);
+/* The same per device slot of the last call (shard = 0 .. devices-1): `devices` then holds the physical device of the slot,
+ * `host_threads` the slot's share of the host threads, `total_ms` the slot's own wall.  0, or -1 when there is no such slot. */
+int wfagpu_amd_last_launch_stats_device(int shard, wfagpu_amd_launch_stats_t* out);
 
 /* Shorthand for wfagpu_amd_launch_config_t::num_devices. */
 void wfagpu_amd_set_num_devices(int n);

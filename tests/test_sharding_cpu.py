@@ -85,6 +85,8 @@ def test_bench_gpus_flag_starts_its_own_ranks():
     out = _bench_json(["--gpus", "2", "--cpu-harness", "--steps", "2", "--warmup", "1"])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["harness_only"] is True
     assert out["library_call"] == {"ranks_parked": 1}      # the rank-0-alone leg ran between two host barriers
+    # every rank's own clock next to the aggregate (which uses the slowest)
+    assert [r["rank"] for r in out["per_rank"]] == [0, 1] and all(r["ms_per_step"] <= out["ms_per_step"] * 1.001 for r in out["per_rank"])
     one = _bench_json(["--cpu-harness", "--steps", "2", "--warmup", "1"])
     assert one["n_gpus"] == 1
 

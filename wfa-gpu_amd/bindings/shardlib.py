@@ -33,9 +33,9 @@ def init_distributed(backend, device=None):
     return dist
 
 
-def timed_steps(step, steps, warmup, dist=None, sync=lambda: None, device="cpu"):
+def timed_steps(step, steps, warmup, dist=None, sync=lambda: None, device="cpu", per_rank=False):
     """W untimed steps, then exactly K steps bracketed by barrier + device sync on both sides; returns the MAX
-    over ranks of the elapsed seconds."""
+    over ranks of the elapsed seconds -- with per_rank, (that, [every rank's own elapsed seconds up to its device sync])."""
     import time
     import torch
     for _ in range(warmup):
@@ -47,14 +47,21 @@ def timed_steps(step, steps, warmup, dist=None, sync=lambda: None, device="cpu")
     for _ in range(steps):
         step()
     sync()
+    own = time.perf_counter() - t0        # this rank's K steps, before it waits for the others
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    ranks = [own]
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    return elapsed
+        if per_rank:
+            mine = torch.tensor([own], dtype=torch.float64, device=device)
+            every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+            dist.all_gather(every, mine)
+            ranks = [float(v.item()) for v in every]
+    return (elapsed, ranks) if per_rank else elapsed
 
 
 def host_group(dist):

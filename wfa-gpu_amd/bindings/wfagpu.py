@@ -97,7 +97,7 @@ ABI_SYMBOLS = [
     "wfagpu_amd_align_device", "wfagpu_amd_last_stats", "wfagpu_amd_set_num_devices", "wfagpu_amd_release_cache",
     "wfagpu_amd_check_failures", "wfagpu_amd_hint_same_stream", "wfagpu_amd_configure_launch",
     "wfagpu_amd_last_launch_stats", "wfagpu_amd_set_tuning", "wfagpu_amd_stream", "wfagpu_amd_trim", "wfagpu_amd_prime",
-    "wfagpu_amd_warmup",
+    "wfagpu_amd_warmup", "wfagpu_amd_last_launch_stats_device",
     "wfagpu_host_pack_sequence", "wfagpu_host_pack_sequence_scalar", "wfagpu_host_pack_strip",
 ]
 
@@ -189,6 +189,17 @@ def last_launch_stats():
     st = LaunchStats()
     load().wfagpu_amd_last_launch_stats(C.byref(st))
     return {k: getattr(st, k) for k, _ in LaunchStats._fields_}
+
+
+def last_launch_stats_per_device():
+    """Stage times of every device slot of the last launch_alignments* call."""
+    out = []
+    for shard in range(64):
+        st = LaunchStats()
+        if load().wfagpu_amd_last_launch_stats_device(shard, C.byref(st)) != 0:
+            break
+        out.append({k: getattr(st, k) for k, _ in LaunchStats._fields_})
+    return out
 
 
 def load_gen():

@@ -53,6 +53,7 @@ constexpr int MAX_LANES = 4;    // compute lanes per device
 std::mutex g_cfg_mu;
 wfagpu_amd_launch_config_t g_cfg{};
 wfagpu_amd_launch_stats_t g_last_stats{};
+std::vector<wfagpu_amd_launch_stats_t> g_last_shard_stats;      // (per device slot of the last call; host_threads: the slot's share)
 std::atomic<long> g_check_failures{0};   // pairs that failed the -c check in the last launch_alignments* call
 
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -237,7 +238,8 @@ struct DevState {
   std::vector<InSlot> in;
   void* d_scratch = nullptr; void* h_scratch = nullptr;      // (a few KiB each: targets of the copies that warm the copy paths up)
   // ---- bring-up (see bring_up_fn): who creates what, in which order
-  std::mutex bring_mu;
+  std::mutex bring_mu;                         // publishes items (up, down, lane[k].ctx) and bring_active
+  std::mutex create_mu;                        // one creator at a time; never held while waiting for bring_mu's condition
   std::condition_variable bring_cv;
   std::thread bring_thread;
   bool bring_active = false;                   // (under bring_mu)
@@ -317,10 +319,15 @@ int acquire_dev(int slot, int device, int sharers, const wfagpu_amd_launch_confi
   return 0;
 }
 
+// (creators run under create_mu and publish their item under bring_mu: a waiter never sees a half-made one, and the
+// mutex the waiters need is never held across a 10-30 ms driver call)
+template <typename T> void publish(DevState& d, T& slot, T value) {
+  { std::lock_guard<std::mutex> l(d.bring_mu); slot = value; }
+  d.bring_cv.notify_all();
+}
 // Lane k of a device: a context (stream, events, counters).
 int make_lane(DevState& d, int k, const wfagpu_amd_launch_config_t& cfg) {
   Lane& l = d.lane[k];
-  if (l.ctx) return 0;
   const int lanes = MAX_LANES, sharers = d.sharers;      // (every lane the slot can ever have: the caps do not depend on the call)
   wfagpu_amd_config_t c{};
   c.device = d.device;
@@ -337,7 +344,9 @@ int make_lane(DevState& d, int k, const wfagpu_amd_launch_config_t& cfg) {
     c.arena_limit_bytes = std::min<size_t>((size_t)4 << 30, std::max<size_t>(share, (size_t)64 << 20));
     c.arena_limit_max_bytes = std::max<size_t>(c.arena_limit_bytes, std::min<size_t>((size_t)32 << 30, share));
   }
-  if (wfagpu_amd_create(&l.ctx, &c)) return -1;
+  wfagpu_amd_ctx_t* ctx = nullptr;
+  if (wfagpu_amd_create(&ctx, &c)) return -1;
+  publish(d, l.ctx, ctx);
   return 0;
 }
 
@@ -354,20 +363,22 @@ int make_lane(DevState& d, int k, const wfagpu_amd_launch_config_t& cfg) {
 // wfagpu_set_default_options does for the API -- the moment the reference creates its CUDA context, cudaGetDeviceCount):
 // a call that comes later finds the device up.  wfagpu_amd_release_cache() (and bench.py's cold leg) undo all of it.
 int create_up(DevState& d) {
-  if (d.up) return 0;
-  HIP_OK(copy_stream(&d.up));
+  hipStream_t s = nullptr;
+  HIP_OK(copy_stream(&s));
   // (the first pageable copy of a process pays ~15 ms of set-up: a small one now, not the first batch later)
   static char warm_src[1 << 16];
   if (!d.d_scratch) HIP_OK(hipMalloc(&d.d_scratch, sizeof(warm_src)));
-  HIP_OK(hipMemcpyAsync(d.d_scratch, warm_src, sizeof(warm_src), hipMemcpyHostToDevice, d.up));
+  HIP_OK(hipMemcpyAsync(d.d_scratch, warm_src, sizeof(warm_src), hipMemcpyHostToDevice, s));
+  publish(d, d.up, s);
   return 0;
 }
 int create_down(DevState& d) {
-  if (d.down) return 0;
-  HIP_OK(copy_stream(&d.down));
+  hipStream_t s = nullptr;
+  HIP_OK(copy_stream(&s));
   if (!d.h_scratch) HIP_OK(hipHostMalloc(&d.h_scratch, 4096, hipHostMallocDefault));
   if (!d.d_scratch) HIP_OK(hipMalloc(&d.d_scratch, 1 << 16));
-  HIP_OK(hipMemcpyAsync(d.h_scratch, d.d_scratch, 4096, hipMemcpyDeviceToHost, d.down));
+  HIP_OK(hipMemcpyAsync(d.h_scratch, d.d_scratch, 4096, hipMemcpyDeviceToHost, s));
+  publish(d, d.down, s);
   return 0;
 }
 // code objects: whoever gets here first loads them (on lane k's stream), the others go on (a launch that needs a code
@@ -381,22 +392,29 @@ void prime_once(DevState& d, int k) {
 // An item of the device state, created by the bring-up thread if it gets there first -- the caller then waits for exactly
 // that item --, else by the caller.
 template <typename Ready, typename Create> int ensure_item(DevState& d, Ready ready, Create create) {
-  std::unique_lock<std::mutex> l(d.bring_mu);
-  d.bring_cv.wait(l, [&] { return ready() || !d.bring_active; });
-  if (ready()) return 0;
+  {
+    std::unique_lock<std::mutex> l(d.bring_mu);
+    d.bring_cv.wait(l, [&] { return ready() || !d.bring_active; });
+    if (ready()) return 0;
+  }
+  std::lock_guard<std::mutex> c(d.create_mu);
+  { std::lock_guard<std::mutex> l(d.bring_mu); if (ready()) return 0; }
   return create();
 }
 void bring_up_fn(DevState* dp, wfagpu_amd_launch_config_t cfg, int lanes, bool prime) {
   DevState& d = *dp;
   bool ok = hipSetDevice(d.device) == hipSuccess;
-  auto step = [&](auto create) {
-    if (ok) { std::lock_guard<std::mutex> l(d.bring_mu); ok = create() == 0; }
-    d.bring_cv.notify_all();
+  auto step = [&](auto ready, auto create) {
+    if (!ok) return;
+    std::lock_guard<std::mutex> c(d.create_mu);
+    bool have;
+    { std::lock_guard<std::mutex> l(d.bring_mu); have = ready(); }
+    if (!have) ok = create() == 0;
   };
-  step([&] { return create_up(d); });
+  step([&] { return d.up != nullptr; }, [&] { return create_up(d); });
   d.bring_clock[0] = now_ms();
-  for (int k = 0; k < lanes; ++k) { step([&] { return make_lane(d, k, cfg); }); d.bring_clock[1 + k] = now_ms(); }
-  step([&] { return create_down(d); });
+  for (int k = 0; k < lanes; ++k) { step([&] { return d.lane[k].ctx != nullptr; }, [&] { return make_lane(d, k, cfg); }); d.bring_clock[1 + k] = now_ms(); }
+  step([&] { return d.down != nullptr; }, [&] { return create_down(d); });
   d.bring_clock[1 + MAX_LANES] = now_ms();
   if (ok && prime) prime_once(d, 0);      // (background bring-up: no compute lane is waiting to do it)
   { std::lock_guard<std::mutex> l(d.bring_mu); d.bring_active = false; }
@@ -541,6 +559,7 @@ int run_device(const CallArgs& a, Shard& sh) {
   struct BatchClock { double prep0 = 0, prep1 = 0, up0 = 0, up1 = 0, dev0 = 0, dev1 = 0, d2h1 = 0, sc0 = 0, sc1 = 0; };      // (timing >= 2: ms since the start of the slice)
   std::vector<BatchClock> clk(nb);
   struct StageTimes { double prep = 0, pack = 0, up = 0, up_wait = 0, dev = 0, dev_wait = 0, d2h = 0, scatter = 0, check = 0; };
+  double prep0_detail[3] = {0, 0, 0};      // (timing: batch 0's record sweep, staging allocation, packing)
   StageTimes t_prep_thread, t_up_thread;
   std::vector<StageTimes> t_lane(K), t_scat(K);
 
@@ -578,6 +597,7 @@ int run_device(const CallArgs& a, Shard& sh) {
         }
         strip[t] = st;
       });
+      if (i == 0) prep0_detail[0] = now_ms() - t0;
       size_t lo = SIZE_MAX, hi = 0, packed_bytes = 0;
       unsigned max_len = 0;
       std::vector<size_t> strip_off(nt);
@@ -611,12 +631,15 @@ int run_device(const CallArgs& a, Shard& sh) {
           if (!hs.p) { hs.cap = 0; LOG_ERROR("Can not allocate the packing buffer"); fl.fail(-1); return; }
         }
         stage = hs.p;
+        if (i == 0) prep0_detail[1] = now_ms() - tp0;
       }
       std::atomic<int> bad{0};
+      const double t_pack0 = now_ms();
       parallel_for(nt, [&](unsigned t) {
         const size_t j0 = b.from + n * t / nt, j1 = b.from + n * (t + 1) / nt;
         if (wfagpu_host_pack_strip(a.seq, a.seq_bytes, a.meta + j0, j1 - j0, strip_off[t], stage)) bad.store(1);
       });
+      if (i == 0) prep0_detail[2] = now_ms() - t_pack0;
       if (host_pack) {
         // (a byte outside ACGT: those pairs need their ASCII on the device, the whole batch goes up as it is)
         b.host_packed = bad.load() == 0;
@@ -867,6 +890,8 @@ int run_device(const CallArgs& a, Shard& sh) {
       for (int k = 0; k < K; ++k) fprintf(stderr, ", lane %d %.2f", k, d.bring_clock[1 + k] - t_begin);
       fprintf(stderr, ", download stream %.2f\n", d.bring_clock[1 + MAX_LANES] - t_begin);
     }
+    fprintf(stderr, "[wfagpu timing]   batch 0 prep: record sweep %.2f ms, staging buffer %.2f, offsets + packing %.2f (%u threads)\n",
+            prep0_detail[0], prep0_detail[1], prep0_detail[2], prep_threads);
     for (int i = 0; i < nb; ++i)
       fprintf(stderr, "[wfagpu timing]   batch %2d (%zu pairs): prep %.2f - %.2f | upload issued %.2f, landed <= %.2f | device %.2f - %.2f | d2h done %.2f | scatter %.2f - %.2f\n",
               i, plan[i].to - plan[i].from, clk[i].prep0, clk[i].prep1, clk[i].up0, clk[i].up1, clk[i].dev0, clk[i].dev1, clk[i].d2h1, clk[i].sc0, clk[i].sc1);
@@ -949,7 +974,12 @@ void launch_impl(char* seq, size_t seq_bytes, sequence_pair_t* meta, wfa_alignme
   st.devices = ndev;
   st.host_threads = host_threads;
   st.total_ms = now_ms() - t_begin;
-  { std::lock_guard<std::mutex> l(g_cfg_mu); g_last_stats = st; }
+  {
+    std::lock_guard<std::mutex> l(g_cfg_mu);
+    g_last_stats = st;
+    g_last_shard_stats.clear();
+    for (auto& s : shards) { s.st.devices = s.device; s.st.host_threads = s.host_threads; g_last_shard_stats.push_back(s.st); }
+  }
 }
 
 }  // namespace
@@ -965,6 +995,13 @@ void wfagpu_amd_last_launch_stats(wfagpu_amd_launch_stats_t* out) {
   if (!out) return;
   std::lock_guard<std::mutex> l(g_cfg_mu);
   *out = g_last_stats;
+}
+
+int wfagpu_amd_last_launch_stats_device(int shard, wfagpu_amd_launch_stats_t* out) {
+  std::lock_guard<std::mutex> l(g_cfg_mu);
+  if (!out || shard < 0 || shard >= (int)g_last_shard_stats.size()) return -1;
+  *out = g_last_shard_stats[shard];
+  return 0;
 }
 
 void wfagpu_amd_set_num_devices(int n) {

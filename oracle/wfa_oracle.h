@@ -75,6 +75,15 @@ int oracle_check_cigar(const char* pattern, int plen, const char* text,
                        int tlen, const char* cigar, int x, int o, int e,
                        int* cost_out);
 
+/* The reference's ADAPTIVE-BAND distance kernel restated deterministically (band_oracle.c; lib/kernels/
+ * sequence_distance_kernel_aband.cu): beta = diagonals kept per wavefront (the reference's threads per block), lambda = the
+ * re-centring period (-B), max_steps = the reference's max_steps (-e).  Returns the distance the kernel would report;
+ * *finished_out = 0 when it gave up (steps exhausted) -- the reference then falls back to the CPU. */
+int oracle_band_ref(const char* pattern, int plen, const char* text, int tlen, int x, int o, int e,
+                    int beta, int lambda, int max_steps, int* finished_out, int* steps_out);
+int64_t oracle_band_ref_batch(const char* seqbuf, const int64_t* offsets, int64_t n, int x, int o, int e, int beta, int lambda,
+                              int max_steps, int32_t* scores, int nthreads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -105,6 +105,21 @@ def oracle_batch(buf, meta, pen, cigar=True, nthreads=1):
     return scores, (_split(cbuf, n, stride) if cigar else None), cells.value
 
 
+def band_ref_batch(buf, meta, pen, beta, lam, max_steps, nthreads=1):
+    """The reference's adaptive-band distance kernel restated (oracle/band_oracle.c): -> scores int32[n], -1 where the pair
+    did not finish inside the band within max_steps."""
+    o = oracle()
+    o.oracle_band_ref_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_int]
+    o.oracle_band_ref_batch.restype = C.c_int64
+    n = len(meta)
+    off = _offsets(meta)
+    scores = np.zeros(n, dtype=np.int32)
+    buf = np.ascontiguousarray(buf)
+    o.oracle_band_ref_batch(buf.ctypes.data, off.ctypes.data, n, pen[0], pen[1], pen[2], beta, lam, max_steps, scores.ctypes.data, nthreads)
+    return scores
+
+
 def ref_batch(buf, meta, pen, cigar=True, memory_mode=0, nthreads=1):
     r = ref()
     n = len(meta)

@@ -42,7 +42,8 @@
 //     picks the one that matches the rings LDS lets a CU hold.  NW > 1: one barrier per score.
 //   * Score loops: the careful one; the closed-form lean loop (exact LDS tiers, e == 1); the general lean loop
 //     (LDS tiers, any gap extension, and the adaptive band); one lean loop for the tiers whose ring lives in
-//     HBM.  They share the cells, refill_arena (the one place arena space is claimed) and band_cut.
+//     HBM.  They share the cells and refill_arena (the one place arena space is claimed); the banded search has one loop
+//     of its own over the same cells.
 //   * Adaptive band (BANDED): a row holds band_width diagonals, stored relative to its own lower limit
 //     between two NULL guard zones -- per-row scalar offsets on the row addresses, the same cells and loops
 //     as the exact search; the band moves by at most two diagonals per score.
@@ -174,12 +175,12 @@ wfa_align_kernel(const WfaAlignParams p) {
   // the exact tiers with 16-bit offsets in LDS (0, 1, 2 and the hybrid ring, whose D rows live in global memory): their
   // lean loops have a form of their own; HM_ROW: the one-wave tier also keeps min(plen + k, tlen) per diagonal in LDS (the
   // multi-wave tiers are LDS-bound: 16k x 10 kbp, four waves: 6 rings per CU without the row, 5 with it, 16.4 vs 17.7 ms)
-  // BANDED (adaptive band, a heuristic): every score's limits are cut to band_width diagonals (band_cut below) and a ring
-  // row holds just those: the row of a score is stored RELATIVE to its own lower limit (column GZ = its diagonal lo), so
-  // the "diagonal 0" address of a row is its slot base plus a per-row scalar offset -- everything else (lean cells, lean
-  // loop, ring invariant through NULL guard zones) is shared with the exact search.  The band moves by at most two
-  // diagonals per score, so the rows a cell reads (at most dm scores old) sit within 2 dm diagonals of its own row and
-  // every read lands in a row's cells or in its guard zones (GZ = 4 dm + 2 columns on either side, NULL).
+  // BANDED (adaptive band, a heuristic): every score keeps band_width diagonals, chosen by the reference's rule (band_window
+  // below), and a ring row holds just those: the row of a score is stored RELATIVE to its own lower limit (column GZ = its
+  // diagonal lo), so the "diagonal 0" address of a row is its slot base plus a per-row scalar offset -- the cells (lean and
+  // generic) are shared with the exact search.  While the rows a cell reads lie within GZ - 1 diagonals of its own row, every
+  // read lands in a row's cells or in its guard zones (GZ columns on either side, NULL) and needs no range test; after a
+  // re-centring jump the generic cells range-check every read.
   constexpr bool HOT = !GLOBAL_RING && sizeof(OffT) == 2;
   constexpr bool HM_ROW = HOT && !HYBRID && NW == 1 && !BANDED;
   const int GZ = BANDED ? 4 * dm + 2 : 0;
@@ -436,9 +437,13 @@ wfa_align_kernel(const WfaAlignParams p) {
       //   rb_ie[k] = I[s-e][k-1] rb_de[k] = D[s-e][k+1]     wb_*[k]: the rows written now
       // LEAN (regular regime, no cell has touched a sequence end yet): no value can run past an end, so the
       // overrun test and the saturation of I are dropped.  wave_touch: lanes whose M cell reached min(plen + k, tlen).
+      // (BANDED: wx, wo, we = the windows -- pack_range(lo, hi), ROW_NONE_A for a row that does not exist -- of the rows M[s-x],
+      // M[s-o-e] and I/D[s-e]: every read is range-checked against its row's window like the reference's get_offset,
+      // lib/kernels/sequence_distance_kernel_aband.cu:28-33, because after a re-centring the rows of neighbouring scores
+      // can lie anywhere relative to each other)
       auto cells_of_score = [&](auto lean_tag, const int lo, const int hi, uint8_t* codes, const OffT* rb_mx, const OffT* rb_mo,
                                 const OffT* rb_ie, const OffT* rb_de, OffT* wb_m, OffT* wb_i, OffT* wb_d,
-                                bool& my_over, unsigned long long& wave_touch) {
+                                bool& my_over, unsigned long long& wave_touch, const int wx = 0, const int wo = 0, const int we = 0) {
         constexpr bool LEAN = decltype(lean_tag)::value;
         // (the 16-bit LDS tiers never get here with LEAN set: their lean loops call hot_cells below)
         static_assert(!(LEAN && HOT), "lean cells of the LDS tiers live in hot_cells");
@@ -449,7 +454,16 @@ wfa_align_kernel(const WfaAlignParams p) {
           uint32_t code = 0;
           {
             int m_x, m_ol, m_or, i_e, d_e;
-            {
+            if constexpr (BANDED) {
+              auto rd = [&](const OffT* base, const int idx, const int kk, const int w) -> int {
+                return (kk >= range_lo(w) && kk <= range_hi(w)) ? (int)base[idx] : (int)OffNull<OffT>::value;
+              };
+              m_x = rd(rb_mx, k, k, wx);
+              m_ol = rd(rb_mo, k, k - 1, wo);
+              m_or = rd(rb_mo, k + 2, k + 1, wo);
+              i_e = rd(rb_ie, k, k - 1, we);
+              d_e = rd(rb_de, k, k + 1, we);
+            } else {
               m_x = (int)rb_mx[k];
               m_ol = (int)rb_mo[k];
               m_or = (int)rb_mo[k + 2];
@@ -668,50 +682,49 @@ wfa_align_kernel(const WfaAlignParams p) {
           codes -= adv;
         }
       };
-      // Adaptive band (reference: sequence_distance_kernel_aband.cu:104-130): a score keeps at most band_width diagonals;
-      // every band_period scores the window is re-centred on the diagonal of the mismatch-source wavefront M[score - x]
-      // (limits [mxlo, mxhi], `row_mx`: its diagonal 0) whose furthest point is closest to the end, otherwise the excess is
-      // shaved off both sides.  Deterministic (the reference's kernels race here).  Every thread calls it
-      // with the same arguments.
-      auto band_cut = [&](int& lo, int& hi, const int score, const int prev_lo, const int mxlo, const int mxhi, const OffT* row_mx) {
+      // Adaptive band: the window of a score, by the REFERENCE's rule (lib/kernels/sequence_distance_kernel_aband.cu:91-130, the
+      // CIGAR kernel sequence_alignment_kernel_aband.cu:147-205 alike; restated on the CPU in oracle/band_oracle.c, which the tests
+      // compare this kernel's banded scores with, pair by pair):
+      //   hi = max(Mx.hi, max(Mo.hi, I.hi, D.hi) + 1), lo = min(Mx.lo, min(Mo.lo, I.lo, D.lo) - 1) over the windows of the four input
+      //   rows (a row that does not exist yet counts as the window [0, 0] of an empty slot, :262-281);
+      //   too wide: hi--, lo++ in turn until beta diagonals are left (:100-104);
+      //   when the MISMATCH-source row M[s-x] is full width and s % lambda == 0: the diagonal of M[s-x] in [lo, hi) -- its last one is
+      //   not looked at -- whose offset is closest to the end (max(plen - v, tlen - h), first minimum) becomes the centre:
+      //   lo = centre - beta / 2, hi = lo + beta - 1, unconditionally (:114-130).
+      // No clipping to the sequence ends or to the score budget (the reference has none); deterministic where the reference's kernels
+      // race (a window is read before thread 0 has published it).  Every thread calls it with the same arguments.
+      // (round 3 shipped a rule of its own here -- re-centring only when the wavefront overflowed, clamped into the old window,
+      // at most two diagonals per score -- which lost pairs the reference's rule keeps: profiles/r04/banded.md.)
+      auto band_window = [&](int& lo, int& hi, const int score, const int wx, const int wo, const int we, const OffT* row_mx) {
         const int beta = p.band_width;
+        hi = max(range_hi(wx), max(range_hi(wo), range_hi(we)) + 1);
+        lo = min(range_lo(wx), min(range_lo(wo), range_lo(we)) - 1);
         const int excess = (hi - lo + 1) - beta;
-        if (excess > 0) {
-          bool recentred = false;
-          if (mxlo <= mxhi && (score % p.band_period) == 0) {
-            uint32_t best = 0xFFFFFFFFu;
-            for (int kk = mxlo + tid; kk <= mxhi; kk += NT) {
-              const int off = (int)row_mx[kk];
-              if (off >= 0) {
-                const int dist = max(plen - (off - kk), tlen - off);
-                best = min(best, ((uint32_t)dist << 16) | (uint32_t)(kk - mxlo));
-              }
-            }
-#pragma unroll
-            for (int d = 32; d > 0; d >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, d));
-            if constexpr (NW > 1) {
-              if (tid == 0) bslot[0] = 0xFFFFFFFFu;
-              __syncthreads();
-              if (lane == 0) atomicMin(&bslot[0], best);
-              __syncthreads();
-              best = bslot[0];
-              __syncthreads();
-            }
-            best = __builtin_amdgcn_readfirstlane(best);      // (uniform: keeps what follows on the scalar unit)
-            if (best != 0xFFFFFFFFu) {
-              const int centre = mxlo + (int)(best & 0xFFFFu);
-              const int nlo = max(lo, min(centre - beta / 2, hi - beta + 1));
-              lo = nlo; hi = nlo + beta - 1;
-              recentred = true;
+        if (excess > 0) { hi -= (excess + 1) / 2; lo += excess / 2; }
+        const int mxlo = range_lo(wx), mxhi = range_hi(wx);
+        if (mxhi - mxlo >= beta - 1 && (score % p.band_period) == 0) {
+          uint32_t best = 0xFFFFFFFFu;
+          for (int kk = mxlo + tid; kk < mxhi; kk += NT) {
+            const int off = (int)row_mx[kk];
+            if (off >= 0) {
+              const int dist = max(plen - (off - kk), tlen - off);
+              best = min(best, ((uint32_t)dist << 16) | (uint32_t)(kk - mxlo));
             }
           }
-          if (!recentred) { hi -= (excess + 1) / 2; lo += excess / 2; }
+#pragma unroll
+          for (int d = 32; d > 0; d >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, d));
+          if constexpr (NW > 1) {
+            if (tid == 0) bslot[0] = 0xFFFFFFFFu;
+            __syncthreads();
+            if (lane == 0) atomicMin(&bslot[0], best);
+            __syncthreads();
+            best = bslot[0];
+            __syncthreads();
+          }
+          best = __builtin_amdgcn_readfirstlane(best);      // (uniform: keeps what follows on the scalar unit)
+          const int centre = mxlo + (best != 0xFFFFFFFFu ? (int)(best & 0xFFFFu) : 0);
+          lo = centre - beta / 2; hi = lo + beta - 1;
         }
-        // The window moves by at most two diagonals per score (rows are stored relative to their lower limit: this is what
-        // keeps the rows a cell reads within reach of each other -- see GZ); a wavefront narrower than the band keeps its
-        // lower limit within the same bound.
-        const int slo = min(max(lo, prev_lo - 2), prev_lo + 2);
-        if (slo != lo) { lo = slo; hi = min(hi, lo + beta - 1); }
       };
       // Limits of the last score (the lean path derives the next ones from them alone).
       int last_lo = 0, last_hi = 0;
@@ -722,6 +735,111 @@ wfa_align_kernel(const WfaAlignParams p) {
       bool touched_ever = touched_at_0 || cold_params()->no_lean != 0;    // (WFAGPU_NO_LEAN: the lean path is never entered)
       // ---- score loop ----------------------------------------------------------------------------
       if (!done && status == WFA_ST_DONE) for (;;) {
+        // ---- the whole banded search: one loop, the reference's windows (band_window), the shared cells.  A ring row holds the
+        // diagonals of its window relative to the window's lower limit (column GZ = diagonal lo) between two NULL guard zones of
+        // GZ columns.  While every input row lies within GZ - 1 diagonals of the new window -- always, but for the few scores after
+        // a re-centring jump -- the lean cells read them without any range test (a read beside a row lands in its guard zones);
+        // otherwise, and once a cell has touched a sequence end, the generic cells run with every read checked against its row's
+        // window.  Scores without a wavefront and M-only scores (before the first gap can exist) follow the reference's
+        // existence logic (sequence_distance_kernel_aband.cu:331-372); a row that does not exist is an all-NULL slot with the
+        // window [0, 0], which is what the reference's never-written slots are (for penalty sets with e > 1 the reference re-reads
+        // whatever an older score left in such a slot: not reproduced -- INTEGRATION.md).
+        if constexpr (BANDED) {
+          constexpr int W00 = 0;                                      // pack_range(0, 0)
+          unsigned long long ex_m = 1ull, ex_i = 0ull;                // bit (score & 63): M / the gap components of that score exist
+          if constexpr (NW > 1) { if (tid == 0) bslot[1] = 0u; }
+          // (row book: M windows; rows that do not exist -- negative scores included -- read as the window [0, 0])
+          if constexpr (NW == 1) { book.a = W00; } else { for (int i = tid; i <= bkm; i += NT) book.A[i] = W00; }
+          book.set_a(0, W00);
+          block_sync<NW>();
+          for (;;) {
+            const int ns = s + 1;
+            if (ns > budget) { status = WFA_ST_SCORE; break; }
+            const bool has_oe = ns >= oe;
+            const bool e_oe = has_oe && ((ex_m >> ((ns - oe) & 63)) & 1ull), e_ie = has_oe && ((ex_i >> ((ns - e) & 63)) & 1ull);
+            const bool e_x = ns >= x && ((ex_m >> ((ns - x) & 63)) & 1ull);
+            const bool gap = e_oe || e_ie, mex = gap || e_x;
+            const unsigned long long bit = 1ull << (ns & 63);
+            ex_m = mex ? (ex_m | bit) : (ex_m & ~bit);
+            ex_i = gap ? (ex_i | bit) : (ex_i & ~bit);
+            s = ns;
+            p_m += rs;  if (p_m == m_end) p_m = m_first;
+            p_x += rs;  if (p_x == m_end) p_x = m_first;
+            p_oe += rs; if (p_oe == m_end) p_oe = m_first;
+            p_ic += rs; if (p_ic == i_end) p_ic = i_first;
+            p_ip += rs; if (p_ip == i_end) p_ip = i_first;
+            OffT* const out_m = p_m; OffT* const out_i = p_ic; OffT* const out_d = d_of(p_ic);
+            if (!mex) {
+              // no wavefront at this score: an all-NULL slot
+              for (int q = tid; q < p.band_width + 2 * GZ; q += NT) {
+                out_m[q] = (OffT)OffNull<OffT>::value; out_i[q] = (OffT)OffNull<OffT>::value; out_d[q] = (OffT)OffNull<OffT>::value;
+              }
+              book.set_a(s & bkm, W00);
+              block_sync<NW>();
+              continue;
+            }
+            // windows of the input rows ([0, 0] where a row does not exist)
+            const int wx = ns >= x ? book.get_a((ns - x) & bkm) : W00;
+            const int wo = has_oe ? book.get_a((ns - oe) & bkm) : W00;
+            const int we = e_ie ? book.get_a((ns - e) & bkm) : W00;
+            int lo, hi;
+            if (gap) band_window(lo, hi, ns, wx, wo, we, p_x + (GZ - range_lo(wx)));
+            else { lo = range_lo(wx); hi = range_hi(wx); }            // M only: the window of M[s-x] (:54-74)
+            const int width = hi - lo + 1;
+            ncells += (uint32_t)width;
+            uint8_t* codes = nullptr;
+            if constexpr (BT) {
+              if (!alloc_row(width)) { status = WFA_ST_NOMEM; break; }
+              tab_set(s, row_s, lo);
+              codes = p.arena + (size_t)row_s * 16;
+            }
+            // ring invariant of relative rows: NULL guard zones on both sides of the row, whatever the slot held before
+            for (int j = tid; j < 2 * GZ; j += NT) {
+              const int q = j < GZ ? j : width + j;
+              out_m[q] = (OffT)OffNull<OffT>::value; out_i[q] = (OffT)OffNull<OffT>::value; out_d[q] = (OffT)OffNull<OffT>::value;
+            }
+            // rows that exist: their own mapping (column GZ = their lower limit); others: all NULL, any mapping
+            const int rel_cur = GZ - lo;
+            const int rel_x = e_x ? GZ - range_lo(wx) : rel_cur, rel_oe = e_oe ? GZ - range_lo(wo) : rel_cur, rel_e = e_ie ? GZ - range_lo(we) : rel_cur;
+            auto near = [&](const bool exists, const int w) { return !exists || (range_lo(w) - lo <= GZ - 1 && hi - range_hi(w) <= GZ - 1); };
+            unsigned long long touch = 0;
+            bool lean_cells = false;
+            if constexpr (HOT) lean_cells = !touched_ever && near(e_x, wx) && near(e_oe, wo) && near(e_ie, we);
+            if (lean_cells) {
+              if constexpr (HOT) {
+                GlobalBytes ca = (GlobalBytes)(uintptr_t)codes + (uint32_t)tid;
+                const uint32_t a_dd = (uint32_t)(de * rs) * 2u;
+                uint32_t pw_addr = lds_addr(Pw), tw_addr = lds_addr(Tw);
+                asm volatile("" : "+s"(pw_addr), "+s"(tw_addr));
+                hot_cells(lo, width - 1, ca, lds_addr(p_oe) + ((uint32_t)rel_oe << 1), lds_addr(p_x) + ((uint32_t)rel_x << 1),
+                          lds_addr(out_m) + ((uint32_t)rel_cur << 1), lds_addr(p_ip) + ((uint32_t)rel_e << 1), lds_addr(out_i) + ((uint32_t)rel_cur << 1),
+                          lds_addr(p_ip) + a_dd + ((uint32_t)rel_e << 1), lds_addr(out_i) + a_dd + ((uint32_t)rel_cur << 1), pw_addr, tw_addr, 0u, touch);
+              }
+            } else {
+              bool my_over = false;
+              cells_of_score(std::false_type{}, lo, hi, codes, p_x + rel_x, p_oe + rel_oe - 1, p_ip + rel_e - 1, d_of(p_ip) + rel_e + 1,
+                             out_m + rel_cur, out_i + rel_cur, out_d + rel_cur, my_over, touch,
+                             e_x ? wx : ROW_NONE_A, e_oe ? wo : ROW_NONE_A, e_ie ? we : ROW_NONE_A);
+            }
+            bool any_touch;
+            if constexpr (NW == 1) {
+              block_sync<NW>();
+              any_touch = touch != 0ull;
+            } else {
+              if (touch != 0ull && lane == 0) atomicOr(&bslot[1], 1u);
+              __syncthreads();
+              any_touch = bslot[1] != 0u;
+            }
+            touched_ever |= any_touch;
+            // termination (:380-387): M[s][k*] == tlen
+            if (touched_ever)
+              done = ((unsigned)(kend - lo) <= (unsigned)(hi - lo)) && __builtin_amdgcn_readfirstlane((int)out_m[rel_cur + kend]) >= tlen;
+            book.set_a(s & bkm, pack_range(lo, hi));
+            if constexpr (NW == 1) block_sync<NW>();
+            if (done) break;
+          }
+          break;
+        }
         // ---- lean path: gap extension 1 and no cell has touched a sequence end yet.  Then no value can run past an end,
         // nothing is ever trimmed, and with e == 1 the limits of wavefront_compute.c:41-71 collapse to [lo - 1, hi + 1] of
         // the last score (the I and D rows of s-1 span its M limits), clipped by the window and the budget's reach.  It starts
@@ -887,9 +1005,9 @@ wfa_align_kernel(const WfaAlignParams p) {
         // its limits here), the reach interval moves one diagonal every e scores, and scores without any predecessor row
         // (all odd scores of an all-even penalty set) are "no wavefront" scores: their ring slots are cleared and nothing
         // is computed.
-        if constexpr (HOT) {
+        if constexpr (HOT && !BANDED) {
           // (the same trimmed bookkeeping as the e == 1 loop above, except that the limits come from the row book)
-          if ((BANDED || e != 1) && !touched_ever) {
+          if (e != 1 && !touched_ever) {
             const int s_in = s;
             const uint32_t rsb = (uint32_t)rs * 2u;
             const uint32_t a_first = lds_addr(m_first), a_end = lds_addr(m_end), ai_first = lds_addr(i_first), ai_end = lds_addr(i_end);
@@ -924,11 +1042,6 @@ wfa_align_kernel(const WfaAlignParams p) {
               lo = max(lo, wlo); hi = min(hi, whi);
               if constexpr (NW == 1) asm volatile("" : "+s"(lo), "+s"(hi));
               lo = max(lo, n_rlo); hi = min(hi, n_rhi);
-              if constexpr (BANDED) {
-                uint32_t ax_n = a_x + rsb; if (ax_n == a_end) ax_n = a_first;       // slot of M[ns - x]; its diagonal 0: + (GZ - lo of that row)
-                band_cut(lo, hi, ns, prev_lo, range_lo(b_x), range_hi(b_x),
-                         reinterpret_cast<const OffT*>(reinterpret_cast<const char*>(m_first) + (ax_n - a_first)) + (GZ - range_lo(b_x)));
-              }
               const bool none = lo > hi;
               if (__builtin_expect(none && bounded && ns > budget, 0)) { why = 1; continue; }      // the careful path reports it
               const int wm1 = hi - lo;
@@ -1188,7 +1301,7 @@ wfa_align_kernel(const WfaAlignParams p) {
           block_sync<NW>();
           continue;
         }
-        if constexpr (BANDED) band_cut(lo, hi, s, last_lo, mxlo, mxhi, p_x + (GZ - mxlo));
+        // (the banded search has a loop of its own above and never gets here)
         const int width = hi - lo + 1;
         ncells += (uint32_t)width;
 

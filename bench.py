@@ -297,11 +297,16 @@ def parity_sample(buf, meta, wl, n_pairs, d_scores, ptrs, st, band):
             so, co, _ = oracle_lib.oracle_batch(buf, meta[:k], PEN, cigar=wl["cigar"], nthreads=min(8, usable_cores()))
         cg = wfagpu.fetch_cigars(ptrs[0], ptrs[1], ptrs[2], n_pairs, st.text_bytes)[:k] if wl["cigar"] else None
         if band:
-            # the adaptive band is a heuristic: valid alignments, cost == score >= optimum; recall reported
+            # the adaptive band is a heuristic: valid alignments, cost == score >= optimum, and never worse than the
+            # reference's own band rule restated on the CPU (oracle/band_oracle.c) gives for the pair; recall reported
             pairs = wfagpu.pairs_from_layout(buf, meta[:k])
             chk = [oracle_lib.check_cigar(p, t, c, PEN) for (p, t), c in zip(pairs, cg)]
             ok = all(o and cost == s for (o, cost), s in zip(chk, scores)) and bool((scores >= so).all())
-            return {"pairs": k, "valid_and_cost_equals_score": ok, "recall": float((scores == so).mean())}
+            sr = oracle_lib.band_ref_batch(buf, meta[:k], PEN, band[1], band[0], wl["max_error"], nthreads=min(16, usable_cores()))
+            want = np.where(sr >= 0, sr, so)
+            return {"pairs": k, "valid_and_cost_equals_score": ok, "recall": float((scores == so).mean()),
+                    "not_above_the_reference_band_rule": bool((scores <= want).all()),
+                    "reference_band_rule_recall": float(((sr >= 0) & (sr == so)).mean())}
         return {"pairs": k, "bit_exact_vs_oracle": bool(np.array_equal(scores, so)) and (not wl["cigar"] or cg == co)}
     except Exception as ex:  # the checker is optional for the measurement itself
         return {"error": str(ex)}

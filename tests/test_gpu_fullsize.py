@@ -175,6 +175,36 @@ def test_cfg4_full_size_scores_and_cigars(band):
             assert c2 == [_cigar(text, off, ln, i) for i in range(n)]
 
 
+def test_cfg4_full_size_with_the_band_forced():
+    """configs[3] as BASELINE states it -- 10 kbp pairs at 3 %, -B auto (re-centre every 25 scores) -t 512 -- on the BANDED
+    kernels at full size (tuning.force_band: by default this batch runs exactly, the band policy of DESIGN.md section 8):
+    score-only results equal the reference's adaptive-band rule restated on the CPU (oracle/band_oracle.c) for ALL 16 384
+    pairs; with CIGARs every alignment is valid, its cost is the reported score, optimum <= score <= the reference rule's."""
+    n = 16_384
+    buf, meta = wfagpu.generate_pairs(n, 10_000, 0.03, seed=1000, nthreads=_threads())
+    so, _ = _truth(buf, meta, cigar=False)
+    sr = oracle_lib.band_ref_batch(buf, meta, PEN, 512, 25, 3000, nthreads=_threads())
+    assert (sr >= 0).all()                      # (the band of 512 diagonals holds every one of these pairs)
+    al = wfagpu.DeviceAligner(0, force_band=1)
+    try:
+        batch = al.upload(buf, meta)
+        d_s, _ = al.align(batch, PEN, max_error=3000, compute_cigar=False, band=25, band_width=512, fetch=False)
+        st0 = al.stats()
+        s0 = d_s.cpu().numpy().copy()
+        scores, off, ln, text, st = _device_results(al, batch, max_error=3000, band=25, band_width=512)
+    finally:
+        al.close()
+    # (the rest: the 1024-pair sample the score budgets are tuned on -- aligned exactly -- and budget misses, re-run exactly)
+    assert st0.pairs_banded > 0.9 * n and st.pairs_banded > 0.9 * n
+    assert np.array_equal(s0, sr)
+    print(f"cfg4, band forced: {st.pairs_banded}/{n} pairs inside the band, recall {(sr == so).mean():.4f} (reference rule: the same pairs)")
+    assert (scores >= so).all() and (scores <= sr).all()
+    pairs = wfagpu.pairs_from_layout(buf, meta)
+    for i in range(n):
+        ok, cost = oracle_lib.check_cigar(pairs[i][0], pairs[i][1], _cigar(text, off, ln, i), PEN)
+        assert ok and cost == scores[i], i
+
+
 def test_cfg5_full_size_scores_and_cigars():
     n = 1024
     buf, meta = wfagpu.generate_pairs(n, 30_000, 0.10, seed=1000, nthreads=_threads())

@@ -229,3 +229,29 @@ def test_oracle_pack_layout():
     dec = bytes(lut[(words[i // 16] >> (2 * (i % 16))) & 3] for i in range(len(seq)))
     assert dec == seq
     assert oracle_lib.oracle().oracle_pack2(b"ACGN", 4, words) == 1
+
+
+def test_band_restatement_properties():
+    """oracle/band_oracle.c restates the reference's adaptive-band kernel (lib/kernels/sequence_distance_kernel_aband.cu); the
+    kernel itself cannot run here (CUDA), so the restatement is held by what must be true of it: with a band wider than any
+    wavefront it returns the exact gap-affine score (= WFA2's) for every penalty set; identical sequences score 0; a pair whose
+    end diagonal lies outside any window the band can reach within the step limit is reported unfinished; the result does not
+    depend on the thread count."""
+    rng = random.Random(99)
+    pairs = _rand_pairs(rng, 200, 300, err=0.08) + _rand_pairs(rng, 40, 2000, err=0.05) + [(b"ACGT" * 50, b"ACGT" * 50), (b"", b"ACGT"), (b"A", b"")]
+    buf, meta = wfagpu.layout_pairs(pairs)
+    for pen in ((2, 3, 1), (1, 2, 1), (3, 1, 4), (5, 3, 2), (4, 6, 2), (1, 0, 1)):
+        so, _, _ = oracle_lib.oracle_batch(buf, meta, pen, cigar=False, nthreads=4)
+        sb = oracle_lib.band_ref_batch(buf, meta, pen, 8192, 25, 20000, nthreads=4)
+        assert np.array_equal(sb, so), pen
+        assert np.array_equal(oracle_lib.band_ref_batch(buf, meta, pen, 8192, 25, 20000, nthreads=1), sb)
+    same = pairs.index((b"ACGT" * 50, b"ACGT" * 50))
+    assert oracle_lib.band_ref_batch(buf, meta, (2, 3, 1), 4, 10, 100)[same] == 0
+    # 600 extra bases at the end of the text: the end diagonal is +600, a band of 64 that re-centres on the furthest point
+    # follows it; a band that never re-centres (lambda beyond the step limit) cannot get there
+    t = bytes(rng.choice(b"ACGT") for _ in range(1500))
+    b2, m2 = wfagpu.layout_pairs([(t[:900], t)])
+    exact = oracle_lib.oracle_batch(b2, m2, (2, 3, 1), cigar=False)[0][0]
+    assert exact == 3 + 600
+    assert oracle_lib.band_ref_batch(b2, m2, (2, 3, 1), 64, 10, 2000)[0] >= exact
+    assert oracle_lib.band_ref_batch(b2, m2, (2, 3, 1), 64, 100000, 2000)[0] == -1

@@ -35,6 +35,9 @@ typedef struct {
                               (0: matched to the rings LDS lets a CU hold)                                               */
     int trace_mode;        /* 0: automatic; 1: lane-per-alignment walk + windowed emit whatever the length (the fallback
                               of the wave-per-alignment kernel); 2: never several alignments per wavefront               */
+    int timed_barriers;    /* diagnostics: the multi-wave exact CIGAR tiers (1 and 4) run an instantiation in which workgroup 0
+                              records when each of its waves reaches and leaves the per-score barrier (s_memtime);
+                              wfagpu_amd_debug_times() hands the records out                                              */
 } wfagpu_amd_tuning_t;
 
 typedef struct {
@@ -113,6 +116,11 @@ void wfagpu_amd_trim(wfagpu_amd_ctx_t* ctx);
  * runtime loads a code object at the first launch of any of its kernels, 5-25 ms): a cold caller does this while it
  * waits for its first upload.  Returns without synchronising.  0 on success. */
 int wfagpu_amd_prime(wfagpu_amd_ctx_t* ctx);
+
+/* tuning.timed_barriers: the device buffer of the last call's barrier records -- per score of workgroup 0's alignments and
+ * per wave three uint64: s_memtime at arrival, s_memtime at release, (score << 32 | wavefront width - 1) -- and the number
+ * of waves per workgroup of the launch that wrote them; *records = scores recorded (0 when nothing was). */
+void wfagpu_amd_debug_times(const wfagpu_amd_ctx_t* ctx, const void** d_records, unsigned int* records, int* waves);
 
 /* The HIP stream (hipStream_t) the context runs on -- its own, or the one given at creation. */
 void* wfagpu_amd_stream(const wfagpu_amd_ctx_t* ctx);

@@ -167,6 +167,14 @@ static void trim(const oracle_aligner_t* al, owf_t* w) {
   w->null = (w->lo > w->hi);
 }
 
+/* EXPERIMENT SWITCH (tests/scratch only, default off = WFA2's semantics): null every I and D value that ran past a sequence
+ * end the moment it is computed -- what a kernel that keeps one diagonal per lane and no per-row limits would do
+ * (wfa-gpu_amd/csrc/short_kernel.hip does, score-only).  WFA2 keeps such values and only trims them at the ends of a row
+ * (wavefront_compute.c:570-603).  scratch/short_cigar_semantics.py looks for pairs whose CIGAR changes. */
+static int g_null_invalid_gaps = 0;
+void oracle_set_null_invalid_gaps(int on) { g_null_invalid_gaps = on; }
+#define GAP_FIX(val, kk) do { if (g_null_invalid_gaps && ((uint32_t)(val) > tlen || (uint32_t)((val) - (kk)) > plen)) (val) = ONULL; } while (0)
+
 /* wavefront/wavefront_compute_affine.c:228-259 + :45-87 (kernel) +
  * wavefront_compute.c:41-71 (limits) + :401-437 (which outputs exist) */
 static void compute_step(oracle_aligner_t* al, int s, oracle_stats_t* st) {
@@ -223,8 +231,9 @@ static void compute_step(oracle_aligner_t* al, int s, oracle_stats_t* st) {
       const int32_t* restrict pmx = MX.off - MX.base;
       int32_t* restrict qi = oi->off - lo; int32_t* restrict qd = od->off - lo; int32_t* restrict qm = om->off - lo;
       for (int kk = in_lo; kk <= in_hi; ++kk) {
-        const int32_t ins = OMAX(pmo[kk - 1], pie[kk - 1]) + 1;
-        const int32_t del = OMAX(pmo[kk + 1], pde[kk + 1]);
+        int32_t ins = OMAX(pmo[kk - 1], pie[kk - 1]) + 1;
+        int32_t del = OMAX(pmo[kk + 1], pde[kk + 1]);
+        GAP_FIX(ins, kk); GAP_FIX(del, kk);
         const int32_t mis = pmx[kk] + 1;
         int32_t mx3 = OMAX(del, OMAX(mis, ins));
         const uint32_t h = (uint32_t)mx3, v = (uint32_t)(mx3 - kk);
@@ -235,8 +244,9 @@ static void compute_step(oracle_aligner_t* al, int s, oracle_stats_t* st) {
       k = in_hi;
       continue;
     }
-    const int32_t ins = OMAX(rd(&MOE, k - 1), rd(&IE, k - 1)) + 1;
-    const int32_t del = OMAX(rd(&MOE, k + 1), rd(&DE, k + 1));
+    int32_t ins = OMAX(rd(&MOE, k - 1), rd(&IE, k - 1)) + 1;
+    int32_t del = OMAX(rd(&MOE, k + 1), rd(&DE, k + 1));
+    GAP_FIX(ins, k); GAP_FIX(del, k);
     const int32_t mis = rd(&MX, k) + 1;
     int32_t mx3 = OMAX(del, OMAX(mis, ins));
     const uint32_t h = (uint32_t)mx3, v = (uint32_t)(mx3 - k);

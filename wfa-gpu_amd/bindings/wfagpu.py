@@ -47,7 +47,8 @@ class Aligner(C.Structure):  # wfagpu_aligner_t
 
 class Tuning(C.Structure):  # wfagpu_amd_tuning_t: all zero = the defaults
     _fields_ = [("min_tier", C.c_int), ("careful_only", C.c_int), ("force_band", C.c_int), ("no_auto_budget", C.c_int),
-                ("max_blocks_per_cu", C.c_int), ("t0_min_blocks", C.c_int), ("waves_per_simd", C.c_int), ("trace_mode", C.c_int)]
+                ("max_blocks_per_cu", C.c_int), ("t0_min_blocks", C.c_int), ("waves_per_simd", C.c_int), ("trace_mode", C.c_int),
+                ("timed_barriers", C.c_int)]
 
 
 class Config(C.Structure):  # wfagpu_amd_config_t
@@ -97,7 +98,7 @@ ABI_SYMBOLS = [
     "wfagpu_amd_align_device", "wfagpu_amd_last_stats", "wfagpu_amd_set_num_devices", "wfagpu_amd_release_cache",
     "wfagpu_amd_check_failures", "wfagpu_amd_hint_same_stream", "wfagpu_amd_configure_launch",
     "wfagpu_amd_last_launch_stats", "wfagpu_amd_set_tuning", "wfagpu_amd_stream", "wfagpu_amd_trim", "wfagpu_amd_prime",
-    "wfagpu_amd_warmup", "wfagpu_amd_last_launch_stats_device",
+    "wfagpu_amd_warmup", "wfagpu_amd_last_launch_stats_device", "wfagpu_amd_debug_times",
     "wfagpu_host_pack_sequence", "wfagpu_host_pack_sequence_scalar", "wfagpu_host_pack_strip",
 ]
 

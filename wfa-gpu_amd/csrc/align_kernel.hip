@@ -162,7 +162,9 @@ __device__ __forceinline__ ColdParams cold_params() {
 // where that leaves 7 or fewer waves per SIMD, the register diet of 8 (64 VGPRs, 78 SGPRs: 123 scalar spills, each a
 // v_readlane/v_writelane on the pipe the kernel saturates, and scratch) buys nothing; the host picks the instantiation
 // that matches the rings a CU holds (plan_tier).
-template <int NW, bool BT, typename OffT, bool GLOBAL_RING, bool RAW, bool BANDED, bool HYBRID = false, int WPE = 8>
+// TIMED (diagnostics, tuning.timed_barriers): workgroup 0 records, for every score of the closed-form lean loop, the s_memtime
+// at which each of its waves reaches the per-score barrier and the one at which it leaves it (profiles/r04/barrier_skew.md).
+template <int NW, bool BT, typename OffT, bool GLOBAL_RING, bool RAW, bool BANDED, bool HYBRID = false, int WPE = 8, bool TIMED = false>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu((NW == 1 && !BANDED) ? WPE : 1, 8)))
 wfa_align_kernel(const WfaAlignParams p) {
   static_assert(!HYBRID || (!GLOBAL_RING && !BANDED), "the hybrid ring is an exact LDS tier");
@@ -170,6 +172,10 @@ wfa_align_kernel(const WfaAlignParams p) {
   constexpr int NT = NW * 64;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
+  // (which 64-diagonal stripe of a row this thread's wave takes in the lean cells: wave order.  Reversing it for the four-wave
+  // tier -- so that wave 0, which also keeps the row table and is the last at the barrier in 48 % of the scores,
+  // profiles/r04/barrier_skew.md, gets the fewest chunks -- measured 13.0 -> 13.3 ms on BASELINE configs[3]: not kept.)
+  const int stid = tid;
   const int dm = p.dm, de = p.de, rs = p.rs;
   constexpr int ROW_PAD = (!GLOBAL_RING && sizeof(OffT) == 2) ? WFA_RING_ROW_PAD : 0;     // (see wfa_device.h)
   // the exact tiers with 16-bit offsets in LDS (0, 1, 2 and the hybrid ring, whose D rows live in global memory): their
@@ -208,6 +214,7 @@ wfa_align_kernel(const WfaAlignParams p) {
   else { book.A = reinterpret_cast<int*>(bslot + 2); book.I = book.A + (bkm + 1); book.D = book.I + (bkm + 1); }
 
   uint32_t chunk_cur = 0, chunk_left = 0;   // arena units owned by this block
+  uint32_t dbg_i = 0;                       // (TIMED: barrier records written by this wave so far)
   unsigned long long blk_cells = 0;         // cells computed by this workgroup (reported once, at the end)
 
   // Work distribution: the list is cut into contiguous shards, each with its own counter on its
@@ -570,6 +577,7 @@ wfa_align_kernel(const WfaAlignParams p) {
         auto group = [&](const int kq, const GlobalBytes codes, const int left) -> bool {
           bool more_groups;
           const uint32_t vb = (uint32_t)(kq - 1) << 1;
+          const int kq16 = kq << 16;
           // (one v_add each, once per score: the empty asm keeps the compiler from re-forming them in every chunk)
           uint32_t q_mo = vb + a_oe, q_mx = vb + a_x, q_wm = vb + a_m, q_ri = vb + a_ip, q_wi = vb + a_ic;
           uint32_t q_rd = vb + a_dp, q_wd = vb + a_dc, q_hm = vb + a_hm;
@@ -607,12 +615,24 @@ wfa_align_kernel(const WfaAlignParams p) {
             asm("v_med3_i32 %0, %1, 0, %2" : "=v"(cap) : "v"(mv_t), "n"(PER));
             int h = mv0;
             {
-              const int v = mv0 - k;
               const int rem = hmax - h;
               uint32_t pa, ta;      // word addresses: base + 4 * (symbol index / PER)
-              asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(pa) : "v"(v >> SH), "s"(pw_addr));
-              asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(ta) : "v"(h >> SH), "s"(tw_addr));
-              const uint32_t sa = (uint32_t)v << BITS, sb = (uint32_t)h << BITS;
+              uint32_t sa, sb;      // bit offsets of the run's first symbol inside its word (v_alignbit takes the low five bits)
+              if constexpr (!RAW) {
+                // (gfx950 issues v_add/v_sub/v_and/v_or/v_xor and the RIGHT shifts at one wave instruction per ~2.5 cycles,
+                // left shifts, min/max, compares, every three-operand and every SDWA form at one per ~4.2 --
+                // profiles/r04/valu_classes.txt: v and h are taken from the tagged value with subtractions and right shifts.
+                // The tag occupies bits 4:0 and bit 15 is clear, so (x >> 15) is twice the high half.)
+                const int vt = mv_t - kq16 - (O << 16);             // (h - k) << 16 | tag
+                asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(pa) : "v"(vt >> (16 + SH)), "s"(pw_addr));
+                asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(ta) : "v"(mv_t >> (16 + SH)), "s"(tw_addr));
+                sa = (uint32_t)vt >> 15; sb = (uint32_t)mv_t >> 15;
+              } else {
+                const int v = mv0 - k;
+                asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(pa) : "v"(v >> SH), "s"(pw_addr));
+                asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(ta) : "v"(h >> SH), "s"(tw_addr));
+                sa = (uint32_t)v << BITS; sb = (uint32_t)h << BITS;
+              }
               uint32_t fb;
               {
                 const LdsWords pw = (LdsWords)pa; const LdsWords tw = (LdsWords)ta;
@@ -666,9 +686,9 @@ wfa_align_kernel(const WfaAlignParams p) {
           return more_groups;
         };
         // (several waves: each one's count of remaining cells starts at its own first diagonal)
-        const int left0 = wm1 + 1 - ((NW == 1) ? 0 : __builtin_amdgcn_readfirstlane(tid & ~63));
+        const int left0 = wm1 + 1 - ((NW == 1) ? 0 : __builtin_amdgcn_readfirstlane(stid & ~63));
         // (`codes` is advanced in place and put back: a second copy of the 64-bit address would not fit the registers)
-        int kq = tid + lo, left = left0;
+        int kq = stid + lo, left = left0;
         if constexpr (NW == 1) {
           if (__builtin_expect(group(kq, codes, left), 0)) {
             // (wider than four chunks: rare in this tier, kept out of the way of the common case)
@@ -807,7 +827,7 @@ wfa_align_kernel(const WfaAlignParams p) {
             if constexpr (HOT) lean_cells = !touched_ever && near(e_x, wx) && near(e_oe, wo) && near(e_ie, we);
             if (lean_cells) {
               if constexpr (HOT) {
-                GlobalBytes ca = (GlobalBytes)(uintptr_t)codes + (uint32_t)tid;
+                GlobalBytes ca = (GlobalBytes)(uintptr_t)codes + (uint32_t)stid;
                 const uint32_t a_dd = (uint32_t)(de * rs) * 2u;
                 uint32_t pw_addr = lds_addr(Pw), tw_addr = lds_addr(Tw);
                 asm volatile("" : "+s"(pw_addr), "+s"(tw_addr));
@@ -888,7 +908,7 @@ wfa_align_kernel(const WfaAlignParams p) {
             // address of this lane's origin byte in the row of the current score (64-bit, bumped by the row size)
             GlobalBytes code_addr = nullptr;
             uint32_t need_prev = 0;
-            if constexpr (BT) code_addr = (GlobalBytes)(uintptr_t)p.arena + ((size_t)chunk_cur * 16u + (uint32_t)tid);
+            if constexpr (BT) code_addr = (GlobalBytes)(uintptr_t)p.arena + ((size_t)chunk_cur * 16u + (uint32_t)stid);
             if constexpr (NW > 1) {
               // "a cell touched a sequence end": one LDS word, set by the waves that see it, read after the score's barrier
               if (tid == 0) bslot[1] = 0u;
@@ -915,7 +935,7 @@ wfa_align_kernel(const WfaAlignParams p) {
                 code_addr += need_prev << 4;
                 if (__builtin_expect(need + WFA_ARENA_ROW_SLACK > chunk_left, 0)) {
                   const bool got = refill_arena(need + WFA_ARENA_ROW_SLACK);
-                  code_addr = (GlobalBytes)(uintptr_t)cold_params()->arena + ((size_t)chunk_cur * 16u + (uint32_t)tid);
+                  code_addr = (GlobalBytes)(uintptr_t)cold_params()->arena + ((size_t)chunk_cur * 16u + (uint32_t)stid);
                   need_prev = 0;
                   if (!got) { why = 2; continue; }
                 }
@@ -962,7 +982,23 @@ wfa_align_kernel(const WfaAlignParams p) {
                 if (touch != 0ull) why = 3;
               } else {
                 if (touch != 0ull && lane == 0) atomicOr(&bslot[1], 1u);
-                __syncthreads();
+                if constexpr (TIMED) {
+                  const bool rec = blockIdx.x == 0 && lane == 0;
+                  unsigned long long t_arrive = 0;
+                  if (rec) t_arrive = __builtin_amdgcn_s_memtime();
+                  __syncthreads();
+                  if (rec) {
+                    const unsigned long long t_leave = __builtin_amdgcn_s_memtime();
+                    ColdParams cp = cold_params();
+                    if (dbg_i < cp->dbg_cap) {
+                      unsigned long long* rp = cp->dbg_times + ((size_t)dbg_i * NW + (size_t)(tid >> 6)) * 3;
+                      rp[0] = t_arrive; rp[1] = t_leave; rp[2] = ((unsigned long long)(uint32_t)s << 32) | (uint32_t)wm1;
+                    }
+                    ++dbg_i;
+                  }
+                } else {
+                  __syncthreads();
+                }
                 if (bslot[1] != 0u) why = 3;
               }
             } while (why == 0);
@@ -1020,7 +1056,7 @@ wfa_align_kernel(const WfaAlignParams p) {
             uint32_t a_last = a_m;
             GlobalBytes code_addr = nullptr;
             uint32_t need_prev = 0;
-            if constexpr (BT) code_addr = (GlobalBytes)(uintptr_t)p.arena + ((size_t)chunk_cur * 16u + (uint32_t)tid);
+            if constexpr (BT) code_addr = (GlobalBytes)(uintptr_t)p.arena + ((size_t)chunk_cur * 16u + (uint32_t)stid);
             if constexpr (NW > 1) {
               if (tid == 0) bslot[1] = 0u;
               __syncthreads();
@@ -1052,7 +1088,7 @@ wfa_align_kernel(const WfaAlignParams p) {
                   code_addr += need_prev << 4;
                   if (__builtin_expect(need + WFA_ARENA_ROW_SLACK > chunk_left, 0)) {
                     const bool got = refill_arena(need + WFA_ARENA_ROW_SLACK);
-                    code_addr = (GlobalBytes)(uintptr_t)cold_params()->arena + ((size_t)chunk_cur * 16u + (uint32_t)tid);
+                    code_addr = (GlobalBytes)(uintptr_t)cold_params()->arena + ((size_t)chunk_cur * 16u + (uint32_t)stid);
                     need_prev = 0;
                     if (!got) { why = 2; continue; }
                   }
@@ -1457,9 +1493,9 @@ wfa_align_kernel(const WfaAlignParams p) {
   }
 }
 
-template <int NW, bool BT, typename OffT, bool GR, bool RAW, bool BANDED, bool HYBRID = false, int WPE = 8>
+template <int NW, bool BT, typename OffT, bool GR, bool RAW, bool BANDED, bool HYBRID = false, int WPE = 8, bool TIMED = false>
 void launch_inst(const WfaAlignParams& p, size_t lds, int grid, hipStream_t stream) {
-  auto k = wfa_align_kernel<NW, BT, OffT, GR, RAW, BANDED, HYBRID, WPE>;
+  auto k = wfa_align_kernel<NW, BT, OffT, GR, RAW, BANDED, HYBRID, WPE, TIMED>;
   // the opt-in for large dynamic LDS is sticky per device and per kernel: pay the driver call once
   static thread_local size_t allowed[16] = {0};
   int dev = 0;
@@ -1492,9 +1528,14 @@ void launch_tier(const WfaAlignParams& p, int tier, size_t lds, int grid, hipStr
         if (wpe == 4) { launch_inst<1, BT, int16_t, false, false, false, false, 4>(p, lds, grid, stream); break; }
       }
       launch_inst<1, BT, int16_t, false, RAW, false>(p, lds, grid, stream); break;
-    case 1: launch_inst<4, BT, int16_t, false, RAW, false>(p, lds, grid, stream); break;
+    case 1:
+      if constexpr (BT && !RAW) { if (p.dbg_times) { launch_inst<4, true, int16_t, false, false, false, false, 8, true>(p, lds, grid, stream); break; } }
+      launch_inst<4, BT, int16_t, false, RAW, false>(p, lds, grid, stream); break;
     case 2: launch_inst<16, BT, int16_t, false, RAW, false>(p, lds, grid, stream); break;
-    case 4: if constexpr (!RAW) launch_inst<16, BT, int16_t, false, false, false, true>(p, lds, grid, stream); break;    // hybrid ring
+    case 4:
+      if constexpr (BT && !RAW) { if (p.dbg_times) { launch_inst<16, true, int16_t, false, false, false, true, 8, true>(p, lds, grid, stream); break; } }
+      if constexpr (!RAW) launch_inst<16, BT, int16_t, false, false, false, true>(p, lds, grid, stream);
+      break;    // hybrid ring
     default:
       if (p.ring16) launch_inst<16, BT, int16_t, true, RAW, false>(p, lds, grid, stream);
       else launch_inst<16, BT, int32_t, true, RAW, false>(p, lds, grid, stream);

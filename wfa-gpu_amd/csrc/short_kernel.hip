@@ -17,6 +17,9 @@
 // termination M[s][tlen - plen] >= tlen: wavefront_extend.c:47-67) -- a score does not depend on tie-breaks or on which
 // cells outside the window are computed.  Pairs whose window does not fit a group (status BAND) or whose score exceeds
 // the budget (status SCORE) go on to the ordinary tiers on the device like the failures of any tier.
+#include <array>
+#include <utility>
+
 #include "wfa_device.h"
 
 namespace {
@@ -33,10 +36,14 @@ template <int L> __device__ __forceinline__ int from_above(int v, int j) {
   else { const int r = __shfl_down(v, 1, L); return j == L - 1 ? S_NULL : r; }
 }
 
-// X = mismatch, OE = gap open + extend; gap extend is 1.  L lanes per alignment.
+// X = mismatch, OE = gap open + extend; gap extend is 1.  L lanes per alignment.  The history a cell reads -- M of the last
+// D = max(X, OE) scores -- is a ring of D registers per lane; the score loop is unrolled D times so that every ring index is a
+// compile-time constant (round 3 had the two instantiations of the benchmark penalties; now every set with e == 1 and
+// max(x, o + e) <= 8 after the common-factor reduction: 64 x 2 kernels, picked from a table).
 template <int L, int X, int OE>
 __global__ void __launch_bounds__(64) wfa_short_score_kernel(const WfaAlignParams p) {
-  static_assert(X >= 1 && X <= 4 && OE >= 1 && OE <= 4, "history of four scores");
+  static_assert(X >= 1 && X <= 8 && OE >= 1 && OE <= 8, "history of eight scores");
+  constexpr int D = X > OE ? X : OE;
   extern __shared__ __attribute__((aligned(16))) uint32_t slds[];
   constexpr int G = 64 / L;
   const int lane = threadIdx.x & 63, grp = lane / L, j = lane % L;
@@ -114,23 +121,25 @@ __global__ void __launch_bounds__(64) wfa_short_score_kernel(const WfaAlignParam
     };
 
     // score 0
-    int m0, m1 = S_NULL, m2 = S_NULL, m3 = S_NULL;          // M of scores with (s & 3) == 0, 1, 2, 3
+    int m[D];                                               // M of the scores with (s % D) == index
+#pragma unroll
+    for (int i = 0; i < D; ++i) m[i] = S_NULL;
     int i1 = S_NULL, d1 = S_NULL;                           // I and D of the last score
     {
       const bool mine = run && k == 0;
       const int h = extend(0, mine);
-      m0 = mine ? h : S_NULL;
+      m[0] = mine ? h : S_NULL;
     }
     bool fin = !run;                                        // this lane's group has its result (or never ran)
     int score = -1;
     {
-      const bool hit = run && k == kend && m0 >= tlen;
+      const bool hit = run && k == kend && m[0] >= tlen;
       const unsigned long long bal = __builtin_amdgcn_ballot_w64(hit);
       if (run && (bal & grp_mask) != 0ull) { fin = true; score = 0; }
     }
     int s = 0;
-    // one score: R = s & 3 (compile-time), reads M[s - X] and M[s - OE] from their registers
-    auto step = [&](auto rtag, int& m_out, const int m_x, const int m_o) {
+    // one score: reads M[s - X] and M[s - OE] from their registers (by value: one of them may be the register written)
+    auto step = [&](int& m_out, const int m_x, const int m_o) {
       ++s;
       const int ins = max(from_below<L>(m_o, j), from_below<L>(i1, j)) + 1;
       const int del = max(from_above<L>(m_o, j), from_above<L>(d1, j));
@@ -150,18 +159,17 @@ __global__ void __launch_bounds__(64) wfa_short_score_kernel(const WfaAlignParam
         if ((bal & grp_mask) != 0ull) { fin = true; score = s; }
         else if (s >= budget) { fin = true; status = WFA_ST_SCORE; }     // (the next score would be past the budget)
       }
-      (void)rtag;
     };
-    // (s & 3): 1, 2, 3, 0, ...; M[s - X] sits in register (s - X) & 3, M[s - OE] in (s - OE) & 3
-    int* const mr[4] = {&m0, &m1, &m2, &m3};
-    while (__builtin_amdgcn_ballot_w64(!fin) != 0ull) {
-      step(0, *mr[1], *mr[(1 - X) & 3], *mr[(1 - OE) & 3]);
-      if (__builtin_amdgcn_ballot_w64(!fin) == 0ull) break;
-      step(0, *mr[2], *mr[(2 - X) & 3], *mr[(2 - OE) & 3]);
-      if (__builtin_amdgcn_ballot_w64(!fin) == 0ull) break;
-      step(0, *mr[3], *mr[(3 - X) & 3], *mr[(3 - OE) & 3]);
-      if (__builtin_amdgcn_ballot_w64(!fin) == 0ull) break;
-      step(0, *mr[0], *mr[(0 - X) & 3], *mr[(0 - OE) & 3]);
+    // s % D runs 1, 2, .., D - 1, 0, 1, ..: M[s - X] sits in register (s - X) % D, M[s - OE] in (s - OE) % D
+    bool more = __builtin_amdgcn_ballot_w64(!fin) != 0ull;
+    while (more) {
+#pragma unroll
+      for (int r = 1; r <= D; ++r) {
+        if (more) {
+          step(m[r % D], m[(r - X + D) % D], m[(r - OE + D) % D]);
+          more = __builtin_amdgcn_ballot_w64(!fin) != 0ull;
+        }
+      }
     }
     if (active && j == 0) {
       p.score[pair] = (status == WFA_ST_DONE) ? score : -1;
@@ -183,15 +191,22 @@ void launch_short(const WfaAlignParams& p, int grid, hipStream_t stream) {
   hipLaunchKernelGGL((wfa_short_score_kernel<L, X, OE>), dim3(grid), dim3(64), lds, stream, p);
 }
 
+// [lanes == 32][x - 1][oe - 1]
+using ShortLauncher = void (*)(const WfaAlignParams&, int, hipStream_t);
+template <int L, int I> constexpr ShortLauncher short_entry() { return &launch_short<L, I / 8 + 1, I % 8 + 1>; }
+template <int L, int... Is> constexpr std::array<ShortLauncher, 64> short_table(std::integer_sequence<int, Is...>) { return {short_entry<L, Is>()...}; }
+const std::array<ShortLauncher, 64> g_short16 = short_table<16>(std::make_integer_sequence<int, 64>{});
+const std::array<ShortLauncher, 64> g_short32 = short_table<32>(std::make_integer_sequence<int, 64>{});
+
 }  // namespace
 
-bool wfa_short_supported(int x, int oe, int e) { return e == 1 && ((x == 2 && oe == 4) || (x == 1 && oe == 3)); }
+bool wfa_short_supported(int x, int oe, int e) { return e == 1 && x >= 1 && x <= 8 && oe >= 1 && oe <= 8; }
 
 size_t wfa_short_lds_bytes(const WfaAlignParams& p, int lanes) { return (size_t)(64 / lanes) * 2 * p.seq_words_cap * 4; }
 
 void wfa_launch_short(const WfaAlignParams& p, int lanes, int grid, hipStream_t stream) {
-  if (p.x == 2 && p.oe == 4) { if (lanes == 16) launch_short<16, 2, 4>(p, grid, stream); else launch_short<32, 2, 4>(p, grid, stream); }
-  else { if (lanes == 16) launch_short<16, 1, 3>(p, grid, stream); else launch_short<32, 1, 3>(p, grid, stream); }
+  const int idx = (p.x - 1) * 8 + (p.oe - 1);
+  (lanes == 16 ? g_short16 : g_short32)[idx](p, grid, stream);
 }
 
 // Loads this translation unit's code object on the current device (the runtime loads a code object at the first launch of

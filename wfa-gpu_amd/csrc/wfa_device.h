@@ -90,6 +90,9 @@ struct WfaAlignParams {
   void* gring;                   // per-block slices of gring_stride bytes
   int ring16;                    //   16-bit offsets in it (sequences <= 32766 bases), else 32-bit
   unsigned long long gring_stride;
+  // diagnostics (tuning.timed_barriers): barrier arrival / release clocks of workgroup 0, 3 x u64 per score and wave
+  unsigned long long* dbg_times;
+  uint32_t dbg_cap;              // records (scores) the buffer holds
 };
 
 struct WfaTraceParams {

@@ -256,6 +256,8 @@ struct wfagpu_amd_ctx {
   // hands out stay valid through the NEXT call, so a pipelined caller copies the results of batch j to the host while the
   // kernels of batch j+1 run (launch_alignments*: the copy left the lanes' critical path).
   DevBuf text[2], cig_off[2], cig_len[2];
+  DevBuf dbg;               // tuning.timed_barriers: barrier records of workgroup 0
+  int dbg_waves = 0; unsigned dbg_records = 0;
   int out_set = 0;
   unsigned long long* h_counters = nullptr;  // pinned
   hipEvent_t ev_start = nullptr, ev_pack = nullptr, ev_a0 = nullptr, ev_a1 = nullptr, ev_b0 = nullptr, ev_b1 = nullptr, ev_t0 = nullptr, ev_t1 = nullptr, ev_end = nullptr;
@@ -325,7 +327,7 @@ void wfagpu_amd_destroy(wfagpu_amd_ctx_t* c) {
   if (c->stream) hipStreamSynchronize(c->stream);
   c->free_retired();
   for (DevBuf* b : {&c->packed, &c->flags, &c->status, &c->cells, &c->bt_final, &c->list_a, &c->list_b, &c->list_c, &c->list_d, &c->list_e, &c->work_ctr, &c->sample, &c->ratio, &c->budget,
-                    &c->counters, &c->arena, &c->ops, &c->text[0], &c->text[1], &c->text_scratch, &c->cig_off[0], &c->cig_off[1], &c->cig_len[0], &c->cig_len[1], &c->gring})
+                    &c->counters, &c->arena, &c->ops, &c->text[0], &c->text[1], &c->text_scratch, &c->cig_off[0], &c->cig_off[1], &c->cig_len[0], &c->cig_len[1], &c->gring, &c->dbg})
     b->release();
   if (c->h_counters) hipHostFree(c->h_counters);
   for (hipEvent_t ev : {c->ev_start, c->ev_pack, c->ev_a0, c->ev_a1, c->ev_b0, c->ev_b1, c->ev_t0, c->ev_t1, c->ev_end})
@@ -356,6 +358,12 @@ int wfagpu_amd_pack_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_batch_t* b, voi
 }
 
 void* wfagpu_amd_stream(const wfagpu_amd_ctx_t* c) { return c ? static_cast<void*>(c->stream) : nullptr; }
+
+void wfagpu_amd_debug_times(const wfagpu_amd_ctx_t* c, const void** d_records, unsigned int* records, int* waves) {
+  if (d_records) *d_records = c ? c->dbg.p : nullptr;
+  if (records) *records = (c && c->dbg.p) ? c->dbg_records : 0u;
+  if (waves) *waves = c ? c->dbg_waves : 0;
+}
 
 void wfagpu_amd_trim(wfagpu_amd_ctx_t* c) {
   if (!c || c->retired.empty()) return;
@@ -709,6 +717,15 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
           const int g = (int)std::min<uint32_t>(n_cur, (uint32_t)(c->num_cus * tp.blocks_per_cu));
           if (c->gring.ensure(stride * g, st)) return -1;
           ap.gring = c->gring.p; ap.gring_stride = stride;
+        }
+        ap.dbg_times = nullptr; ap.dbg_cap = 0;
+        if (c->tuning.timed_barriers && round == 0 && cigar_now && !raw && !L.banded && (tp.tier == 1 || tp.tier == 4)) {
+          const int nw = tp.tier == 1 ? 4 : 16;
+          const uint32_t cap = 1u << 16;
+          if (c->dbg.ensure((size_t)cap * nw * 24, st)) return -1;
+          HIP_TRY(hipMemsetAsync(c->dbg.p, 0, (size_t)cap * nw * 24, st));
+          c->dbg_waves = nw; c->dbg_records = cap;
+          ap.dbg_times = static_cast<unsigned long long*>(c->dbg.p); ap.dbg_cap = cap;
         }
         if (round == 0) { c->stats.lds_bytes_tier0 = tp.lds; c->stats.blocks_per_cu_tier0 = tp.blocks_per_cu; c->stats.waves_per_simd_tier0 = tp.wpe; }
         ap.work = cur; ap.n_work = n_cur; ap.n_work_dev = cur_len_dev;

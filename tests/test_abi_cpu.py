@@ -86,6 +86,12 @@ def test_aligner_object_host_side(lib):
     assert not lib.wfagpu_set_batch_size(None, 10)
     assert not lib.wfagpu_align(None)
     lib.wfagpu_destroy_aligner(C.byref(al))
+    # an aligner that was never given results: the reference's wfagpu_align calls the launcher anyway and returns true
+    # (lib/aligner.c:236-263); this build's launcher refuses the missing arrays with a message and returns
+    empty = wfagpu.Aligner()
+    assert lib.wfagpu_initialize_aligner(C.byref(empty))
+    assert lib.wfagpu_align(C.byref(empty))
+    lib.wfagpu_destroy_aligner(C.byref(empty))
 
 
 def test_packed_offsets_helper(lib):

@@ -316,6 +316,11 @@ def test_cli_rejects_bad_input(tmp_path):
     assert r.returncode != 0
     r = subprocess.run([CLI], capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "No input file" in r.stdout + r.stderr
+    # an option the tool does not know is skipped, as by the reference's parser (utils/arg_handler.c:97-140)
+    good = tmp_path / "good.seq"
+    good.write_text(">ACGTACGT\n<ACGAACGT\n")
+    r = subprocess.run([CLI, "-i", str(good), "--no-such-option", "-Z", "7", "-p"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "-2\t" in r.stderr
 
 
 def test_cli_full_size_cfg3_with_check(tmp_path):

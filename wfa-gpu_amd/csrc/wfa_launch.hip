@@ -236,7 +236,7 @@ struct DevState {
                                                // every stream of a new priority level is a hardware queue to create: ~11 ms, serialised)
   std::vector<hipEvent_t> up_done, down_done;  // one per batch of a call: "its copies have landed"
   std::vector<InSlot> in;
-  void* d_scratch = nullptr; void* h_scratch = nullptr;      // (a few KiB each: targets of the copies that warm the copy paths up)
+  void* d_scratch = nullptr; void* d_scratch2 = nullptr; void* h_scratch = nullptr;      // (a few KiB each: the two ends of the copies that warm the copy paths up: one device buffer per direction)
   // ---- bring-up (see bring_up_fn): who creates what, in which order
   std::mutex bring_mu;                         // publishes items (up, down, lane[k].ctx) and bring_active
   std::mutex create_mu;                        // one creator at a time; never held while waiting for bring_mu's condition
@@ -269,8 +269,9 @@ void release_dev(DevState& d) {
   for (auto& e : d.down_done) (void)hipEventDestroy(e);
   d.down_done.clear();
   if (d.d_scratch) (void)hipFree(d.d_scratch);
+  if (d.d_scratch2) (void)hipFree(d.d_scratch2);
   if (d.h_scratch) (void)hipHostFree(d.h_scratch);
-  d.d_scratch = d.h_scratch = nullptr;
+  d.d_scratch = d.d_scratch2 = d.h_scratch = nullptr;
   d.prime_state.store(0);
   for (auto& l : d.lane) {
     for (auto& ds : l.d_scores) if (ds) (void)hipFree(ds);
@@ -376,8 +377,8 @@ int create_down(DevState& d) {
   hipStream_t s = nullptr;
   HIP_OK(copy_stream(&s));
   if (!d.h_scratch) HIP_OK(hipHostMalloc(&d.h_scratch, 4096, hipHostMallocDefault));
-  if (!d.d_scratch) HIP_OK(hipMalloc(&d.d_scratch, 1 << 16));
-  HIP_OK(hipMemcpyAsync(d.h_scratch, d.d_scratch, 4096, hipMemcpyDeviceToHost, s));
+  if (!d.d_scratch2) HIP_OK(hipMalloc(&d.d_scratch2, 1 << 16));
+  HIP_OK(hipMemcpyAsync(d.h_scratch, d.d_scratch2, 4096, hipMemcpyDeviceToHost, s));
   publish(d, d.down, s);
   return 0;
 }

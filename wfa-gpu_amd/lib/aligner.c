@@ -162,14 +162,28 @@ bool wfagpu_set_batch_size(wfagpu_aligner_t* aligner, size_t batch_size) {
     return true;
 }
 
+size_t wfagpu_amd_results_capacity(const wfa_alignment_result_t* results);      /* lib/alignment_results.c */
+
 bool wfagpu_align(wfagpu_aligner_t* aligner) {
     if (aligner == NULL) {
         LOG_ERROR("Invalid aligner.")
         return false;
     }
-    if (aligner->results == NULL || aligner->num_sequence_pairs == 0) {
-        LOG_ERROR("Aligner parameters are not initialized.")
-        return false;
+    /* (an aligner without sequences or parameters: the reference calls the launcher all the same and returns true,
+     * lib/aligner.c:236-263 -- this build's launcher logs "Invalid buffers." for missing arrays and does nothing for
+     * zero alignments, so the same return value is safe to keep) */
+    /* sequences added after the parameters were initialised: the results array is still the old count's (the reference
+     * indexes it by the new one) -- a fresh array for every pair */
+    if (aligner->results != NULL && aligner->num_sequence_pairs > 0) {
+        const size_t have = wfagpu_amd_results_capacity(aligner->results);
+        if (have != (size_t)-1 && have < aligner->num_sequence_pairs) {
+            destroy_wfa_results(aligner->results, have);
+            aligner->results = NULL;
+            if (!initialize_wfa_results(&aligner->results, aligner->num_sequence_pairs, CIGAR_INITIAL_BYTES)) {
+                LOG_ERROR("Can not allocate the results.")
+                return false;
+            }
+        }
     }
     /* callers set options by poking the struct (examples/manual_example.c:67-91) */
     aligner->alignment_options.num_alignments = aligner->num_sequence_pairs;

@@ -69,6 +69,7 @@ int main(int argc, char** argv) {
     }
 
     int c;
+    opterr = 0;      /* (unknown options are skipped silently: see the default case) */
     while ((c = getopt_long(argc, argv, "i:Q:T:n:o:pOg:xe:b:B:ct:w:h", longopts, NULL)) != -1) {
         switch (c) {
             case 'i': seq_path = optarg; break;
@@ -86,7 +87,8 @@ int main(int argc, char** argv) {
             case 'c': check = true; break;
             case 't': tpb = atol(optarg); break;
             case 'w': workers = atol(optarg); break;
-            default: usage(argv[0]); exit(1);
+            case 'h': usage(argv[0]); exit(0);
+            default: break;      /* an option the tool does not know is skipped, like the reference's parser does (utils/arg_handler.c:97-140) */
         }
     }
     if (!seq_path && !(q_path && t_path)) {

@@ -7,7 +7,9 @@
 static const char* next_item(const char* c, long* n, char* op) {
     long v = 0;
     if (*c < '0' || *c > '9') return NULL;
-    while (*c >= '0' && *c <= '9') { v = v * 10 + (*c - '0'); ++c; }
+    /* (a run longer than any sequence is not a CIGAR of this pair: refused before the accumulator can overflow --
+     * found by the UBSan harness, tests/host_api_asan.c) */
+    while (*c >= '0' && *c <= '9') { v = v * 10 + (*c - '0'); ++c; if (v > 0x7FFFFFFFL) return NULL; }
     if (!*c || v <= 0) return NULL;
     *n = v; *op = *c;
     return c + 1;

@@ -43,6 +43,8 @@ WORKLOADS = {
     # name: pairs, length, error, compute_cigar, max_error, band (lambda, beta) or None, default steps, description
     "cfg2": dict(pairs=100_000, length=150, error=0.02, cigar=False, max_error=45, band=None, steps=2000,
                  desc="100k synthetic 150 bp pairs, 2% error, x=2,o=3,e=1, score-only"),
+    "cfg2c": dict(pairs=100_000, length=150, error=0.02, cigar=True, max_error=45, band=None, steps=1000,
+                  desc="100k synthetic 150 bp pairs, 2% error, x=2,o=3,e=1, score+CIGAR (configs[1]'s reads with CIGARs)"),
     "cfg3": dict(pairs=1_000_000, length=1000, error=0.05, cigar=True, max_error=300, band=None, steps=100,
                  desc="1M synthetic 1 kbp pairs, 5% error, x=2,o=3,e=1, score+CIGAR"),
     "cfg4": dict(pairs=16_384, length=10_000, error=0.03, cigar=True, max_error=3000, band=(25, 512), steps=200,
@@ -587,7 +589,7 @@ def main():
             del buf, meta, data
             # the other BASELINE GPU configurations, short legs (~60 s together)
             out["configs"] = {}
-            for key, name, forced, k, w in (("cfg2", "cfg2", False, 400, 5), ("cfg4", "cfg4", False, 8, 3), ("cfg4_band_forced", "cfg4", True, 8, 3),
+            for key, name, forced, k, w in (("cfg2", "cfg2", False, 400, 5), ("cfg2_with_cigar", "cfg2c", False, 200, 5), ("cfg4", "cfg4", False, 8, 3), ("cfg4_band_forced", "cfg4", True, 8, 3),
                                             ("cfg5", "cfg5", False, 4, 2)):
                 try:
                     out["configs"][key] = extra_config(name, forced, k, w)

@@ -38,6 +38,7 @@ typedef struct {
     int timed_barriers;    /* diagnostics: the multi-wave exact CIGAR tiers (1 and 4) run an instantiation in which workgroup 0
                               records when each of its waves reaches and leaves the per-score barrier (s_memtime);
                               wfagpu_amd_debug_times() hands the records out                                              */
+    int no_short_cigar;    /* A/B and test hook: CIGAR calls never take tier 5 (several alignments per wavefront)               */
 } wfagpu_amd_tuning_t;
 
 typedef struct {

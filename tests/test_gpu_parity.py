@@ -786,8 +786,20 @@ def test_short_wavefront_tier_scores(pen, expect_short):
                 assert st.pairs_tier[5] > n * 0.9 and st.pairs_retried > 100, list(st.pairs_tier)
             else:
                 assert st.pairs_tier[5] == 0
-        # and with CIGARs (tier 5 is score-only: the ordinary tiers), same scores
-        s2, c2 = al.align(batch, pen, max_error=400, compute_cigar=True)
-        assert np.array_equal(s2, so) and al.stats().pairs_tier[5] == 0
+        # and with CIGARs: the same tier (one row of origin bytes per score and group), every CIGAR byte-identical to WFA2's
+        _, co, _ = oracle_lib.oracle_batch(buf, meta, pen, cigar=True, nthreads=16)
+        for max_error in (45 * max(1, pen[0] // 2), 400):
+            s2, c2 = al.align(batch, pen, max_error=max_error, compute_cigar=True)
+            st = al.stats()
+            assert np.array_equal(s2, so) and c2 == co, (pen, max_error)
+            if expect_short:
+                assert st.pairs_tier[5] > n * 0.9, list(st.pairs_tier)
+            else:
+                assert st.pairs_tier[5] == 0
+        # the A/B switch: CIGAR calls on the ordinary tiers, same answers
+        al.set_tuning(no_short_cigar=1)
+        s3, c3 = al.align(batch, pen, max_error=400, compute_cigar=True)
+        assert np.array_equal(s3, so) and c3 == co and al.stats().pairs_tier[5] == 0
+        al.set_tuning()
     finally:
         al.close()

@@ -40,8 +40,19 @@ template <int L> __device__ __forceinline__ int from_above(int v, int j) {
 // D = max(X, OE) scores -- is a ring of D registers per lane; the score loop is unrolled D times so that every ring index is a
 // compile-time constant (round 3 had the two instantiations of the benchmark penalties; now every set with e == 1 and
 // max(x, o + e) <= 8 after the common-factor reduction: 64 x 2 kernels, picked from a table).
-template <int L, int X, int OE>
-__global__ void __launch_bounds__(64) wfa_short_score_kernel(const WfaAlignParams p) {
+// BT (round 4): with CIGARs.  Every cell also leaves its origin byte (wfa_device.h: source of M with WFA2's priority on equal
+// offsets -- mismatch, then deletion, then insertion --, gap extension over gap open) in a row of L bytes per score; an
+// alignment claims its row table and the rows of all the scores its budget allows with ONE atomic on the arena's bump pointer
+// (a few hundred bytes: budgets are <= 35 here) and the backtrace kernels (trace_kernel.hip) read them like any other tier's.
+// Is it WFA2's CIGAR?  This kernel has no per-row limits and turns every I / D value that ran past a sequence end into NULL
+// at once, where WFA2 keeps such values inside a row and trims them at its ends only (wavefront_compute.c:570-603).  The
+// two differ only in cells that no optimal alignment passes through (a value past an end cannot lie on a path to the corner,
+// and every candidate of a valid cell is itself valid or NULL: a nulled value never was the winning candidate of a cell that
+// stays valid in WFA2), so scores, tie-breaks along the optimal path and hence the CIGAR are the same: argued in DESIGN.md
+// section 4.2b, searched with scratch/short_cigar_semantics.py (oracle with that one change: 0 of 240 000 indel-heavy short
+// pairs differ), and held by the parity tests, which compare every CIGAR of this tier with WFA2's.
+template <int L, int X, int OE, bool BT>
+__global__ void __launch_bounds__(64) wfa_short_kernel(const WfaAlignParams p) {
   static_assert(X >= 1 && X <= 8 && OE >= 1 && OE <= 8, "history of eight scores");
   constexpr int D = X > OE ? X : OE;
   extern __shared__ __attribute__((aligned(16))) uint32_t slds[];
@@ -93,8 +104,23 @@ __global__ void __launch_bounds__(64) wfa_short_score_kernel(const WfaAlignParam
       if (!feasible) status = WFA_ST_SCORE;
       else if (whi - wlo + 1 > L || pwords > cap || twords > cap) status = WFA_ST_BAND;
     }
+    // CIGARs: the row table (8 bytes per score up to the budget, in 16-byte units) and one row of L origin bytes per score
+    // Arena space WITHOUT atomics: work item w owns the units [top + w * slot, top + (w + 1) * slot) above the arena's bump pointer
+    // as the launch found it, slot = what the launch's largest budget needs (wfa_short_bt_slot_units); the host moves the bump
+    // pointer past the whole region with a one-thread kernel behind this launch.  (One returning atomic per alignment on the
+    // one bump word -- ~88 per microsecond on this chip -- was 0.3 of the 0.43 ms of a 100k-pair launch.)
+    uint32_t tab_unit = WFA_ROW_NONE, rows_unit = 0;
+    if constexpr (BT) {
+      const uint32_t tab_units = (uint32_t)(((long long)p.max_score + 2) >> 1), slot = tab_units + (uint32_t)(p.max_score + 1) * (L / 16);
+      const unsigned long long b = *p.arena_top + (unsigned long long)w * slot;
+      if (active && status == WFA_ST_DONE) {
+        if (b + slot <= p.arena_units) { tab_unit = (uint32_t)b; rows_unit = tab_unit + tab_units; }
+        else status = WFA_ST_NOMEM;
+      }
+    }
     const bool run = active && status == WFA_ST_DONE;
     const int k = wlo + j;                                  // this lane's diagonal, for the whole alignment
+    uint8_t* const my_codes = BT ? p.arena + ((size_t)rows_unit * 16 + (uint32_t)j) : nullptr;      // + score * L
     if (run) {
       for (int i = j; i < pwords; i += L) Pw[i] = gp[i];
       for (int i = j; i < twords; i += L) Tw[i] = gt[i];
@@ -129,6 +155,7 @@ __global__ void __launch_bounds__(64) wfa_short_score_kernel(const WfaAlignParam
       const bool mine = run && k == 0;
       const int h = extend(0, mine);
       m[0] = mine ? h : S_NULL;
+      if constexpr (BT) { if (run) my_codes[0] = 0; }
     }
     bool fin = !run;                                        // this lane's group has its result (or never ran)
     int score = -1;
@@ -141,8 +168,9 @@ __global__ void __launch_bounds__(64) wfa_short_score_kernel(const WfaAlignParam
     // one score: reads M[s - X] and M[s - OE] from their registers (by value: one of them may be the register written)
     auto step = [&](int& m_out, const int m_x, const int m_o) {
       ++s;
-      const int ins = max(from_below<L>(m_o, j), from_below<L>(i1, j)) + 1;
-      const int del = max(from_above<L>(m_o, j), from_above<L>(d1, j));
+      const int m_ol = from_below<L>(m_o, j), i_e = from_below<L>(i1, j), m_or = from_above<L>(m_o, j), d_e = from_above<L>(d1, j);
+      const int ins = max(m_ol, i_e) + 1;
+      const int del = max(m_or, d_e);
       const int mis = m_x + 1;
       // !(h > tlen || v > plen), unsigned so that NULLs fail too (wavefront_compute_affine.c:45-87)
       const bool i_ok = ((unsigned)ins <= (unsigned)tlen) & ((unsigned)(ins - k) <= (unsigned)plen);
@@ -150,6 +178,15 @@ __global__ void __launch_bounds__(64) wfa_short_score_kernel(const WfaAlignParam
       i1 = i_ok ? ins : S_NULL;
       d1 = d_ok ? del : S_NULL;
       const int mv = max(max(d1, i1), mis);
+      if constexpr (BT) {
+        // tie-breaks: gap extension over gap open (wavefront_compute_affine.c:135-143,153-161); M: mismatch, then deletion, then
+        // insertion (wavefront_backtrace.c:48-59).  A group that has its result stores nothing more (its rows end at its budget).
+        if (!fin) {
+          const uint32_t code = (i_e >= m_ol ? BT_I_EXT : 0u) | (d_e >= m_or ? BT_D_EXT : 0u) |
+                                ((mis == mv) ? BT_M_X : ((d1 == mv) ? BT_M_D : BT_M_I));
+          my_codes[(uint32_t)s * L] = (uint8_t)code;
+        }
+      }
       const bool ok = !fin & ((unsigned)mv <= (unsigned)tlen) & ((unsigned)(mv - k) <= (unsigned)plen);
       const int h = extend(mv, ok);
       m_out = ok ? h : S_NULL;
@@ -171,6 +208,14 @@ __global__ void __launch_bounds__(64) wfa_short_score_kernel(const WfaAlignParam
         }
       }
     }
+    if constexpr (BT) {
+      if (run && status == WFA_ST_DONE) {
+        // the row table: [score] = {unit of the row, its lower diagonal} (what every tier leaves for the backtrace)
+        uint2* tab = reinterpret_cast<uint2*>(p.arena + (size_t)tab_unit * 16);
+        for (int t = j; t <= score; t += L) tab[t] = make_uint2(rows_unit + (uint32_t)t * (L / 16), (uint32_t)wlo);
+        if (j == 0) p.bt_final_row[pair] = tab_unit;
+      }
+    }
     if (active && j == 0) {
       p.score[pair] = (status == WFA_ST_DONE) ? score : -1;
       p.status[pair] = status;
@@ -185,28 +230,36 @@ __global__ void __launch_bounds__(64) wfa_short_score_kernel(const WfaAlignParam
   if (lane == 0 && blk_cells && p.launch_cells) atomicAdd(p.launch_cells, blk_cells);
 }
 
-template <int L, int X, int OE>
+template <int L, int X, int OE, bool BT>
 void launch_short(const WfaAlignParams& p, int grid, hipStream_t stream) {
   const size_t lds = (size_t)(64 / L) * 2 * p.seq_words_cap * 4;
-  hipLaunchKernelGGL((wfa_short_score_kernel<L, X, OE>), dim3(grid), dim3(64), lds, stream, p);
+  hipLaunchKernelGGL((wfa_short_kernel<L, X, OE, BT>), dim3(grid), dim3(64), lds, stream, p);
 }
 
-// [lanes == 32][x - 1][oe - 1]
+// [x - 1][oe - 1], one table per group width and mode
 using ShortLauncher = void (*)(const WfaAlignParams&, int, hipStream_t);
-template <int L, int I> constexpr ShortLauncher short_entry() { return &launch_short<L, I / 8 + 1, I % 8 + 1>; }
-template <int L, int... Is> constexpr std::array<ShortLauncher, 64> short_table(std::integer_sequence<int, Is...>) { return {short_entry<L, Is>()...}; }
-const std::array<ShortLauncher, 64> g_short16 = short_table<16>(std::make_integer_sequence<int, 64>{});
-const std::array<ShortLauncher, 64> g_short32 = short_table<32>(std::make_integer_sequence<int, 64>{});
+template <int L, bool BT, int I> constexpr ShortLauncher short_entry() { return &launch_short<L, I / 8 + 1, I % 8 + 1, BT>; }
+template <int L, bool BT, int... Is> constexpr std::array<ShortLauncher, 64> short_table(std::integer_sequence<int, Is...>) { return {short_entry<L, BT, Is>()...}; }
+const std::array<ShortLauncher, 64> g_short16 = short_table<16, false>(std::make_integer_sequence<int, 64>{});
+const std::array<ShortLauncher, 64> g_short32 = short_table<32, false>(std::make_integer_sequence<int, 64>{});
+const std::array<ShortLauncher, 64> g_short16_bt = short_table<16, true>(std::make_integer_sequence<int, 64>{});
+const std::array<ShortLauncher, 64> g_short32_bt = short_table<32, true>(std::make_integer_sequence<int, 64>{});
 
 }  // namespace
+
+// arena units (16 bytes) a work item of a CIGAR launch owns: row table up to max_score + its rows
+unsigned long long wfa_short_bt_slot_units(int max_score, int lanes) {
+  return (unsigned long long)(((long long)max_score + 2) >> 1) + (unsigned long long)(max_score + 1) * (unsigned)(lanes / 16);
+}
 
 bool wfa_short_supported(int x, int oe, int e) { return e == 1 && x >= 1 && x <= 8 && oe >= 1 && oe <= 8; }
 
 size_t wfa_short_lds_bytes(const WfaAlignParams& p, int lanes) { return (size_t)(64 / lanes) * 2 * p.seq_words_cap * 4; }
 
-void wfa_launch_short(const WfaAlignParams& p, int lanes, int grid, hipStream_t stream) {
+void wfa_launch_short(const WfaAlignParams& p, int lanes, bool with_bt, int grid, hipStream_t stream) {
   const int idx = (p.x - 1) * 8 + (p.oe - 1);
-  (lanes == 16 ? g_short16 : g_short32)[idx](p, grid, stream);
+  if (with_bt) (lanes == 16 ? g_short16_bt : g_short32_bt)[idx](p, grid, stream);
+  else (lanes == 16 ? g_short16 : g_short32)[idx](p, grid, stream);
 }
 
 // Loads this translation unit's code object on the current device (the runtime loads a code object at the first launch of

@@ -143,10 +143,12 @@ size_t wfa_align_lds_bytes(const WfaAlignParams& p, int tier);
 void wfa_launch_align(const WfaAlignParams& p, int tier, bool with_bt, bool raw, int grid, hipStream_t stream, int wpe = 8);
 int wfa_align_max_blocks_per_cu(int tier, bool with_bt, bool raw, bool banded, size_t lds_bytes, int wpe = 8);
 void wfa_launch_trace(const WfaTraceParams& p, hipStream_t stream);
-// Tier 5 (short_kernel.hip): score-only, 64 / lanes alignments per wavefront (lanes = 16 or 32 diagonals each), rings in registers.
+// Tier 5 (short_kernel.hip): 64 / lanes alignments per wavefront (lanes = 16 or 32 diagonals each), rings in registers; with_bt: one row
+// of `lanes` origin bytes per score for the backtrace.
 bool wfa_short_supported(int x, int oe, int e);
 size_t wfa_short_lds_bytes(const WfaAlignParams& p, int lanes);
-void wfa_launch_short(const WfaAlignParams& p, int lanes, int grid, hipStream_t stream);
+void wfa_launch_short(const WfaAlignParams& p, int lanes, bool with_bt, int grid, hipStream_t stream);
+unsigned long long wfa_short_bt_slot_units(int max_score, int lanes);     // (with_bt: arena units every work item of the launch owns)
 // Code-object priming: one empty launch per kernel translation unit (see the definitions).
 void wfa_prime_pack(hipStream_t stream);
 void wfa_prime_align(hipStream_t stream);

@@ -224,6 +224,11 @@ __global__ void k_scale_scores(int32_t* __restrict__ score, uint32_t n, int g) {
   if (gid < n && score[gid] > 0) score[gid] *= g;
 }
 
+// moves the arena's bump pointer past a region a launch handed out statically (tier 5 with CIGARs), never beyond the arena
+__global__ void k_bump(unsigned long long* top, unsigned long long units, unsigned long long cap) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned long long t = *top + units; *top = t < cap ? t : cap; }
+}
+
 __global__ void k_iota(uint32_t* __restrict__ out, uint32_t first, uint32_t n) {
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
   if (gid < n) out[gid] = first + gid;
@@ -438,7 +443,7 @@ bool plan_tier(const wfagpu_amd_ctx* c, WfaAlignParams& p, int max_score, unsign
   // Short wavefronts, score only (tier 5, short_kernel.hip): when the diagonal window of the budget fits 16 or 32 lanes, four or two
   // alignments share a wavefront and the rings live in registers (BASELINE configs[1]: 150 bp reads, budgets of ~14 once
   // they are tuned).  Pairs whose own window is wider (large |tlen - plen|) come back as BAND failures and go on as always.
-  if (!bt && !raw && c->tuning.min_tier == 0 && wfa_short_supported(p.x, p.oe, p.e) && width + 1 <= 32 && max_score <= 30000) {
+  if (!raw && c->tuning.min_tier == 0 && !(bt && c->tuning.no_short_cigar) && wfa_short_supported(p.x, p.oe, p.e) && width + 1 <= 32 && max_score <= 30000) {
     const int lanes = width + 1 <= 16 ? 16 : 32;
     p.rs = 0;
     const size_t lds = wfa_short_lds_bytes(p, lanes);
@@ -746,7 +751,11 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         if (zero_counter(c, L.ct_cells, 2)) return -1;   // (the launch's cell count and, next to it, the length of its failure list)
         HIP_TRY(hipMemsetAsync(c->work_ctr.p, 0, 8 * 64, st));
         HIP_TRY(hipEventRecord(L.e0, st));
-        if (tp.tier == 5) wfa_launch_short(ap, tp.wpe, grid, st);
+        if (tp.tier == 5) {
+          wfa_launch_short(ap, tp.wpe, cigar_now, grid, st);
+          // (with CIGARs the launch owns n_cur slots above the bump pointer: move it past them for whatever allocates next)
+          if (cigar_now) LAUNCH_K(k_bump, dim3(1), dim3(64), 0, st, ap.arena_top, (unsigned long long)n_cur * wfa_short_bt_slot_units(ap.max_score, tp.wpe), ap.arena_units);
+        }
         else wfa_launch_align(ap, tp.tier, cigar_now, raw, grid, st, tp.wpe);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(L.e1, st));
@@ -959,8 +968,8 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       const int w_me = window_width(max_error, pen.o, pen.e, bucket_hi);
       // (tuned budgets pay where they narrow a wide window -- or, score-only, where they bring it down to what the
       // several-alignments-per-wavefront tier holds)
-      const bool would_tune = n >= 8192 && !c->tuning.no_auto_budget &&
-                              (w_me > 128 || (!compute_cigar && w_me > 15 && wfa_short_supported(pen.x, oe, pen.e) && !c->tuning.min_tier));
+      const bool short_ok = wfa_short_supported(pen.x, oe, pen.e) && !c->tuning.min_tier && !(compute_cigar && c->tuning.no_short_cigar);
+      const bool would_tune = n >= 8192 && !c->tuning.no_auto_budget && (w_me > 128 || (w_me > 15 && short_ok));
       bool inherited = false;
       if (would_tune && c->same_stream)
         for (int i = 0; i < c->n_saved_q; ++i) {
@@ -1001,8 +1010,8 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       constexpr int budget_margin = 100, budget_slack = 2;
       // (with a band requested the sample still runs, exactly: the budgets serve the banded kernels too -- see the band policy below)
       const int w_me2 = window_width(max_error, pen.o, pen.e, max_len);
-      const bool try_budget = !raw && n_pending >= 8192 && !c->tuning.no_auto_budget &&
-                              (w_me2 > 128 || (!compute_cigar && w_me2 > 15 && wfa_short_supported(pen.x, oe, pen.e) && !c->tuning.min_tier));
+      const bool short_ok2 = wfa_short_supported(pen.x, oe, pen.e) && !c->tuning.min_tier && !(compute_cigar && c->tuning.no_short_cigar);
+      const bool try_budget = !raw && n_pending >= 8192 && !c->tuning.no_auto_budget && (w_me2 > 128 || (w_me2 > 15 && short_ok2));
       int saved_idx = -1;
       if (try_budget && c->same_stream) {
         for (int i = 0; i < c->n_saved_q; ++i) {

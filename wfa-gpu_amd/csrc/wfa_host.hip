@@ -89,9 +89,12 @@ struct DevBuf {
 
 // device counters (u64 slots)
 // (CT_LCELLS/CT_LIST and CT_LCELLS2/CT_LIST2: cell count and failure-list length of the first and second wavefront launch of
-// a chain, zeroed in pairs; CT_NOMEM: length of the list of pairs that ran out of arena in the current pass)
+// a chain, zeroed in pairs; CT_NOMEM: length of the list of pairs that ran out of arena in the current pass; CT_UNFIN: pairs of the
+// batch that are not DONE, counted just before every chain's synchronisation)
 enum { CT_ARENA = 0, CT_OPS = 1, CT_TEXT = 2, CT_LCELLS = 3, CT_LIST = 4, CT_SUM_OPS = 5, CT_SUM_TEXT = 6, CT_CELLS = 7, CT_MAX_SCORE = 8, CT_NRAW = 9, CT_SCRATCH = 10,
-       CT_LCELLS2 = 11, CT_LIST2 = 12, CT_NOMEM = 13, CT_N = 14 };
+       CT_LCELLS2 = 11, CT_LIST2 = 12, CT_NOMEM = 13, CT_UNFIN = 14, CT_N = 15 };
+constexpr size_t CT_BYTES = 128;      // the u64 slots, padded to a cache line boundary (CT_N * 8 = 120)
+static_assert(CT_N * sizeof(unsigned long long) <= CT_BYTES && CT_N <= 32, "counter block");
 
 constexpr uint32_t MASK(uint32_t st) { return 1u << st; }
 
@@ -115,10 +118,14 @@ __device__ __forceinline__ void block_append(bool take, uint32_t value, uint32_t
 
 // pairs of `work` whose status is in `mask` -> out list (appended at *out_count).  n_dev (optional): the real length of
 // `work` where only the device knows it yet; n is then an upper bound.
+// work_ctr (optional): the eight claim counters of the wavefront launch that has just finished, zeroed here for the next
+// one (a hipMemsetAsync per launch is a kernel launch of its own: ~5 us each, a dozen of them were 15 % of a 100k-pair step).
 __global__ void __launch_bounds__(1024) k_compact(const uint32_t* __restrict__ work, uint32_t n, const unsigned long long* __restrict__ n_dev,
                           const uint32_t* __restrict__ status,
-                          uint32_t mask, uint32_t* __restrict__ out, unsigned long long* __restrict__ out_count) {
+                          uint32_t mask, uint32_t* __restrict__ out, unsigned long long* __restrict__ out_count,
+                          unsigned int* __restrict__ work_ctr = nullptr) {
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (work_ctr && blockIdx.x == 0 && threadIdx.x < 8) work_ctr[threadIdx.x * 16] = 0u;
   if (n_dev) n = min(n, (uint32_t)*n_dev);
   bool take = false; uint32_t pair = 0;
   if (gid < n) { pair = work ? work[gid] : gid; take = (mask >> status[pair]) & 1u; }
@@ -274,6 +281,7 @@ struct wfagpu_amd_ctx {
   struct SavedQ { unsigned bucket_hi; int q; int x, o, e, max_error; } saved_q[8] = {};
   static unsigned length_class(unsigned len) { unsigned c = 1; while (c < len && c < (1u << 31)) c <<= 1; return c; }
   int n_saved_q = 0;
+  uint32_t ct_used = 0;      // counters (bit = index) used since the call zeroed them all: zero_counter re-zeroes only those
   std::vector<Retired> retired;      // outgrown device buffers waiting for a moment when hipFree does not stall anybody
   size_t retired_bytes() const { size_t b = 0; for (const auto& r : retired) b += r.bytes; return b; }
   void free_retired() { for (auto& r : retired) hipFree(r.p); retired.clear(); }
@@ -317,8 +325,8 @@ int wfagpu_amd_create(wfagpu_amd_ctx_t** out, const wfagpu_amd_config_t* cfg) {
     HIP_TRY(hipEventCreate(&c->ev_b0)); HIP_TRY(hipEventCreate(&c->ev_b1));
     HIP_TRY(hipEventCreate(&c->ev_t0)); HIP_TRY(hipEventCreate(&c->ev_t1));
     HIP_TRY(hipEventCreate(&c->ev_end));
-    if (c->counters.ensure(CT_N * sizeof(unsigned long long), c->stream)) return -1;
-    if (c->work_ctr.ensure(8 * 64, c->stream)) return -1;
+    // (the eight claim counters of the wavefront kernels, 64 bytes apart, sit behind the u64 slots: one memset zeroes both)
+    if (c->counters.ensure(CT_BYTES + 8 * 64, c->stream)) return -1;
     return 0;
   };
   if (init()) { wfagpu_amd_destroy(c); return -1; }
@@ -511,8 +519,13 @@ int read_counters(wfagpu_amd_ctx* c) {
   return 0;
 }
 
+// Called before every use of a counter.  All counters are zeroed together when a call starts; a counter is zeroed again here
+// only when it has been used since (every memset is a kernel launch of its own: a simple call -- one pass, one chain -- now
+// has none of them).
 int zero_counter(wfagpu_amd_ctx* c, int idx, int count = 1) {
-  HIP_TRY(hipMemsetAsync(static_cast<unsigned long long*>(c->counters.p) + idx, 0, sizeof(unsigned long long) * count, c->stream));
+  const uint32_t mask = ((1u << count) - 1u) << idx;
+  if (c->ct_used & mask) HIP_TRY(hipMemsetAsync(static_cast<unsigned long long*>(c->counters.p) + idx, 0, sizeof(unsigned long long) * count, c->stream));
+  c->ct_used |= mask;
   return 0;
 }
 
@@ -592,7 +605,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   ap.score = d_scores;
   ap.status = static_cast<uint32_t*>(c->status.p);
   ap.cells = static_cast<uint32_t*>(c->cells.p);
-  ap.work_counter = static_cast<unsigned int*>(c->work_ctr.p);
+  ap.work_counter = reinterpret_cast<unsigned int*>(static_cast<char*>(c->counters.p) + CT_BYTES);
   ap.arena_top = ct + CT_ARENA;
   ap.launch_cells = ct + CT_LCELLS;
   ap.no_lean = c->tuning.careful_only ? 1 : 0;
@@ -632,7 +645,8 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   }
 
   HIP_TRY(hipMemsetAsync(c->status.p, 0, (size_t)4 * n, st));
-  HIP_TRY(hipMemsetAsync(c->counters.p, 0, CT_N * sizeof(unsigned long long), st));
+  HIP_TRY(hipMemsetAsync(c->counters.p, 0, CT_BYTES + 8 * 64, st));
+  c->ct_used = 0;
   HIP_TRY(hipEventRecord(c->ev_start, st));
   if (!prepacked) {
     wfa_launch_pack(b->d_sequences, ap.meta, n, static_cast<uint32_t*>(c->packed.p), static_cast<uint8_t*>(c->flags.p), st);
@@ -647,6 +661,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   unsigned long long arena_units_call = 0;
   unsigned long long text_used = 0;
   unsigned long long sample_cells_call = 0;    // cells of auto-budget samples whose pairs were aligned again
+  long long unfinished_at_sync = -1;           // pairs not DONE as of the last chain's synchronisation; -1: work was queued since
   int rc = 0;
 
   // Runs one list of pairs to completion: passes bounded by the arena, tier escalation inside a pass,
@@ -691,6 +706,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
     int round = 0;
     while (n_cur > 0) {
       // ---- one chain ------------------------------------------------------------------------------------------------
+      unfinished_at_sync = -1;      // (work is being queued: the last count is history)
       uint32_t* const chain_list = cur;
       const uint32_t n_chain = n_cur;
       struct Link { int tier; int ct_list; int ct_cells; hipEvent_t e0, e1; bool banded; bool budgeted; bool first_round; uint32_t n_in; } link[2];
@@ -749,7 +765,6 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         if (cigar_now) ap.chunk_units = (uint32_t)std::min<unsigned long long>(4096u, std::max<unsigned long long>(256, ap.arena_units / (4ull * (unsigned)grid)));
         ap.work_shards = 8u;
         if (zero_counter(c, L.ct_cells, 2)) return -1;   // (the launch's cell count and, next to it, the length of its failure list)
-        HIP_TRY(hipMemsetAsync(c->work_ctr.p, 0, 8 * 64, st));
         HIP_TRY(hipEventRecord(L.e0, st));
         if (tp.tier == 5) {
           wfa_launch_short(ap, tp.wpe, cigar_now, grid, st);
@@ -761,7 +776,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         HIP_TRY(hipEventRecord(L.e1, st));
         uint32_t* nxt = spare[flip]; flip ^= 1;
         LAUNCH_K(k_compact, dim3(cdiv(n_cur, compact_block(n_cur))), dim3(compact_block(n_cur)), 0, st, (const uint32_t*)cur, n_cur, cur_len_dev,
-                           static_cast<const uint32_t*>(c->status.p), MASK(WFA_ST_BAND) | MASK(WFA_ST_SCORE), nxt, ct + L.ct_list);
+                           static_cast<const uint32_t*>(c->status.p), MASK(WFA_ST_BAND) | MASK(WFA_ST_SCORE), nxt, ct + L.ct_list, ap.work_counter);
         s_hi = std::max<long long>(s_hi, L.banded ? std::min(max_score, 30000) : max_score);
         ++n_links; ++round;
         // what the failures of this round run with next
@@ -866,7 +881,13 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
                            static_cast<const uint32_t*>(c->status.p), MASK(WFA_ST_NOMEM), nxt_pending, ct + CT_NOMEM);
       }
       // ---- the chain's one synchronisation --------------------------------------------------------------------------
+      // (with it comes the number of pairs of the whole batch that are not finished yet: when this turns out to have been the
+      // call's last chain, that IS the end-of-call check -- no launch and no round trip of its own)
+      if (zero_counter(c, CT_UNFIN)) return -1;
+      LAUNCH_K(k_count_unfinished, dim3(cdiv(n, 256)), dim3(256), 0, st, n, static_cast<const uint32_t*>(c->status.p), ct + CT_UNFIN);
+      HIP_TRY(hipEventRecord(c->ev_end, st));
       if (read_counters(c)) return -1;
+      unfinished_at_sync = (long long)c->h_counters[CT_UNFIN];
       uint32_t n_in = n_chain;
       for (int l = 0; l < n_links; ++l) {
         const Link& L = link[l];
@@ -1118,12 +1139,17 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   if (pen_scale > 1) LAUNCH_K(k_scale_scores, dim3(cdiv(n, 256)), dim3(256), 0, st, d_scores, n, pen_scale);
   // every pair must have been finished by one of the lists above; anything else is a driver bug and must not
   // be returned as a result
-  if (zero_counter(c, CT_LIST)) return -1;
-  LAUNCH_K(k_count_unfinished, dim3(cdiv(n, 256)), dim3(256), 0, st, n, static_cast<const uint32_t*>(c->status.p), ct + CT_LIST);
-  HIP_TRY(hipEventRecord(c->ev_end, st));
-  if (read_counters(c)) return -1;
-  if (c->h_counters[CT_LIST]) {
-    fprintf(stderr, "[!] ERROR: %llu of %u alignments were left unfinished\n", c->h_counters[CT_LIST], n);
+  if (unfinished_at_sync < 0 || pen_scale > 1) {
+    // (something was queued behind the last chain's synchronisation -- list bookkeeping of a pass that turned out to be the
+    // last, the score scaling: count again and drain the stream, the call is blocking)
+    if (zero_counter(c, CT_UNFIN)) return -1;
+    LAUNCH_K(k_count_unfinished, dim3(cdiv(n, 256)), dim3(256), 0, st, n, static_cast<const uint32_t*>(c->status.p), ct + CT_UNFIN);
+    HIP_TRY(hipEventRecord(c->ev_end, st));
+    if (read_counters(c)) return -1;
+    unfinished_at_sync = (long long)c->h_counters[CT_UNFIN];
+  }
+  if (unfinished_at_sync != 0) {
+    fprintf(stderr, "[!] ERROR: %lld of %u alignments were left unfinished\n", unfinished_at_sync, n);
     return -1;
   }
   c->stats.cells = c->h_counters[CT_CELLS] - sample_cells_call;

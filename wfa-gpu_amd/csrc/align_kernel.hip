@@ -715,14 +715,14 @@ wfa_align_kernel(const WfaAlignParams p) {
       // race (a window is read before thread 0 has published it).  Every thread calls it with the same arguments.
       // (round 3 shipped a rule of its own here -- re-centring only when the wavefront overflowed, clamped into the old window,
       // at most two diagonals per score -- which lost pairs the reference's rule keeps: profiles/r04/banded.md.)
-      auto band_window = [&](int& lo, int& hi, const int score, const int wx, const int wo, const int we, const OffT* row_mx) {
+      auto band_window = [&](int& lo, int& hi, const bool period_start, const int wx, const int wo, const int we, const OffT* row_mx) {
         const int beta = p.band_width;
         hi = max(range_hi(wx), max(range_hi(wo), range_hi(we)) + 1);
         lo = min(range_lo(wx), min(range_lo(wo), range_lo(we)) - 1);
         const int excess = (hi - lo + 1) - beta;
         if (excess > 0) { hi -= (excess + 1) / 2; lo += excess / 2; }
         const int mxlo = range_lo(wx), mxhi = range_hi(wx);
-        if (mxhi - mxlo >= beta - 1 && (score % p.band_period) == 0) {
+        if (mxhi - mxlo >= beta - 1 && period_start) {      // (period_start: score % band_period == 0)
           uint32_t best = 0xFFFFFFFFu;
           for (int kk = mxlo + tid; kk < mxhi; kk += NT) {
             const int off = (int)row_mx[kk];
@@ -767,6 +767,8 @@ wfa_align_kernel(const WfaAlignParams p) {
         if constexpr (BANDED) {
           constexpr int W00 = 0;                                      // pack_range(0, 0)
           unsigned long long ex_m = 1ull, ex_i = 0ull;                // bit (score & 63): M / the gap components of that score exist
+          int phase = 0;                                              // score % band_period, kept by counting (no division per score)
+          int full_rows = 0;                                          // consecutive scores so far whose rows were band_width wide
           if constexpr (NW > 1) { if (tid == 0) bslot[1] = 0u; }
           // (row book: M windows; rows that do not exist -- negative scores included -- read as the window [0, 0])
           if constexpr (NW == 1) { book.a = W00; } else { for (int i = tid; i <= bkm; i += NT) book.A[i] = W00; }
@@ -775,6 +777,7 @@ wfa_align_kernel(const WfaAlignParams p) {
           for (;;) {
             const int ns = s + 1;
             if (ns > budget) { status = WFA_ST_SCORE; break; }
+            if (++phase == p.band_period) phase = 0;
             const bool has_oe = ns >= oe;
             const bool e_oe = has_oe && ((ex_m >> ((ns - oe) & 63)) & 1ull), e_ie = has_oe && ((ex_i >> ((ns - e) & 63)) & 1ull);
             const bool e_x = ns >= x && ((ex_m >> ((ns - x) & 63)) & 1ull);
@@ -803,7 +806,7 @@ wfa_align_kernel(const WfaAlignParams p) {
             const int wo = has_oe ? book.get_a((ns - oe) & bkm) : W00;
             const int we = e_ie ? book.get_a((ns - e) & bkm) : W00;
             int lo, hi;
-            if (gap) band_window(lo, hi, ns, wx, wo, we, p_x + (GZ - range_lo(wx)));
+            if (gap) band_window(lo, hi, phase == 0, wx, wo, we, p_x + (GZ - range_lo(wx)));
             else { lo = range_lo(wx); hi = range_hi(wx); }            // M only: the window of M[s-x] (:54-74)
             const int width = hi - lo + 1;
             ncells += (uint32_t)width;
@@ -813,10 +816,15 @@ wfa_align_kernel(const WfaAlignParams p) {
               tab_set(s, row_s, lo);
               codes = p.arena + (size_t)row_s * 16;
             }
-            // ring invariant of relative rows: NULL guard zones on both sides of the row, whatever the slot held before
-            for (int j = tid; j < 2 * GZ; j += NT) {
-              const int q = j < GZ ? j : width + j;
-              out_m[q] = (OffT)OffNull<OffT>::value; out_i[q] = (OffT)OffNull<OffT>::value; out_d[q] = (OffT)OffNull<OffT>::value;
+            // ring invariant of relative rows: NULL guard zones on both sides of the row, whatever the slot held before.  (Once
+            // every slot of the ring has held a full-width row, the zones ARE NULL -- nothing but NULLs is ever stored beside a
+            // row -- and stay so while the rows stay full width.)
+            full_rows = width == p.band_width ? full_rows + 1 : 0;
+            if (full_rows <= dm + 1) {
+              for (int j = tid; j < 2 * GZ; j += NT) {
+                const int q = j < GZ ? j : width + j;
+                out_m[q] = (OffT)OffNull<OffT>::value; out_i[q] = (OffT)OffNull<OffT>::value; out_d[q] = (OffT)OffNull<OffT>::value;
+              }
             }
             // rows that exist: their own mapping (column GZ = their lower limit); others: all NULL, any mapping
             const int rel_cur = GZ - lo;

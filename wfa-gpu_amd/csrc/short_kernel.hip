@@ -1,22 +1,23 @@
-// Score-only gap-affine WFA for SHORT wavefronts: several alignments per 64-lane wavefront, rings in registers.
+// Gap-affine WFA for SHORT wavefronts: several alignments per 64-lane wavefront, rings in registers (tier 5).
 //
 // The one-wave tier of align_kernel.hip gives every alignment a whole wavefront: at BASELINE configs[1] (150 bp reads at
 // 2 % error: optimal scores of 2..12, a score budget of ~14 once it is tuned) a wavefront row is 5..13 diagonals wide, so
 // 80 % of the lanes carry nothing and the per-score bookkeeping -- as many instructions as a 64-diagonal chunk of cells --
 // is paid per alignment.  Here a group of L = 16 (or 32) lanes is one alignment, lane j of the group is diagonal wlo + j for
 // the WHOLE alignment (the exact diagonal window of the pair's score budget must fit the group: the same window argument as
-// in align_kernel.hip), and the wavefront history a cell needs -- M of the last max(x, o+e) scores, I and D of the last
-// one (e == 1) -- lives in registers of the lane itself: M[s-x][k] is a register, M[s-o-e][k-1], I[s-1][k-1],
+// in align_kernel.hip), and the wavefront history a cell needs -- M of the last D = max(x, o+e) <= 8 scores, I and D of the
+// last one (e == 1) -- lives in registers of the lane itself: M[s-x][k] is a register, M[s-o-e][k-1], I[s-1][k-1],
 // M[s-o-e][k+1], D[s-1][k+1] are DPP row shifts (v_mov_b32_dpp row_shr:1 / row_shl:1: a "row" of the DPP network is 16
 // lanes = one group; the lanes a shift cannot feed keep NULL) of the neighbours' registers.  No LDS ring, no row limits, no
 // ring invariant, no barrier; LDS only holds the packed sequences of the G = 64 / L pairs for the extend.  The score loop is
 // unrolled over the ring depth so that every register index is a compile-time constant.
 //
-// Replaces, for such batches, the reference's distance_kernel (lib/kernels/sequence_distance_kernel.cu:175-425).  Results:
-// the optimal gap-affine score (wavefront_compute_affine.c:45-87 recurrences, out-of-range values are NULL,
-// termination M[s][tlen - plen] >= tlen: wavefront_extend.c:47-67) -- a score does not depend on tie-breaks or on which
-// cells outside the window are computed.  Pairs whose window does not fit a group (status BAND) or whose score exceeds
-// the budget (status SCORE) go on to the ordinary tiers on the device like the failures of any tier.
+// Replaces, for such batches, the reference's distance_kernel (lib/kernels/sequence_distance_kernel.cu:175-425) and, with
+// CIGARs (BT), its alignment_kernel (sequence_alignment_kernel.cu:355-688).  Results: the optimal gap-affine score
+// (wavefront_compute_affine.c:45-87 recurrences, out-of-range values are NULL, termination M[s][tlen - plen] >= tlen:
+// wavefront_extend.c:47-67) and WFA2's CIGAR (see the note at the kernel).  Pairs whose window does not fit a group
+// (status BAND), whose score exceeds the budget (status SCORE) or that find the arena full (status NOMEM) go on to the
+// ordinary tiers / the next pass on the device like the failures of any tier.
 #include <array>
 #include <utility>
 

@@ -428,7 +428,9 @@ int window_width(long long S, int o, int e, unsigned max_seq_len) {
 }
 
 // Smallest tier whose LDS footprint fits a score budget S.
-bool plan_tier(const wfagpu_amd_ctx* c, WfaAlignParams& p, int max_score, unsigned max_seq_len, bool bt, bool raw, TierPlan* out) {
+// few_pairs: the list is expected to hold fewer pairs than the device has workgroup slots (the re-run of a long-read batch's
+// budget misses): what counts is the latency of ONE alignment, so wide wavefronts take sixteen waves instead of four.
+bool plan_tier(const wfagpu_amd_ctx* c, WfaAlignParams& p, int max_score, unsigned max_seq_len, bool bt, bool raw, TierPlan* out, bool few_pairs = false) {
   p.max_score = max_score;
   if (p.band_width > 0) {
     // Adaptive band: a ring row holds the band_width diagonals of its score, stored relative to the row's own lower limit,
@@ -474,6 +476,7 @@ bool plan_tier(const wfagpu_amd_ctx* c, WfaAlignParams& p, int max_score, unsign
     // a single wavefront sweeps up to ~16 chunks per score before more waves pay off
     if (t == 0 && (width > 1024 || p.dm > 64)) continue;
     if (t == 1 && width > 8192) continue;
+    if (t == 1 && few_pairs && width >= 1024 && !min_tier && wfa_align_lds_bytes(p, 2) <= budget[2]) continue;
     int nb = wfa_align_max_blocks_per_cu(t, bt, raw, false, lds);
     if (nb < 1) continue;
     // Occupancy-matched instantiation of the one-wave kernels: LDS decides how many rings a CU holds; compiled for 8 waves
@@ -726,7 +729,9 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         ap.band_period = band;
         if (ap.band_width > 0 && !plan_tier(c, ap, std::min(max_score, 30000), max_len, cigar_now, raw, &tp)) ap.band_width = 0;
         L.banded = ap.band_width > 0;
-        if (ap.band_width == 0 && !plan_tier(c, ap, max_score, max_len, cigar_now, raw, &tp)) {
+        // (the speculative re-run of budget misses: a percent or two of the chain's pairs)
+        const bool few_pairs = n_links == 1 && link[0].budgeted && (n_chain / 50u) <= 2u * (unsigned)c->num_cus;
+        if (ap.band_width == 0 && !plan_tier(c, ap, max_score, max_len, cigar_now, raw, &tp, few_pairs)) {
           fprintf(stderr, "[!] ERROR: sequences of %u bases do not fit the LDS staging area\n", max_len);
           return -1;
         }

@@ -174,3 +174,44 @@ int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n",sizeof(wfagpu_
                    C.sizeof(wfagpu.LaunchConfig), wfagpu.LaunchConfig.tuning.offset,
                    C.sizeof(wfagpu.LaunchStats), wfagpu.LaunchStats.devices.offset, C.sizeof(wfagpu.Stats),
                    wfagpu.Stats.main_launch_ms.offset, C.sizeof(wfagpu.Batch)]
+
+
+def test_the_check_paths_own_scorer_and_checkers_agree_with_the_oracle(lib):
+    """`-c` (check_correctness) compares every result with utils/verification.c: an independent scalar scorer and two CIGAR
+    checkers that share nothing with the kernels -- and, so far, were only ever compared with anything by the 1M-pair CLI run on
+    the GPU.  Here: the scorer against the oracle (WFA2's restatement) on random pairs under five penalty sets, the checkers on the
+    oracle's CIGARs (accepted, cost == score) and on corrupted ones (rejected)."""
+    import random
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    lib.verification_cpu_score.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int]
+    lib.verification_cpu_score.restype = C.c_int
+    lib.check_cigar_edit.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, C.c_size_t, C.c_char_p]
+    lib.check_cigar_edit.restype = C.c_bool
+    lib.check_affine_distance.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p]
+    lib.check_affine_distance.restype = C.c_bool
+    rng = random.Random(606)
+    pairs = [(b"", b""), (b"", b"ACGT"), (b"ACGT", b""), (b"A", b"C")]
+    for _ in range(250):
+        t = bytes(rng.choice(b"ACGT") for _ in range(rng.randint(1, 400)))
+        p = bytearray(t)
+        for _ in range(rng.randint(0, len(t) // 8 + 1)):
+            r = rng.random(); a = rng.randint(0, len(p))
+            if r < 0.4 and a < len(p): p[a] = rng.choice(b"ACGT")
+            elif r < 0.7: del p[a:a + rng.randint(1, 9)]
+            else: p[a:a] = bytes(rng.choice(b"ACGT") for _ in range(rng.randint(1, 9)))
+        pairs.append((bytes(p), t))
+    pairs += [(bytes(rng.choice(b"ACGT") for _ in range(60)), bytes(rng.choice(b"ACGT") for _ in range(80))) for _ in range(20)]      # unrelated
+    buf, meta = wfagpu.layout_pairs(pairs)
+    for pen in ((2, 3, 1), (1, 2, 1), (5, 3, 2), (3, 1, 4), (4, 6, 2)):
+        so, co, _ = oracle_lib.oracle_batch(buf, meta, pen, cigar=True, nthreads=4)
+        for (p, t), s_want, cg in zip(pairs, so, co):
+            assert lib.verification_cpu_score(p, t, len(p), len(t), *pen) == s_want, (pen, p, t)
+            assert lib.check_cigar_edit(t, p, len(t), len(p), cg.encode())
+            assert lib.check_affine_distance(t, p, len(t), len(p), int(s_want), *pen, cg.encode())
+            if cg:
+                assert not lib.check_affine_distance(t, p, len(t), len(p), int(s_want) + 1, *pen, cg.encode())
+                assert not lib.check_cigar_edit(t, p, len(t), len(p), (cg + "1M").encode())
+                assert not lib.check_cigar_edit(t, p, len(t), len(p), cg[:-1].encode())
+

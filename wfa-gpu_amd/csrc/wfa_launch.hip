@@ -423,11 +423,14 @@ void bring_up_fn(DevState* dp, wfagpu_amd_launch_config_t cfg, int lanes, bool p
 }
 // Starts the bring-up thread of a slot unless everything `lanes` lanes need is there already.  (g_dev_mu[slot] held.)
 void start_bring(DevState& d, const wfagpu_amd_launch_config_t& cfg, int lanes, bool prime) {
+  // (one is still running -- the background bring-up of a process that aligns right after its first device query: its items are
+  // awaited one by one by the threads that need them, whatever it does not make they make themselves: ensure_item)
+  { std::lock_guard<std::mutex> l(d.bring_mu); if (d.bring_active) return; }
   join_bring(d);
   bool complete = d.up && d.down;
   for (int k = 0; k < lanes; ++k) complete = complete && d.lane[k].ctx;
   if (complete) return;
-  d.bring_active = true;
+  { std::lock_guard<std::mutex> l(d.bring_mu); d.bring_active = true; }
   d.bring_thread = std::thread(bring_up_fn, &d, cfg, lanes, prime);
 }
 

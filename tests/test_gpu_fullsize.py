@@ -104,7 +104,9 @@ def test_cfg2_full_size_score_only_as_benched():
             assert st.pairs_tier[5] + st.pairs_tier[0] == n, list(st.pairs_tier)
             assert st.pairs_tier[0] <= (4096 if call == 0 else 0) + st.pairs_budget_missed, list(st.pairs_tier)
             assert st.pairs_tier[5] >= (n - 4096 if call == 0 else 0.99 * n), list(st.pairs_tier)
-            assert st.main_launch_tier == 5
+            # (the longest wavefront launch of the first call may be the one-wave launch of the 4096 sampled pairs: 0.13 ms,
+            # against 0.11 ms for the other 95 904 pairs on tier 5)
+            assert st.main_launch_tier == 5 or call == 0
             al.hint_same_stream(True)
     finally:
         al.close()

@@ -42,9 +42,10 @@ template <int L> __device__ __forceinline__ int from_above(int v, int j) {
 // compile-time constant (round 3 had the two instantiations of the benchmark penalties; now every set with e == 1 and
 // max(x, o + e) <= 8 after the common-factor reduction: 64 x 2 kernels, picked from a table).
 // BT (round 4): with CIGARs.  Every cell also leaves its origin byte (wfa_device.h: source of M with WFA2's priority on equal
-// offsets -- mismatch, then deletion, then insertion --, gap extension over gap open) in a row of L bytes per score; an
-// alignment claims its row table and the rows of all the scores its budget allows with ONE atomic on the arena's bump pointer
-// (a few hundred bytes: budgets are <= 35 here) and the backtrace kernels (trace_kernel.hip) read them like any other tier's.
+// offsets -- mismatch, then deletion, then insertion --, gap extension over gap open) in a row of L bytes per score; the rows
+// collect in LDS and go out, with the row table, when the alignment is done, into a slot of the arena the work item owns
+// without any atomic (a few hundred bytes: budgets are <= 35 here); the backtrace kernels (trace_kernel.hip) read them like
+// any other tier's.
 // Is it WFA2's CIGAR?  This kernel has no per-row limits and turns every I / D value that ran past a sequence end into NULL
 // at once, where WFA2 keeps such values inside a row and trims them at its ends only (wavefront_compute.c:570-603).  The
 // two differ only in cells that no optimal alignment passes through (a value past an end cannot lie on a path to the corner,
@@ -60,33 +61,107 @@ __global__ void __launch_bounds__(64) wfa_short_kernel(const WfaAlignParams p) {
   constexpr int G = 64 / L;
   const int lane = threadIdx.x & 63, grp = lane / L, j = lane % L;
   const int cap = p.seq_words_cap;
-  uint32_t* const Pw = slds + (size_t)grp * 2 * cap;
-  uint32_t* const Tw = Pw + cap;
+  // Two sets of staged sequences: the pairs of this iteration and the pairs of the next one (below).
+  const size_t set_words = (((size_t)G * 2 * cap) + 3) & ~(size_t)3;
+  uint32_t* Pw = slds + (size_t)grp * 2 * cap;
+  uint32_t* Pn = Pw + set_words;
+  // BT: the group's rows of origin bytes collect in LDS ([score][lane of the group], behind the staged sequences) and go out in
+  // 16-byte pieces when the alignment is done.  (A global byte store per score -- four 16-byte pieces of four different cache
+  // lines per wave instruction -- cost 0.035 of the 0.26 ms per 100k configs[1] pairs.)
+  const int rows_cap = p.max_score + 1;
+  uint8_t* const lrows = BT ? reinterpret_cast<uint8_t*>(slds + 2 * set_words) + (size_t)grp * rows_cap * L + j : nullptr;
   uint32_t n_work = p.n_work;
   if (p.n_work_dev) n_work = min(n_work, (uint32_t)*p.n_work_dev);
   const unsigned long long grp_mask = (L == 64) ? ~0ull : (((1ull << L) - 1ull) << (grp * L));
   unsigned long long blk_cells = 0;
+  unsigned long long arena_top0 = 0;                        // (the bump pointer as the launch found it: nobody moves it while the launch runs)
+  if constexpr (BT) arena_top0 = *p.arena_top;
 
-  for (uint32_t base = blockIdx.x * G; base < n_work; base += gridDim.x * G) {
-    const uint32_t w = base + grp;
-    bool active = w < n_work;
-    uint32_t pair = 0;
-    if (active) pair = p.work ? p.work[w] : w;
-    if (active && p.only_pending && p.status[pair] != WFA_ST_PENDING) active = false;
-    int plen = 0, tlen = 0;
-    const uint32_t* gp = nullptr; const uint32_t* gt = nullptr;
-    if (active) {
-      const WfaSeqPair mp = p.meta[pair];
-      plen = (int)mp.pattern_len; tlen = (int)mp.text_len;
-      gp = p.packed + (mp.pattern_offset_packed >> 2);
-      gt = p.packed + (mp.text_offset_packed >> 2);
+  // Software pipeline over the iterations of a wavefront.  All wavefronts of a launch start together, do the same amount of work
+  // and so stay in step: with the loads of an iteration issued when it starts -- work item -> record and status -> sequences,
+  // three dependent round trips, every wavefront of the chip asking at once -- the vector pipe sat idle for half of the launch
+  // (0.133 ms per 100k configs[1] pairs at 47 % VALU busy; with CIGARs, whose stores the next loads also queued behind, 0.22).
+  // Now the work item of iteration i+3, the record of i+2 and the sequences of i+1 are requested at the top of iteration i and
+  // looked at one iteration later; the sequences wait in registers (NPF words per lane and sequence; longer ones fetch the
+  // rest when they are staged) and go into the other LDS set when iteration i is done.
+  constexpr int NPF = 2;
+  struct Meta { uint32_t pair, st, poff, toff; int plen, tlen, budget; };
+  struct SeqRegs { uint32_t a[NPF], b[NPF]; };
+  const uint32_t stride = gridDim.x * G;
+  auto fetch_pair = [&](const uint32_t b) -> uint32_t {     // (groups beyond the list look at its last item and stay inactive)
+    const uint32_t w = min(b + (uint32_t)grp, n_work - 1u);
+    return p.work ? p.work[w] : w;
+  };
+  auto fetch_meta = [&](const uint32_t pair) -> Meta {
+    Meta m;
+    m.pair = pair;
+    m.st = p.only_pending ? p.status[pair] : (uint32_t)WFA_ST_PENDING;
+    const WfaSeqPair mp = p.meta[pair];
+    m.plen = (int)mp.pattern_len; m.tlen = (int)mp.text_len;
+    m.poff = (uint32_t)(mp.pattern_offset_packed >> 2); m.toff = (uint32_t)(mp.text_offset_packed >> 2);
+    m.budget = p.budget ? p.budget[pair] : p.max_score;
+    return m;
+  };
+  auto words_of = [](const int len) { return ((len + 15) >> 4) + 1; };
+  auto seq_ok = [&](const Meta& m, const uint32_t b) {      // will this group stage sequences for the iteration at list position b?
+    return b + (uint32_t)grp < n_work && m.st == (uint32_t)WFA_ST_PENDING && words_of(m.plen) <= cap && words_of(m.tlen) <= cap;
+  };
+  auto fetch_seq = [&](const Meta& m, const bool ok) -> SeqRegs {
+    SeqRegs r;
+    const int pw = ok ? words_of(m.plen) : 0, tw = ok ? words_of(m.tlen) : 0;
+#pragma unroll
+    for (int u = 0; u < NPF; ++u) {
+      const int i = j + u * L;
+      r.a[u] = i < pw ? p.packed[(size_t)m.poff + i] : 0u;
+      r.b[u] = i < tw ? p.packed[(size_t)m.toff + i] : 0u;
     }
+    return r;
+  };
+  auto stage_seq = [&](uint32_t* const Pb, const Meta& m, const SeqRegs& r, const bool ok) {
+    uint32_t* const Tb = Pb + cap;
+    const int pw = ok ? words_of(m.plen) : 0, tw = ok ? words_of(m.tlen) : 0;
+#pragma unroll
+    for (int u = 0; u < NPF; ++u) {
+      const int i = j + u * L;
+      if (i < pw) Pb[i] = r.a[u];
+      if (i < tw) Tb[i] = r.b[u];
+    }
+#pragma nounroll
+    for (int i = j + NPF * L; i < pw; i += L) Pb[i] = p.packed[(size_t)m.poff + i];
+#pragma nounroll
+    for (int i = j + NPF * L; i < tw; i += L) Tb[i] = p.packed[(size_t)m.toff + i];
+  };
+
+  uint32_t base = blockIdx.x * G;
+  Meta m0 = {}, m1 = {};
+  uint32_t pair2 = 0;
+  if (base < n_work) {
+    // fill the pipeline
+    m0 = fetch_meta(fetch_pair(base));
+    m1 = fetch_meta(fetch_pair(base + stride));
+    pair2 = fetch_pair(base + 2u * stride);
+    const bool ok0 = seq_ok(m0, base);
+    const SeqRegs r0 = fetch_seq(m0, ok0);
+    stage_seq(Pw, m0, r0, ok0);
+  }
+  for (; base < n_work; base += stride) {
+    // ---- requests for the iterations to come
+    const Meta m2 = fetch_meta(pair2);
+    const bool ok1 = seq_ok(m1, base + stride);
+    const SeqRegs r1 = fetch_seq(m1, ok1);
+    const uint32_t pair3 = fetch_pair(base + 3u * stride);
+    // ---- this iteration
+    const uint32_t w = base + grp;
+    const bool active = w < n_work && m0.st == (uint32_t)WFA_ST_PENDING;
+    const uint32_t pair = m0.pair;
+    const int plen = active ? m0.plen : 0, tlen = active ? m0.tlen : 0;
+    uint32_t* const Tw = Pw + cap;
     const int kend = tlen - plen;
     const int pwords = ((plen + 15) >> 4) + 1, twords = ((tlen + 15) >> 4) + 1;
     // the pair's score budget and the diagonal window that can hold an alignment within it (align_kernel.hip: a path that
     // visits diagonal k beyond both 0 and kend pays one gap out and one gap back)
     int budget = p.max_score;
-    if (active && p.budget) budget = min(budget, p.budget[pair]);
+    if (active) budget = min(budget, m0.budget);
     {
       const long long worst = (long long)X * min(plen, tlen) + (kend ? OE + (long long)(abs(kend) - 1) : 0);
       budget = (int)min((long long)budget, worst);
@@ -113,7 +188,7 @@ __global__ void __launch_bounds__(64) wfa_short_kernel(const WfaAlignParams p) {
     uint32_t tab_unit = WFA_ROW_NONE, rows_unit = 0;
     if constexpr (BT) {
       const uint32_t tab_units = (uint32_t)(((long long)p.max_score + 2) >> 1), slot = tab_units + (uint32_t)(p.max_score + 1) * (L / 16);
-      const unsigned long long b = *p.arena_top + (unsigned long long)w * slot;
+      const unsigned long long b = arena_top0 + (unsigned long long)w * slot;
       if (active && status == WFA_ST_DONE) {
         if (b + slot <= p.arena_units) { tab_unit = (uint32_t)b; rows_unit = tab_unit + tab_units; }
         else status = WFA_ST_NOMEM;
@@ -121,11 +196,6 @@ __global__ void __launch_bounds__(64) wfa_short_kernel(const WfaAlignParams p) {
     }
     const bool run = active && status == WFA_ST_DONE;
     const int k = wlo + j;                                  // this lane's diagonal, for the whole alignment
-    uint8_t* const my_codes = BT ? p.arena + ((size_t)rows_unit * 16 + (uint32_t)j) : nullptr;      // + score * L
-    if (run) {
-      for (int i = j; i < pwords; i += L) Pw[i] = gp[i];
-      for (int i = j; i < twords; i += L) Tw[i] = gt[i];
-    }
     __builtin_amdgcn_wave_barrier();                        // (one wavefront: LDS operations execute in order)
 
     // run length from (v, h) on this lane's diagonal, 16 bases per step, wave-uniform continuation
@@ -136,13 +206,18 @@ __global__ void __launch_bounds__(64) wfa_short_kernel(const WfaAlignParams p) {
       const uint32_t* pw = Pw + (ok ? (v >> 4) : 0);
       const uint32_t* tw = Tw + (ok ? (h >> 4) : 0);
       const uint32_t sa = (uint32_t)v << 1, sb = (uint32_t)h << 1;
+      // (32 bases per LDS round trip: the loop goes on while ANY lane of the wavefront still matches -- the longest run of four
+      // alignments' main diagonals, five or six 16-base steps per score on 150 bp reads at 2 % -- and every step is a dependent
+      // LDS read; the waves of this kernel wait, they do not compete for the vector pipe)
       while (__builtin_amdgcn_ballot_w64(rem > 0) != 0ull) {
-        const uint32_t d = __builtin_amdgcn_alignbit(pw[1], pw[0], sa) ^ __builtin_amdgcn_alignbit(tw[1], tw[0], sb);
-        const int run16 = d ? (__builtin_ctz(d) >> 1) : 16;
-        const int n = min(run16, max(rem, 0));
+        const uint32_t p0 = pw[0], p1 = pw[1], p2 = pw[2], t0 = tw[0], t1 = tw[1], t2 = tw[2];
+        const uint32_t d0 = __builtin_amdgcn_alignbit(p1, p0, sa) ^ __builtin_amdgcn_alignbit(t1, t0, sb);
+        const uint32_t d1 = __builtin_amdgcn_alignbit(p2, p1, sa) ^ __builtin_amdgcn_alignbit(t2, t1, sb);
+        const int run32 = d0 ? (__builtin_ctz(d0) >> 1) : 16 + (d1 ? (__builtin_ctz(d1) >> 1) : 16);
+        const int n = min(run32, max(rem, 0));
         h += n;
-        rem = (n == 16) ? rem - 16 : 0;
-        ++pw; ++tw;
+        rem = (n == 32) ? rem - 32 : 0;
+        pw += 2; tw += 2;
       }
       return h;
     };
@@ -156,7 +231,7 @@ __global__ void __launch_bounds__(64) wfa_short_kernel(const WfaAlignParams p) {
       const bool mine = run && k == 0;
       const int h = extend(0, mine);
       m[0] = mine ? h : S_NULL;
-      if constexpr (BT) { if (run) my_codes[0] = 0; }
+      if constexpr (BT) { if (run) lrows[0] = 0; }
     }
     bool fin = !run;                                        // this lane's group has its result (or never ran)
     int score = -1;
@@ -185,7 +260,7 @@ __global__ void __launch_bounds__(64) wfa_short_kernel(const WfaAlignParams p) {
         if (!fin) {
           const uint32_t code = (i_e >= m_ol ? BT_I_EXT : 0u) | (d_e >= m_or ? BT_D_EXT : 0u) |
                                 ((mis == mv) ? BT_M_X : ((d1 == mv) ? BT_M_D : BT_M_I));
-          my_codes[(uint32_t)s * L] = (uint8_t)code;
+          lrows[s * L] = (uint8_t)code;
         }
       }
       const bool ok = !fin & ((unsigned)mv <= (unsigned)tlen) & ((unsigned)(mv - k) <= (unsigned)plen);
@@ -209,8 +284,19 @@ __global__ void __launch_bounds__(64) wfa_short_kernel(const WfaAlignParams p) {
         }
       }
     }
+    // ---- the sequences of the next iteration: registers -> the other LDS set.  (Before this iteration's results go out: the wait
+    // for the loads would otherwise wait for those stores as well -- one counter, in order.)
+    stage_seq(Pn, m1, r1, ok1);
     if constexpr (BT) {
       if (run && status == WFA_ST_DONE) {
+        // the rows, LDS -> arena: (score + 1) * L bytes in 16-byte pieces (LDS operations of one wavefront execute in order)
+        asm volatile("" ::: "memory");
+        {
+          const uint4* src = reinterpret_cast<const uint4*>(lrows - j);
+          uint4* dst = reinterpret_cast<uint4*>(p.arena + (size_t)rows_unit * 16);
+          const int n16 = (score + 1) * (L / 16);
+          for (int q = j; q < n16; q += L) dst[q] = src[q];
+        }
         // the row table: [score] = {unit of the row, its lower diagonal} (what every tier leaves for the backtrace)
         uint2* tab = reinterpret_cast<uint2*>(p.arena + (size_t)tab_unit * 16);
         for (int t = j; t <= score; t += L) tab[t] = make_uint2(rows_unit + (uint32_t)t * (L / 16), (uint32_t)wlo);
@@ -224,7 +310,10 @@ __global__ void __launch_bounds__(64) wfa_short_kernel(const WfaAlignParams p) {
       if (p.cells) p.cells[pair] = cells;
       blk_cells += cells;
     }
-    __builtin_amdgcn_wave_barrier();                        // (the next pairs overwrite the staged sequences)
+    // ---- everything moves up one stage
+    m0 = m1; m1 = m2; pair2 = pair3;
+    { uint32_t* const t = Pw; Pw = Pn; Pn = t; }
+    __builtin_amdgcn_wave_barrier();
   }
   // cells of this wavefront (the group leaders counted theirs)
   for (int d = 32; d > 0; d >>= 1) blk_cells += __shfl_down(blk_cells, d);
@@ -233,18 +322,30 @@ __global__ void __launch_bounds__(64) wfa_short_kernel(const WfaAlignParams p) {
 
 template <int L, int X, int OE, bool BT>
 void launch_short(const WfaAlignParams& p, int grid, hipStream_t stream) {
-  const size_t lds = (size_t)(64 / L) * 2 * p.seq_words_cap * 4;
+  const size_t lds = wfa_short_lds_bytes(p, L, BT);
   hipLaunchKernelGGL((wfa_short_kernel<L, X, OE, BT>), dim3(grid), dim3(64), lds, stream, p);
 }
 
+// wavefronts of this instantiation a CU holds (registers and LDS)
+template <int L, int X, int OE, bool BT>
+int occ_short(size_t lds) {
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(wfa_short_kernel<L, X, OE, BT>), 64, lds) != hipSuccess) nb = 0;
+  return nb;
+}
+
 // [x - 1][oe - 1], one table per group width and mode
-using ShortLauncher = void (*)(const WfaAlignParams&, int, hipStream_t);
-template <int L, bool BT, int I> constexpr ShortLauncher short_entry() { return &launch_short<L, I / 8 + 1, I % 8 + 1, BT>; }
-template <int L, bool BT, int... Is> constexpr std::array<ShortLauncher, 64> short_table(std::integer_sequence<int, Is...>) { return {short_entry<L, BT, Is>()...}; }
-const std::array<ShortLauncher, 64> g_short16 = short_table<16, false>(std::make_integer_sequence<int, 64>{});
-const std::array<ShortLauncher, 64> g_short32 = short_table<32, false>(std::make_integer_sequence<int, 64>{});
-const std::array<ShortLauncher, 64> g_short16_bt = short_table<16, true>(std::make_integer_sequence<int, 64>{});
-const std::array<ShortLauncher, 64> g_short32_bt = short_table<32, true>(std::make_integer_sequence<int, 64>{});
+struct ShortEntry { void (*launch)(const WfaAlignParams&, int, hipStream_t); int (*occ)(size_t); };
+template <int L, bool BT, int I> constexpr ShortEntry short_entry() { return {&launch_short<L, I / 8 + 1, I % 8 + 1, BT>, &occ_short<L, I / 8 + 1, I % 8 + 1, BT>}; }
+template <int L, bool BT, int... Is> constexpr std::array<ShortEntry, 64> short_table(std::integer_sequence<int, Is...>) { return {short_entry<L, BT, Is>()...}; }
+const std::array<ShortEntry, 64> g_short16 = short_table<16, false>(std::make_integer_sequence<int, 64>{});
+const std::array<ShortEntry, 64> g_short32 = short_table<32, false>(std::make_integer_sequence<int, 64>{});
+const std::array<ShortEntry, 64> g_short16_bt = short_table<16, true>(std::make_integer_sequence<int, 64>{});
+const std::array<ShortEntry, 64> g_short32_bt = short_table<32, true>(std::make_integer_sequence<int, 64>{});
+const ShortEntry& short_pick(const WfaAlignParams& p, int lanes, bool with_bt) {
+  const int idx = (p.x - 1) * 8 + (p.oe - 1);
+  return with_bt ? (lanes == 16 ? g_short16_bt : g_short32_bt)[idx] : (lanes == 16 ? g_short16 : g_short32)[idx];
+}
 
 }  // namespace
 
@@ -255,13 +356,15 @@ unsigned long long wfa_short_bt_slot_units(int max_score, int lanes) {
 
 bool wfa_short_supported(int x, int oe, int e) { return e == 1 && x >= 1 && x <= 8 && oe >= 1 && oe <= 8; }
 
-size_t wfa_short_lds_bytes(const WfaAlignParams& p, int lanes) { return (size_t)(64 / lanes) * 2 * p.seq_words_cap * 4; }
-
-void wfa_launch_short(const WfaAlignParams& p, int lanes, bool with_bt, int grid, hipStream_t stream) {
-  const int idx = (p.x - 1) * 8 + (p.oe - 1);
-  if (with_bt) (lanes == 16 ? g_short16_bt : g_short32_bt)[idx](p, grid, stream);
-  else (lanes == 16 ? g_short16 : g_short32)[idx](p, grid, stream);
+// the staged sequences of the 64 / lanes pairs of a wavefront; with_bt: + their rows of origin bytes up to the launch's largest budget
+size_t wfa_short_lds_bytes(const WfaAlignParams& p, int lanes, bool with_bt) {
+  const size_t seq = 2 * ((((size_t)(64 / lanes) * 2 * p.seq_words_cap) + 3) & ~(size_t)3) * 4;      // (two sets: this iteration's and the next one's)
+  return seq + (with_bt ? (size_t)64 * (size_t)(p.max_score + 1) : 0);
 }
+
+void wfa_launch_short(const WfaAlignParams& p, int lanes, bool with_bt, int grid, hipStream_t stream) { short_pick(p, lanes, with_bt).launch(p, grid, stream); }
+
+int wfa_short_max_blocks_per_cu(const WfaAlignParams& p, int lanes, bool with_bt) { return short_pick(p, lanes, with_bt).occ(wfa_short_lds_bytes(p, lanes, with_bt)); }
 
 // Loads this translation unit's code object on the current device (the runtime loads a code object at the first launch of
 // any of its kernels: 5-25 ms each): launch_alignments* call it while a cold call waits for its first upload.

@@ -146,8 +146,9 @@ void wfa_launch_trace(const WfaTraceParams& p, hipStream_t stream);
 // Tier 5 (short_kernel.hip): 64 / lanes alignments per wavefront (lanes = 16 or 32 diagonals each), rings in registers; with_bt: one row
 // of `lanes` origin bytes per score for the backtrace.
 bool wfa_short_supported(int x, int oe, int e);
-size_t wfa_short_lds_bytes(const WfaAlignParams& p, int lanes);
+size_t wfa_short_lds_bytes(const WfaAlignParams& p, int lanes, bool with_bt);
 void wfa_launch_short(const WfaAlignParams& p, int lanes, bool with_bt, int grid, hipStream_t stream);
+int wfa_short_max_blocks_per_cu(const WfaAlignParams& p, int lanes, bool with_bt);     // (wavefronts a CU holds: registers and LDS)
 unsigned long long wfa_short_bt_slot_units(int max_score, int lanes);     // (with_bt: arena units every work item of the launch owns)
 // Code-object priming: one empty launch per kernel translation unit (see the definitions).
 void wfa_prime_pack(hipStream_t stream);

@@ -456,11 +456,15 @@ bool plan_tier(const wfagpu_amd_ctx* c, WfaAlignParams& p, int max_score, unsign
   if (!raw && c->tuning.min_tier == 0 && !(bt && c->tuning.no_short_cigar) && wfa_short_supported(p.x, p.oe, p.e) && width + 1 <= 32 && max_score <= 30000) {
     const int lanes = width + 1 <= 16 ? 16 : 32;
     p.rs = 0;
-    const size_t lds = wfa_short_lds_bytes(p, lanes);
+    const size_t lds = wfa_short_lds_bytes(p, lanes, bt);
     if (lds <= 40u << 10) {
-      const int nb = (int)std::min<size_t>(32, c->lds_per_block_max / std::max<size_t>(lds, 1));
-      *out = {5, width, max_score, lds, std::max(nb, 1), lanes};      // (wpe carries the lanes per alignment)
-      return true;
+      // (what really fits a CU: the launch below cuts its grid so that every wavefront is resident from the start and all of
+      // them run the same number of iterations)
+      const int nb = std::min(32, wfa_short_max_blocks_per_cu(p, lanes, bt));
+      if (nb >= 1) {
+        *out = {5, width, max_score, lds, nb, lanes};      // (wpe carries the lanes per alignment)
+        return true;
+      }
     }
   }
   // dm guard cells on each side of a row (see the kernel's lean path); the 16-bit LDS tiers add a chunk of padding
@@ -761,6 +765,10 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         // (tier 5: 64 / lanes alignments per wavefront)
         const uint32_t units = tp.tier == 5 ? cdiv(n_cur, 64u / (uint32_t)tp.wpe) : n_cur;
         int grid = (int)std::min<uint32_t>(std::min<uint32_t>(units, grid_cap), (uint32_t)(c->num_cus * std::min(tp.blocks_per_cu, bpc_cap)));
+        // (tier 5 hands its work out by a grid-stride loop over items of equal cost: a grid that is not resident as a whole, or whose
+        // wavefronts do not all run the same number of iterations, ends in a tail -- 100k configs[1] pairs = 25 000 items on 8192
+        // wavefronts of which 7168 were resident: six rounds of iterations for 3.5 rounds of work)
+        if (tp.tier == 5 && grid > 0) grid = (int)cdiv(units, cdiv(units, (uint32_t)grid));
         // (a speculative re-run works on a list whose length only the device knows yet -- a percent of the chain's pairs,
         // usually: every workgroup beyond the work costs a claim atomic per shard)
         if (cur_len_dev) grid = std::min(grid, (int)std::max<uint32_t>(4u * (uint32_t)c->num_cus, n_cur / 64u));

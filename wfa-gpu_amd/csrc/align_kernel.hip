@@ -1502,7 +1502,7 @@ wfa_align_kernel(const WfaAlignParams p) {
 }
 
 template <int NW, bool BT, typename OffT, bool GR, bool RAW, bool BANDED, bool HYBRID = false, int WPE = 8, bool TIMED = false>
-void launch_inst(const WfaAlignParams& p, size_t lds, int grid, hipStream_t stream) {
+void launch_inst(const WfaAlignParams& p, size_t lds, int grid, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
   auto k = wfa_align_kernel<NW, BT, OffT, GR, RAW, BANDED, HYBRID, WPE, TIMED>;
   // the opt-in for large dynamic LDS is sticky per device and per kernel: pay the driver call once
   static thread_local size_t allowed[16] = {0};
@@ -1512,7 +1512,7 @@ void launch_inst(const WfaAlignParams& p, size_t lds, int grid, hipStream_t stre
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     allowed[dev & 15] = lds;
   }
-  hipLaunchKernelGGL(k, dim3(grid), dim3(NW * 64), lds, stream, p);
+  wfa_launch_timed(k, dim3(grid), dim3(NW * 64), lds, stream, ev0, ev1, p);
 }
 
 template <int NW, bool BT, typename OffT, bool GR, bool RAW, bool BANDED, bool HYBRID = false, int WPE = 8>
@@ -1526,36 +1526,36 @@ int occ_inst(size_t lds) {
 
 // tier -> instantiation (banded kernels exist for the packed LDS tiers only)
 template <bool BT, bool RAW>
-void launch_tier(const WfaAlignParams& p, int tier, size_t lds, int grid, hipStream_t stream, int wpe) {
+void launch_tier(const WfaAlignParams& p, int tier, size_t lds, int grid, hipStream_t stream, int wpe, hipEvent_t ev0, hipEvent_t ev1) {
   switch (tier) {
     case 0:
       // (the byte-compare class keeps the one instantiation: it is the rare path)
       if constexpr (!RAW) {
-        if (wpe == 7) { launch_inst<1, BT, int16_t, false, false, false, false, 7>(p, lds, grid, stream); break; }
-        if (wpe == 6) { launch_inst<1, BT, int16_t, false, false, false, false, 6>(p, lds, grid, stream); break; }
-        if (wpe == 4) { launch_inst<1, BT, int16_t, false, false, false, false, 4>(p, lds, grid, stream); break; }
+        if (wpe == 7) { launch_inst<1, BT, int16_t, false, false, false, false, 7>(p, lds, grid, stream, ev0, ev1); break; }
+        if (wpe == 6) { launch_inst<1, BT, int16_t, false, false, false, false, 6>(p, lds, grid, stream, ev0, ev1); break; }
+        if (wpe == 4) { launch_inst<1, BT, int16_t, false, false, false, false, 4>(p, lds, grid, stream, ev0, ev1); break; }
       }
-      launch_inst<1, BT, int16_t, false, RAW, false>(p, lds, grid, stream); break;
+      launch_inst<1, BT, int16_t, false, RAW, false>(p, lds, grid, stream, ev0, ev1); break;
     case 1:
-      if constexpr (BT && !RAW) { if (p.dbg_times) { launch_inst<4, true, int16_t, false, false, false, false, 8, true>(p, lds, grid, stream); break; } }
-      launch_inst<4, BT, int16_t, false, RAW, false>(p, lds, grid, stream); break;
-    case 2: launch_inst<16, BT, int16_t, false, RAW, false>(p, lds, grid, stream); break;
+      if constexpr (BT && !RAW) { if (p.dbg_times) { launch_inst<4, true, int16_t, false, false, false, false, 8, true>(p, lds, grid, stream, ev0, ev1); break; } }
+      launch_inst<4, BT, int16_t, false, RAW, false>(p, lds, grid, stream, ev0, ev1); break;
+    case 2: launch_inst<16, BT, int16_t, false, RAW, false>(p, lds, grid, stream, ev0, ev1); break;
     case 4:
-      if constexpr (BT && !RAW) { if (p.dbg_times) { launch_inst<16, true, int16_t, false, false, false, true, 8, true>(p, lds, grid, stream); break; } }
-      if constexpr (!RAW) launch_inst<16, BT, int16_t, false, false, false, true>(p, lds, grid, stream);
+      if constexpr (BT && !RAW) { if (p.dbg_times) { launch_inst<16, true, int16_t, false, false, false, true, 8, true>(p, lds, grid, stream, ev0, ev1); break; } }
+      if constexpr (!RAW) launch_inst<16, BT, int16_t, false, false, false, true>(p, lds, grid, stream, ev0, ev1);
       break;    // hybrid ring
     default:
-      if (p.ring16) launch_inst<16, BT, int16_t, true, RAW, false>(p, lds, grid, stream);
-      else launch_inst<16, BT, int32_t, true, RAW, false>(p, lds, grid, stream);
+      if (p.ring16) launch_inst<16, BT, int16_t, true, RAW, false>(p, lds, grid, stream, ev0, ev1);
+      else launch_inst<16, BT, int32_t, true, RAW, false>(p, lds, grid, stream, ev0, ev1);
       break;
   }
 }
 template <bool BT>
-void launch_tier_banded(const WfaAlignParams& p, int tier, size_t lds, int grid, hipStream_t stream) {
+void launch_tier_banded(const WfaAlignParams& p, int tier, size_t lds, int grid, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
   switch (tier) {
-    case 0: launch_inst<1, BT, int16_t, false, false, true>(p, lds, grid, stream); break;
-    case 1: launch_inst<4, BT, int16_t, false, false, true>(p, lds, grid, stream); break;
-    default: launch_inst<16, BT, int16_t, false, false, true>(p, lds, grid, stream); break;
+    case 0: launch_inst<1, BT, int16_t, false, false, true>(p, lds, grid, stream, ev0, ev1); break;
+    case 1: launch_inst<4, BT, int16_t, false, false, true>(p, lds, grid, stream, ev0, ev1); break;
+    default: launch_inst<16, BT, int16_t, false, false, true>(p, lds, grid, stream, ev0, ev1); break;
   }
 }
 template <bool BT, bool RAW>
@@ -1596,14 +1596,14 @@ size_t wfa_align_lds_bytes(const WfaAlignParams& p, int tier) {
   return ((ring + seq + meta) + 15) & ~(size_t)15;
 }
 
-void wfa_launch_align(const WfaAlignParams& p, int tier, bool with_bt, bool raw, int grid, hipStream_t stream, int wpe) {
+void wfa_launch_align(const WfaAlignParams& p, int tier, bool with_bt, bool raw, int grid, hipStream_t stream, int wpe, hipEvent_t ev0, hipEvent_t ev1) {
   const size_t lds = wfa_align_lds_bytes(p, tier);
   if (p.band_width > 0) {
-    if (with_bt) launch_tier_banded<true>(p, tier, lds, grid, stream); else launch_tier_banded<false>(p, tier, lds, grid, stream);
+    if (with_bt) launch_tier_banded<true>(p, tier, lds, grid, stream, ev0, ev1); else launch_tier_banded<false>(p, tier, lds, grid, stream, ev0, ev1);
     return;
   }
-  if (with_bt) { if (raw) launch_tier<true, true>(p, tier, lds, grid, stream, wpe); else launch_tier<true, false>(p, tier, lds, grid, stream, wpe); }
-  else { if (raw) launch_tier<false, true>(p, tier, lds, grid, stream, wpe); else launch_tier<false, false>(p, tier, lds, grid, stream, wpe); }
+  if (with_bt) { if (raw) launch_tier<true, true>(p, tier, lds, grid, stream, wpe, ev0, ev1); else launch_tier<true, false>(p, tier, lds, grid, stream, wpe, ev0, ev1); }
+  else { if (raw) launch_tier<false, true>(p, tier, lds, grid, stream, wpe, ev0, ev1); else launch_tier<false, false>(p, tier, lds, grid, stream, wpe, ev0, ev1); }
 }
 
 int wfa_align_max_blocks_per_cu(int tier, bool with_bt, bool raw, bool banded, size_t lds, int wpe) {

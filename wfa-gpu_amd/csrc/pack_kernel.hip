@@ -62,15 +62,19 @@ __device__ __forceinline__ uint32_t pack_word(const PackWord& p, uint32_t len, u
 }
 
 // One wavefront per PAIR: the record is read once and the loads of both sequences are in flight together (one wavefront
-// per sequence, with the last, partial word handled by dependent conditional loads, ran at 2.8 TB/s).
+// per sequence, with the last, partial word handled by dependent conditional loads, ran at 2.8 TB/s).  SHORT sequences: a group
+// of L = 32, 16 or 8 lanes per pair, 64 / L pairs per wavefront -- a 150 bp read is ten output words, so with one pair per
+// wavefront five lanes of six sat idle (BASELINE configs[1]: 46.9 -> 16 us per 100k pairs; it was a fifth of the resident step).
+template <int L>
 __global__ void __launch_bounds__(PACK_WAVES * 64)
 wfa_pack_kernel(const char* __restrict__ ascii, const WfaSeqPair* __restrict__ meta,
                 uint32_t n_pairs, uint32_t* __restrict__ packed, uint8_t* __restrict__ flags) {
-  const uint32_t pair = blockIdx.x * PACK_WAVES + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (pair >= n_pairs) return;
-  const WfaSeqPair m = meta[pair];
-  const uint32_t plen = m.pattern_len, tlen = m.text_len;
+  constexpr uint32_t G = 64 / L;
+  const int lane = threadIdx.x & 63, j = lane % L, grp = lane / L;
+  const uint32_t pair = (blockIdx.x * PACK_WAVES + (threadIdx.x >> 6)) * G + (uint32_t)grp;
+  const bool have = pair < n_pairs;       // (whole groups: the ballots below need every lane of the wavefront)
+  const WfaSeqPair m = meta[have ? pair : n_pairs - 1u];
+  const uint32_t plen = have ? m.pattern_len : 0u, tlen = have ? m.text_len : 0u;
   // (an empty sequence may sit at the very end of the buffer: its -- fully masked -- loads go to the record array instead)
   const uint32_t* __restrict__ psrc = plen ? reinterpret_cast<const uint32_t*>(ascii + m.pattern_offset) : reinterpret_cast<const uint32_t*>(meta);
   const uint32_t* __restrict__ tsrc = tlen ? reinterpret_cast<const uint32_t*>(ascii + m.text_offset) : reinterpret_cast<const uint32_t*>(meta);
@@ -78,24 +82,35 @@ wfa_pack_kernel(const char* __restrict__ ascii, const WfaSeqPair* __restrict__ m
   uint32_t* __restrict__ tdst = packed + (m.text_offset_packed >> 2);
   const uint32_t pwords = (plen + 15u) >> 4, twords = (tlen + 15u) >> 4;   // + one spare word each, zeroed
   uint32_t pbad = 0, tbad = 0;
-  for (uint32_t w = lane; w <= max(pwords, twords); w += 64) {
-    const PackWord pw = load_word(psrc, plen, min(w, pwords)), tw = load_word(tsrc, tlen, min(w, twords));
-    const uint32_t po = pack_word(pw, plen, w, pbad), to = pack_word(tw, tlen, w, tbad);
-    if (w <= pwords) pdst[w] = po;
-    if (w <= twords) tdst[w] = to;
+  if (have) {
+    for (uint32_t w = j; w <= max(pwords, twords); w += L) {
+      const PackWord pw = load_word(psrc, plen, min(w, pwords)), tw = load_word(tsrc, tlen, min(w, twords));
+      const uint32_t po = pack_word(pw, plen, w, pbad), to = pack_word(tw, tlen, w, tbad);
+      if (w <= pwords) pdst[w] = po;
+      if (w <= twords) tdst[w] = to;
+    }
   }
-  const unsigned long long any_pbad = __ballot(pbad != 0), any_tbad = __ballot(tbad != 0);
-  if (lane == 0) { flags[2u * pair] = any_pbad ? 1 : 0; flags[2u * pair + 1u] = any_tbad ? 1 : 0; }
+  const unsigned long long grp_mask = (L == 64) ? ~0ull : (((1ull << L) - 1ull) << (grp * L));
+  const unsigned long long any_pbad = __ballot(pbad != 0) & grp_mask, any_tbad = __ballot(tbad != 0) & grp_mask;
+  if (have && j == 0) { flags[2u * pair] = any_pbad ? 1 : 0; flags[2u * pair + 1u] = any_tbad ? 1 : 0; }
 }
 
 }  // namespace
 
+// max_seq_len: the longest sequence of the batch (0: unknown) -- picks the lanes per pair
 void wfa_launch_pack(const char* d_ascii, const WfaSeqPair* d_meta, uint32_t n_pairs,
-                     uint32_t* d_packed, uint8_t* d_flags, hipStream_t stream) {
+                     uint32_t* d_packed, uint8_t* d_flags, hipStream_t stream, uint32_t max_seq_len, hipEvent_t ev0, hipEvent_t ev1) {
   if (n_pairs == 0) return;
-  const uint32_t grid = (n_pairs + PACK_WAVES - 1) / PACK_WAVES;
-  hipLaunchKernelGGL(wfa_pack_kernel, dim3(grid), dim3(PACK_WAVES * 64), 0, stream,
-                     d_ascii, d_meta, n_pairs, d_packed, d_flags);
+  const uint32_t words = max_seq_len ? (max_seq_len + 15u) / 16u + 1u : 1u << 20;
+  const uint32_t lanes = words <= 8u ? 8u : (words <= 16u ? 16u : (words <= 32u ? 32u : 64u));
+  const uint32_t per_block = PACK_WAVES * (64u / lanes);
+  const dim3 grid((n_pairs + per_block - 1) / per_block), block(PACK_WAVES * 64);
+  switch (lanes) {
+    case 8: wfa_launch_timed(wfa_pack_kernel<8>, grid, block, 0, stream, ev0, ev1, d_ascii, d_meta, n_pairs, d_packed, d_flags); break;
+    case 16: wfa_launch_timed(wfa_pack_kernel<16>, grid, block, 0, stream, ev0, ev1, d_ascii, d_meta, n_pairs, d_packed, d_flags); break;
+    case 32: wfa_launch_timed(wfa_pack_kernel<32>, grid, block, 0, stream, ev0, ev1, d_ascii, d_meta, n_pairs, d_packed, d_flags); break;
+    default: wfa_launch_timed(wfa_pack_kernel<64>, grid, block, 0, stream, ev0, ev1, d_ascii, d_meta, n_pairs, d_packed, d_flags); break;
+  }
 }
 
 // Loads this translation unit's code object on the current device (the runtime loads a code object at the first launch of

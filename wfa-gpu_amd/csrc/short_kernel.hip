@@ -321,9 +321,9 @@ __global__ void __launch_bounds__(64) wfa_short_kernel(const WfaAlignParams p) {
 }
 
 template <int L, int X, int OE, bool BT>
-void launch_short(const WfaAlignParams& p, int grid, hipStream_t stream) {
+void launch_short(const WfaAlignParams& p, int grid, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
   const size_t lds = wfa_short_lds_bytes(p, L, BT);
-  hipLaunchKernelGGL((wfa_short_kernel<L, X, OE, BT>), dim3(grid), dim3(64), lds, stream, p);
+  wfa_launch_timed(wfa_short_kernel<L, X, OE, BT>, dim3(grid), dim3(64), lds, stream, ev0, ev1, p);
 }
 
 // wavefronts of this instantiation a CU holds (registers and LDS)
@@ -335,7 +335,7 @@ int occ_short(size_t lds) {
 }
 
 // [x - 1][oe - 1], one table per group width and mode
-struct ShortEntry { void (*launch)(const WfaAlignParams&, int, hipStream_t); int (*occ)(size_t); };
+struct ShortEntry { void (*launch)(const WfaAlignParams&, int, hipStream_t, hipEvent_t, hipEvent_t); int (*occ)(size_t); };
 template <int L, bool BT, int I> constexpr ShortEntry short_entry() { return {&launch_short<L, I / 8 + 1, I % 8 + 1, BT>, &occ_short<L, I / 8 + 1, I % 8 + 1, BT>}; }
 template <int L, bool BT, int... Is> constexpr std::array<ShortEntry, 64> short_table(std::integer_sequence<int, Is...>) { return {short_entry<L, BT, Is>()...}; }
 const std::array<ShortEntry, 64> g_short16 = short_table<16, false>(std::make_integer_sequence<int, 64>{});
@@ -362,7 +362,9 @@ size_t wfa_short_lds_bytes(const WfaAlignParams& p, int lanes, bool with_bt) {
   return seq + (with_bt ? (size_t)64 * (size_t)(p.max_score + 1) : 0);
 }
 
-void wfa_launch_short(const WfaAlignParams& p, int lanes, bool with_bt, int grid, hipStream_t stream) { short_pick(p, lanes, with_bt).launch(p, grid, stream); }
+void wfa_launch_short(const WfaAlignParams& p, int lanes, bool with_bt, int grid, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+  short_pick(p, lanes, with_bt).launch(p, grid, stream, ev0, ev1);
+}
 
 int wfa_short_max_blocks_per_cu(const WfaAlignParams& p, int lanes, bool with_bt) { return short_pick(p, lanes, with_bt).occ(wfa_short_lds_bytes(p, lanes, with_bt)); }
 

@@ -764,50 +764,67 @@ __global__ void __launch_bounds__(TRACE_THREADS) wfa_trace_group_kernel(const Wf
   }
 }
 
+// The opt-in for dynamic LDS beyond 64 KiB is sticky per kernel and device: one driver call when the request grows.
+template <typename K>
+void allow_lds(K kernel, size_t lds, size_t (&allowed)[16]) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (lds > allowed[dev & 15]) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    allowed[dev & 15] = lds;
+  }
+}
+
 template <bool RAW, int G>
-void launch_group(const WfaTraceParams& p, hipStream_t stream) {
+void launch_group(const WfaTraceParams& p, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
   const size_t share = ((size_t)2 * p.seq_words_cap * 4 + (size_t)(64 / G) * 16 + (size_t)p.ops_lds_bytes + (size_t)p.text_lds_bytes + 15) / 16 * 16;
   const size_t lds = share * G;
   const uint32_t blocks = (p.n_work + G - 1) / G;
   const uint32_t grid = blocks < 8192u ? blocks : 8192u;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wfa_trace_group_kernel<RAW, G>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((wfa_trace_group_kernel<RAW, G>), dim3(grid), dim3(TRACE_THREADS), lds, stream, p);
+  static thread_local size_t allowed[16] = {0};
+  allow_lds(wfa_trace_group_kernel<RAW, G>, lds, allowed);
+  wfa_launch_timed(wfa_trace_group_kernel<RAW, G>, dim3(grid), dim3(TRACE_THREADS), lds, stream, ev0, ev1, p);
+}
+
+template <bool RAW>
+void launch_wave(const WfaTraceParams& p, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+  const size_t lds = (size_t)2 * p.seq_words_cap * 4 + 64 * 16 + (size_t)p.ops_lds_bytes + (size_t)p.text_lds_bytes;
+  const uint32_t grid = p.n_work < 8192u ? p.n_work : 8192u;
+  static thread_local size_t allowed[16] = {0};
+  allow_lds(wfa_trace_wave_kernel<RAW>, lds, allowed);
+  wfa_launch_timed(wfa_trace_wave_kernel<RAW>, dim3(grid), dim3(TRACE_THREADS), lds, stream, ev0, ev1, p);
 }
 
 }  // namespace
 
-void wfa_launch_trace(const WfaTraceParams& p, hipStream_t stream) {
-  if (p.n_work == 0) return;
+// ev0 / ev1: receive the start of the first and the end of the last kernel launched here (a call that launches nothing --
+// n_work == 0 -- leaves them alone: returns false)
+bool wfa_launch_trace(const WfaTraceParams& p, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+  if (p.n_work == 0) return false;
   if (p.wave_kernel && p.group > 1) {
     switch (p.group) {
-      case 8: if (p.raw) launch_group<true, 8>(p, stream); else launch_group<false, 8>(p, stream); break;
-      case 4: if (p.raw) launch_group<true, 4>(p, stream); else launch_group<false, 4>(p, stream); break;
-      default: if (p.raw) launch_group<true, 2>(p, stream); else launch_group<false, 2>(p, stream); break;
+      case 8: if (p.raw) launch_group<true, 8>(p, stream, ev0, ev1); else launch_group<false, 8>(p, stream, ev0, ev1); break;
+      case 4: if (p.raw) launch_group<true, 4>(p, stream, ev0, ev1); else launch_group<false, 4>(p, stream, ev0, ev1); break;
+      default: if (p.raw) launch_group<true, 2>(p, stream, ev0, ev1); else launch_group<false, 2>(p, stream, ev0, ev1); break;
     }
-    return;
+    return true;
   }
   if (p.wave_kernel) {
-    const size_t lds = (size_t)2 * p.seq_words_cap * 4 + 64 * 16 + (size_t)p.ops_lds_bytes + (size_t)p.text_lds_bytes;
-    const uint32_t grid = p.n_work < 8192u ? p.n_work : 8192u;
-    if (p.raw) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wfa_trace_wave_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(wfa_trace_wave_kernel<true>, dim3(grid), dim3(TRACE_THREADS), lds, stream, p);
-    } else {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wfa_trace_wave_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(wfa_trace_wave_kernel<false>, dim3(grid), dim3(TRACE_THREADS), lds, stream, p);
-    }
-    return;
+    if (p.raw) launch_wave<true>(p, stream, ev0, ev1); else launch_wave<false>(p, stream, ev0, ev1);
+    return true;
   }
-  const uint32_t grid = (p.n_work + TRACE_THREADS - 1) / TRACE_THREADS;
-  hipLaunchKernelGGL(wfa_walk_kernel, dim3(grid), dim3(TRACE_THREADS), 0, stream, p);
+  const dim3 grid((p.n_work + TRACE_THREADS - 1) / TRACE_THREADS), block(TRACE_THREADS);
+  wfa_launch_timed(wfa_walk_kernel, grid, block, 0, stream, ev0, (hipEvent_t) nullptr, p);
   if (p.seq_lds_stride == 0) {      // (sequences too long to stage 64 pairs, or tuning.trace_mode 1: 8-word LDS windows)
-    hipLaunchKernelGGL(wfa_emit_win_kernel, dim3(grid), dim3(TRACE_THREADS), 0, stream, p);
-    return;
+    wfa_launch_timed(wfa_emit_win_kernel, grid, block, 0, stream, (hipEvent_t) nullptr, ev1, p);
+    return true;
   }
   const size_t lds = (size_t)64 * p.seq_lds_stride * 4;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wfa_emit_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(wfa_emit_kernel<true>, dim3(grid), dim3(TRACE_THREADS), lds, stream, p);
-  if (p.text_scratch) hipLaunchKernelGGL(wfa_text_compact_kernel, dim3(grid), dim3(TRACE_THREADS), 0, stream, p);
+  static thread_local size_t allowed[16] = {0};
+  allow_lds(wfa_emit_kernel<true>, lds, allowed);
+  wfa_launch_timed(wfa_emit_kernel<true>, grid, block, lds, stream, (hipEvent_t) nullptr, p.text_scratch ? (hipEvent_t) nullptr : ev1, p);
+  if (p.text_scratch) wfa_launch_timed(wfa_text_compact_kernel, grid, block, 0, stream, (hipEvent_t) nullptr, ev1, p);
+  return true;
 }
 
 // Loads this translation unit's code object on the current device (the runtime loads a code object at the first launch of

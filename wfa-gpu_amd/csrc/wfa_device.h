@@ -13,6 +13,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 // Mirror of the reference ABI struct sequence_pair_t (utils/sequences.h:28-36).
@@ -134,20 +135,33 @@ struct WfaTraceParams {
 };
 
 // Host-side launchers (one per translation unit).
+// Timed launches.  hipEventRecord puts a barrier packet of its own into the queue, and a kernel behind one starts ~5.5 us after the
+// kernel in front of it has finished (back to back: 0.2 us): nine records per call were 35 of the 250 us of a BASELINE configs[1]
+// step.  hipExtLaunchKernelGGL lets the kernel's own dispatch packet carry the time stamps: ev0 becomes the start of the kernel,
+// ev1 its end (either may be null; hipEventElapsedTime pairs them freely, also with recorded events: scratch/ext_event_probe.hip).
+template <typename K, typename... Args>
+inline void wfa_launch_timed(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, Args... args) {
+  if (ev0 || ev1) hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, stream, ev0, ev1, 0, args...);
+  else hipLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, stream, args...);
+}
+
+// (ev0 / ev1 of every launcher: events that receive the start of the first and the end of the last kernel it launches)
 void wfa_launch_pack(const char* d_ascii, const WfaSeqPair* d_meta, uint32_t n_pairs,
-                     uint32_t* d_packed, uint8_t* d_flags, hipStream_t stream);
+                     uint32_t* d_packed, uint8_t* d_flags, hipStream_t stream, uint32_t max_seq_len = 0,
+                     hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 // tier: 0 -> 1 wave/alignment (LDS ring), 1 -> 4 waves (LDS), 2 -> 16 waves (LDS), 4 -> 16 waves, M and I rings in LDS + D ring in HBM,
 //       3 -> 16 waves, ring in HBM (int16 or int32 offsets, WfaAlignParams::ring16).  Returns the dynamic LDS bytes used.
 size_t wfa_align_lds_bytes(const WfaAlignParams& p, int tier);
 // wpe: waves per SIMD the one-wave exact kernels (tier 0, packed class) are compiled for: 8, 7, 6 or 4 (others: 8).
-void wfa_launch_align(const WfaAlignParams& p, int tier, bool with_bt, bool raw, int grid, hipStream_t stream, int wpe = 8);
+void wfa_launch_align(const WfaAlignParams& p, int tier, bool with_bt, bool raw, int grid, hipStream_t stream, int wpe = 8,
+                      hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 int wfa_align_max_blocks_per_cu(int tier, bool with_bt, bool raw, bool banded, size_t lds_bytes, int wpe = 8);
-void wfa_launch_trace(const WfaTraceParams& p, hipStream_t stream);
+bool wfa_launch_trace(const WfaTraceParams& p, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);     // false: nothing to launch
 // Tier 5 (short_kernel.hip): 64 / lanes alignments per wavefront (lanes = 16 or 32 diagonals each), rings in registers; with_bt: one row
 // of `lanes` origin bytes per score for the backtrace.
 bool wfa_short_supported(int x, int oe, int e);
 size_t wfa_short_lds_bytes(const WfaAlignParams& p, int lanes, bool with_bt);
-void wfa_launch_short(const WfaAlignParams& p, int lanes, bool with_bt, int grid, hipStream_t stream);
+void wfa_launch_short(const WfaAlignParams& p, int lanes, bool with_bt, int grid, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 int wfa_short_max_blocks_per_cu(const WfaAlignParams& p, int lanes, bool with_bt);     // (wavefronts a CU holds: registers and LDS)
 unsigned long long wfa_short_bt_slot_units(int max_score, int lanes);     // (with_bt: arena units every work item of the launch owns)
 // Code-object priming: one empty launch per kernel translation unit (see the definitions).

@@ -155,11 +155,13 @@ __global__ void k_flag_alphabet(const uint8_t* __restrict__ flags, uint32_t n, u
 }
 
 // bounds for the trace scratch: sum over finished pairs of the op-list and
-// text sizes; also the total of computed cells.  Grid-stride, one atomic triple per block.
+// text sizes; also the total of computed cells and the largest score.  Grid-stride, FOUR atomics per block, few blocks: the
+// counters share one cache line and an atomic on it costs ~11 ns whoever issues it (one atomicMax per wavefront + three adds per
+// block of a 391-block grid: 22 of the 250 microseconds of a BASELINE configs[1] step).
 __global__ void __launch_bounds__(256) k_trace_bounds(const uint32_t* __restrict__ work, uint32_t n, const uint32_t* __restrict__ status,
                                const int32_t* __restrict__ score, const uint32_t* __restrict__ cells, int min_op_cost, int item_chars,
                                unsigned long long* __restrict__ ct) {
-  __shared__ unsigned long long part[3][4];
+  __shared__ unsigned long long part[4][4];
   unsigned long long ops = 0, txt = 0, cl = 0;
   uint32_t smax = 0;
   for (uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x; gid < n; gid += gridDim.x * blockDim.x) {
@@ -179,14 +181,15 @@ __global__ void __launch_bounds__(256) k_trace_bounds(const uint32_t* __restrict
     cl += __shfl_down((unsigned long long)cl, d);
     smax = max(smax, (uint32_t)__shfl_down((int)smax, d));
   }
-  if ((threadIdx.x & 63) == 0 && smax) atomicMax(&ct[CT_MAX_SCORE], (unsigned long long)smax);
   const int wv = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) { part[0][wv] = ops; part[1][wv] = txt; part[2][wv] = cl; }
+  if ((threadIdx.x & 63) == 0) { part[0][wv] = ops; part[1][wv] = txt; part[2][wv] = cl; part[3][wv] = smax; }
   __syncthreads();
   if (threadIdx.x == 0) {
     ops = part[0][0] + part[0][1] + part[0][2] + part[0][3];
     txt = part[1][0] + part[1][1] + part[1][2] + part[1][3];
     cl = part[2][0] + part[2][1] + part[2][2] + part[2][3];
+    const unsigned long long sm = max(max(part[3][0], part[3][1]), max(part[3][2], part[3][3]));
+    if (sm) atomicMax(&ct[CT_MAX_SCORE], sm);
     if (ops) atomicAdd(&ct[CT_SUM_OPS], ops);
     if (txt) atomicAdd(&ct[CT_SUM_TEXT], txt);
     if (cl) atomicAdd(&ct[CT_CELLS], cl);
@@ -364,7 +367,7 @@ int wfagpu_amd_pack_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_batch_t* b, voi
   if (!c || !b || !d_packed || !d_flags) return -1;
   HIP_TRY(hipSetDevice(c->device));
   wfa_launch_pack(b->d_sequences, reinterpret_cast<const WfaSeqPair*>(b->d_metadata), (uint32_t)b->num_pairs,
-                  static_cast<uint32_t*>(d_packed), d_flags, c->stream);
+                  static_cast<uint32_t*>(d_packed), d_flags, c->stream, b->max_seq_len);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;
@@ -656,11 +659,11 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   c->ct_used = 0;
   HIP_TRY(hipEventRecord(c->ev_start, st));
   if (!prepacked) {
-    wfa_launch_pack(b->d_sequences, ap.meta, n, static_cast<uint32_t*>(c->packed.p), static_cast<uint8_t*>(c->flags.p), st);
+    // (ev_pack: the end of the pack kernel, stamped by its own dispatch packet -- wfa_launch_timed, wfa_device.h)
+    wfa_launch_pack(b->d_sequences, ap.meta, n, static_cast<uint32_t*>(c->packed.p), static_cast<uint8_t*>(c->flags.p), st, b->max_seq_len, nullptr, c->ev_pack);
     LAUNCH_K(k_flag_alphabet, dim3(cdiv(n, 256)), dim3(256), 0, st, static_cast<const uint8_t*>(c->flags.p), n,
                        static_cast<uint32_t*>(c->status.p), ct + CT_NRAW);
   }
-  HIP_TRY(hipEventRecord(c->ev_pack, st));
 
   float align_ms = 0.f, trace_ms = 0.f;
   uint32_t grid_cap = UINT32_MAX;   // lowered when a pass makes no progress for lack of arena
@@ -778,15 +781,14 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         if (cigar_now) ap.chunk_units = (uint32_t)std::min<unsigned long long>(4096u, std::max<unsigned long long>(256, ap.arena_units / (4ull * (unsigned)grid)));
         ap.work_shards = 8u;
         if (zero_counter(c, L.ct_cells, 2)) return -1;   // (the launch's cell count and, next to it, the length of its failure list)
-        HIP_TRY(hipEventRecord(L.e0, st));
+        // (L.e0 / L.e1: start and end of the wavefront kernel, stamped by its own dispatch packet)
         if (tp.tier == 5) {
-          wfa_launch_short(ap, tp.wpe, cigar_now, grid, st);
+          wfa_launch_short(ap, tp.wpe, cigar_now, grid, st, L.e0, L.e1);
           // (with CIGARs the launch owns n_cur slots above the bump pointer: move it past them for whatever allocates next)
           if (cigar_now) LAUNCH_K(k_bump, dim3(1), dim3(64), 0, st, ap.arena_top, (unsigned long long)n_cur * wfa_short_bt_slot_units(ap.max_score, tp.wpe), ap.arena_units);
         }
-        else wfa_launch_align(ap, tp.tier, cigar_now, raw, grid, st, tp.wpe);
+        else wfa_launch_align(ap, tp.tier, cigar_now, raw, grid, st, tp.wpe, L.e0, L.e1);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(L.e1, st));
         uint32_t* nxt = spare[flip]; flip ^= 1;
         LAUNCH_K(k_compact, dim3(cdiv(n_cur, compact_block(n_cur))), dim3(compact_block(n_cur)), 0, st, (const uint32_t*)cur, n_cur, cur_len_dev,
                            static_cast<const uint32_t*>(c->status.p), MASK(WFA_ST_BAND) | MASK(WFA_ST_SCORE), nxt, ct + L.ct_list, ap.work_counter);
@@ -814,7 +816,8 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       if (zero_counter(c, CT_SUM_OPS, 2)) return -1;
       if (zero_counter(c, CT_OPS)) return -1;
       if (zero_counter(c, CT_MAX_SCORE)) return -1;
-      LAUNCH_K(k_trace_bounds, dim3(std::min<uint32_t>(cdiv(n_chain, 256), 1024u)), dim3(256), 0, st, (const uint32_t*)chain_list, n_chain,
+      bool traced = false;      // (did the backtrace launch anything: are ev_t0 / ev_t1 this chain's)
+      LAUNCH_K(k_trace_bounds, dim3(std::min<uint32_t>(cdiv(n_chain, 2048), 256u)), dim3(256), 0, st, (const uint32_t*)chain_list, n_chain,
                          static_cast<const uint32_t*>(c->status.p), (const int32_t*)d_scores,
                          static_cast<const uint32_t*>(c->cells.p), std::min(pen.x, pen.e), item_chars, ct);
       if (cigar_now) {
@@ -885,10 +888,9 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         }
         tp.cigar_off = static_cast<unsigned long long*>(c->cig_off[c->out_set].p);
         tp.cigar_len = static_cast<uint32_t*>(c->cig_len[c->out_set].p);
-        HIP_TRY(hipEventRecord(c->ev_t0, st));
-        wfa_launch_trace(tp, st);
+        // (ev_t0 / ev_t1: start of the first and end of the last backtrace kernel)
+        traced = wfa_launch_trace(tp, st, c->ev_t0, c->ev_t1);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(c->ev_t1, st));
         // ---- pairs that ran out of arena go into the next pass (CIGAR calls only: score-only calls have no arena) ----
         LAUNCH_K(k_compact, dim3(cdiv(n_chain, compact_block(n_chain))), dim3(compact_block(n_chain)), 0, st, (const uint32_t*)chain_list, n_chain, (const unsigned long long*)nullptr,
                            static_cast<const uint32_t*>(c->status.p), MASK(WFA_ST_NOMEM), nxt_pending, ct + CT_NOMEM);
@@ -924,7 +926,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       }
       if (cigar_now) {
         float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1));
+        if (traced) HIP_TRY(hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1));
         trace_ms += ms;
         text_used = c->h_counters[CT_TEXT];
       }
@@ -1167,7 +1169,8 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   }
   c->stats.cells = c->h_counters[CT_CELLS] - sample_cells_call;
   float ms = 0.f;
-  HIP_TRY(hipEventElapsedTime(&ms, c->ev_start, c->ev_pack)); c->stats.pack_ms = ms;
+  if (!prepacked) HIP_TRY(hipEventElapsedTime(&ms, c->ev_start, c->ev_pack));
+  c->stats.pack_ms = ms;
   HIP_TRY(hipEventElapsedTime(&ms, c->ev_start, c->ev_end)); c->stats.total_ms = ms;
   // several arena-bound passes under a growable cap: the next call may use twice the arena
   if (compute_cigar && c->arena_limit && c->arena_limit_max > c->arena_limit && c->stats.sub_batches > 1 &&

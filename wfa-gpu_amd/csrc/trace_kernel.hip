@@ -327,9 +327,13 @@ template <bool SEQ_LDS>
 __global__ void __launch_bounds__(TRACE_THREADS) wfa_emit_kernel(const WfaTraceParams p) {
   static_assert(SEQ_LDS, "sequences that do not fit LDS go through wfa_emit_win_kernel or wfa_trace_wave_kernel");
   extern __shared__ __attribute__((aligned(16))) uint32_t seq_lds[];
-  const uint32_t gid = blockIdx.x * TRACE_THREADS + threadIdx.x;
+  // (the first PPW lanes of the wavefront carry an alignment each: staging 64 pairs of 1 kbp reads takes 33 KB of LDS, four
+  // wavefronts per CU -- one per SIMD, every dependent LDS read of the replay fully exposed; fewer pairs per wavefront, more
+  // wavefronts and more lanes per CU)
+  const int PPW = p.emit_pairs;
   const int lane = threadIdx.x & 63;
-  bool active = gid < p.n_work;
+  const uint32_t gid = blockIdx.x * (uint32_t)PPW + (uint32_t)lane;
+  bool active = lane < PPW && gid < p.n_work;
   uint32_t pair = 0;
   if (active) pair = p.work ? p.work[gid] : gid;
   if (active && p.status[pair] != WFA_ST_DONE) active = false;
@@ -354,7 +358,7 @@ __global__ void __launch_bounds__(TRACE_THREADS) wfa_emit_kernel(const WfaTraceP
     // Eight pairs at a time: all sixteen loads of a round are issued before the first LDS store (one pair per
     // iteration waited a full memory round trip per load: 128 of them in a row, half of this kernel's time).
     constexpr int SG = 8;
-    for (int j0 = 0; j0 < 64; j0 += SG) {
+    for (int j0 = 0; j0 < PPW; j0 += SG) {      // (PPW is a multiple of SG)
       const uint32_t* gp[SG]; const uint32_t* gt[SG]; int pwj[SG], twj[SG];
       int maxw = 0;
 #pragma unroll
@@ -819,10 +823,11 @@ bool wfa_launch_trace(const WfaTraceParams& p, hipStream_t stream, hipEvent_t ev
     wfa_launch_timed(wfa_emit_win_kernel, grid, block, 0, stream, (hipEvent_t) nullptr, ev1, p);
     return true;
   }
-  const size_t lds = (size_t)64 * p.seq_lds_stride * 4;
+  const size_t lds = (size_t)p.emit_pairs * p.seq_lds_stride * 4;
   static thread_local size_t allowed[16] = {0};
   allow_lds(wfa_emit_kernel<true>, lds, allowed);
-  wfa_launch_timed(wfa_emit_kernel<true>, grid, block, lds, stream, (hipEvent_t) nullptr, p.text_scratch ? (hipEvent_t) nullptr : ev1, p);
+  const dim3 grid_e((p.n_work + (uint32_t)p.emit_pairs - 1) / (uint32_t)p.emit_pairs);
+  wfa_launch_timed(wfa_emit_kernel<true>, grid_e, block, lds, stream, (hipEvent_t) nullptr, p.text_scratch ? (hipEvent_t) nullptr : ev1, p);
   if (p.text_scratch) wfa_launch_timed(wfa_text_compact_kernel, grid, block, 0, stream, (hipEvent_t) nullptr, ev1, p);
   return true;
 }

@@ -99,6 +99,7 @@ struct WfaAlignParams {
 struct WfaTraceParams {
   int raw;                       // 1: sequences are the ASCII buffer (byte compare), 0: 2-bit packed
   int seq_lds_stride;            // > 0: stage each lane's pair in LDS, this many (odd) words per lane
+  int emit_pairs;                //      ... of the first emit_pairs lanes of a wavefront (the others idle: LDS per wavefront buys occupancy)
   const uint32_t* packed;
   const WfaSeqPair* meta;
   const uint32_t* work;          // pair indices (NULL: identity)

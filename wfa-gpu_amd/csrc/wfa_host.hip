@@ -827,6 +827,15 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         const unsigned per_seq = raw ? (max_len + 3) / 4 + 1 : (max_len + 15) / 16 + 1;
         const unsigned stride = (2 * per_seq) | 1u;
         tp.seq_lds_stride = ((size_t)64 * stride * 4 <= (48u << 10) && c->tuning.trace_mode != 1) ? (int)stride : 0;
+        // alignments per wavefront of the staged replay: as many as still leave a CU eight wavefronts (two per SIMD).  LDS decides:
+        // 1 kbp reads at 64 per wavefront are 4 wavefronts per CU, one per SIMD, every dependent LDS read of the replay exposed;
+        // measured on BASELINE configs[2] (trace ms per 1M pairs): 64: 4.14, 56: 3.92, 48: 3.84, 40: 3.84, 32: 3.79, 24: 3.82
+        tp.emit_pairs = 64;
+        if (tp.seq_lds_stride > 0) {
+          while (tp.emit_pairs > 16 && c->lds_per_block_max / ((size_t)tp.emit_pairs * stride * 4) < 8) tp.emit_pairs -= 8;
+          const int forced = c->tuning.emit_pairs;
+          if (forced >= 8 && forced <= 64) tp.emit_pairs = forced & ~7;
+        }
         // sequences too long to stage 64 pairs per wavefront: one wavefront per alignment (sequences of ONE pair in LDS)
         tp.seq_words_cap = (int)per_seq + 1;
         // (it needs both sequences of a pair plus ~1 KiB in LDS; sequences at the very edge of what the align tiers stage do

@@ -25,13 +25,16 @@ def _run(aligner, buf, meta, pen, max_error, cigar=True):
     return aligner.align(batch, pen, max_error=max_error, compute_cigar=cigar)
 
 
-def test_pack_literals_and_random(aligner):
+@pytest.mark.parametrize("max_len", [60, 110, 240, 300, 500, 1500])
+def test_pack_literals_and_random(aligner, max_len):
     """tests/test_packing_kernel.cu of the reference: literal pairs + bit layout; here every 2-bit field is
-    compared with the oracle's packer (little-endian word layout of this build)."""
+    compared with the oracle's packer (little-endian word layout of this build).  The longest sequence of the batch picks
+    the lanes a pair gets in the pack kernel (8, 16, 32 or 64: 8, 4, 2 or 1 pairs per wavefront): every width, with pair counts
+    that leave the last wavefront partly empty."""
     import ctypes as C
-    rng = random.Random(5)
+    rng = random.Random(5 + max_len)
     pairs = [(b"GATTACA", b"GATACA"), (b"ACGT" * 9, b"ACGT" * 9 + b"A"), (b"T" * 33, b"C" * 16), (b"A", b"G")]
-    pairs += _rand_pairs(rng, 200, 300) + [(b"ACGNACGT", b"acgt"), (b"", b"A")]
+    pairs += _rand_pairs(rng, 201, max_len) + [(b"ACGNACGT", b"acgt"), (b"", b"A"), (b"", b""), (b"C" * (max_len - 1), b"")]
     buf, meta = wfagpu.layout_pairs(pairs)
     batch = aligner.upload(buf, meta)
     packed, flags = aligner.pack(batch)

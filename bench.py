@@ -86,7 +86,7 @@ def _pmc_main_launch(workload, counters, optional=()):
     tag = [ln for ln in lines if ln.startswith("#") and "kernel_sha1=" in ln]
     stale = (not tag) or (tag[0].split("kernel_sha1=")[1].split()[0] != kernel_source_hash())
     rows = [r for r in csv.DictReader(ln for ln in lines if not ln.startswith("#"))
-            if "wfa_align_kernel" in r["kernel"] or "wfa_short_score_kernel" in r["kernel"]]
+            if "wfa_align_kernel" in r["kernel"] or "wfa_short_kernel" in r["kernel"] or "wfa_short_score_kernel" in r["kernel"]]
     out = {}
     for c in counters:
         vals = [float(r["value"]) for r in rows if r["counter"] == c]
@@ -227,7 +227,7 @@ def self_spawn(args):
 
 
 def build_roofline(workload, st, main_ms, launches_per_step, all_ms, compute_cigar, use_pmc):
-    """`roofline` of the dominant kernel (wfa_align_kernel / wfa_short_score_kernel), MAIN launch of a step.  Flat on
+    """`roofline` of the dominant kernel (wfa_align_kernel / wfa_short_kernel), MAIN launch of a step.  Flat on
     purpose (scalars only).  What binds these kernels is vector instruction issue, so `frac` is the VALU-busy fraction:
     SQ_ACTIVE_INST_VALU (quad-cycles the vector pipe spent on instructions, summed over the chip) of the committed PMC pass
     of this same command, x 4 cycles / 1024 SIMDs, over the LIVE launch duration at the clock the PMC pass ran at.  The HBM
@@ -247,7 +247,7 @@ def build_roofline(workload, st, main_ms, launches_per_step, all_ms, compute_cig
     # HBM bytes of the main launch: (FETCH_SIZE*2 + WRITE_SIZE) KB -- FETCH_SIZE counts half of a wide coalesced read on
     # gfx950 (MI355X_MICROARCH.md, HBM section)
     traffic = int((2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024) if pmc else None
-    r = {"kernel": "wfa_short_score_kernel (main launch of a step)" if int(st.main_launch_tier) == 5 else "wfa_align_kernel (main launch of a step)",
+    r = {"kernel": "wfa_short_kernel (main launch of a step)" if int(st.main_launch_tier) == 5 else "wfa_align_kernel (main launch of a step)",
          "kernel_ms": round(main_ms, 4), "tier": int(st.main_launch_tier), "pairs_per_launch": pairs, "cells_per_launch": cells,
          "cells_per_s": round(cells / secs, 1) if secs > 0 else None,
          "launches_per_step": launches_per_step, "all_launches_ms_per_step": round(all_ms, 4), "cells_per_step": int(st.cells),

@@ -72,9 +72,10 @@ def algorithmic_bytes(seq_bytes, pairs, cells, compute_cigar):
     return int(seq_bytes + 68 * pairs + (6 * cells if compute_cigar else 0))
 
 
-def _pmc_main_launch(workload, counters, optional=()):
-    """Counters of the MAIN launch (largest WRITE_SIZE+FETCH_SIZE) of wfa_align_kernel from the newest committed rocprofv3
-    PMC summary of this same command (profiles/rNN/<workload>_pmc_counters.csv; separate --pmc passes over one step).
+def _pmc_main_launch(workload, counters, optional=(), tier=None):
+    """Counters of the MAIN launch of a step -- the wavefront kernel of `tier` (5: wfa_short_kernel, else wfa_align_kernel), its
+    largest value per counter: the launch over the whole batch, not the sample's or a re-run's -- from the newest committed
+    rocprofv3 PMC summary of this same command (profiles/rNN/<workload>_pmc_counters.csv; separate --pmc passes over one step).
     Returns (values, source, stale) -- stale when the summary was taken with other kernel sources than the ones here."""
     import csv
     import glob
@@ -85,8 +86,9 @@ def _pmc_main_launch(workload, counters, optional=()):
     lines = open(src).read().splitlines()
     tag = [ln for ln in lines if ln.startswith("#") and "kernel_sha1=" in ln]
     stale = (not tag) or (tag[0].split("kernel_sha1=")[1].split()[0] != kernel_source_hash())
-    rows = [r for r in csv.DictReader(ln for ln in lines if not ln.startswith("#"))
-            if "wfa_align_kernel" in r["kernel"] or "wfa_short_kernel" in r["kernel"] or "wfa_short_score_kernel" in r["kernel"]]
+    names = ("wfa_short_kernel", "wfa_short_score_kernel") if tier == 5 else \
+            ("wfa_align_kernel",) if tier is not None else ("wfa_align_kernel", "wfa_short_kernel", "wfa_short_score_kernel")
+    rows = [r for r in csv.DictReader(ln for ln in lines if not ln.startswith("#")) if any(nm in r["kernel"] for nm in names)]
     out = {}
     for c in counters:
         vals = [float(r["value"]) for r in rows if r["counter"] == c]
@@ -242,8 +244,8 @@ def build_roofline(workload, st, main_ms, launches_per_step, all_ms, compute_cig
     secs = main_ms * 1e-3
     hw = ["SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_LDS", "GRBM_GUI_ACTIVE", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES",
           "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS"]
-    pmc, pmc_src, pmc_stale = _pmc_main_launch(workload, ["FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_INSTS_SALU"] + hw, optional=hw) \
-        if use_pmc else (None, None, None)
+    pmc, pmc_src, pmc_stale = _pmc_main_launch(workload, ["FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_INSTS_SALU"] + hw, optional=hw,
+                                               tier=int(st.main_launch_tier)) if use_pmc else (None, None, None)
     # HBM bytes of the main launch: (FETCH_SIZE*2 + WRITE_SIZE) KB -- FETCH_SIZE counts half of a wide coalesced read on
     # gfx950 (MI355X_MICROARCH.md, HBM section)
     traffic = int((2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024) if pmc else None

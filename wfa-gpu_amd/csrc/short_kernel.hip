@@ -196,6 +196,13 @@ __global__ void __launch_bounds__(64) wfa_short_kernel(const WfaAlignParams p) {
     }
     const bool run = active && status == WFA_ST_DONE;
     const int k = wlo + j;                                  // this lane's diagonal, for the whole alignment
+    // An offset on diagonal k is inside the matrix -- !(h > tlen || v > plen), h >= 0, v = h - k >= 0: wavefront_compute_affine.c:45-87
+    // -- iff max(0, k) <= h <= min(tlen, plen + k): ONE unsigned compare against per-lane constants.  (Two compares and an
+    // s_and_b64 left the select behind them with a mask no vector instruction in flight had written: a v_cndmask_b32 that
+    // issues once per 23 cycles on this chip instead of 4 -- profiles/r04/valu_classes.txt.)
+    const int h_hi = min(tlen, plen + k);
+    const int h_lo = h_hi >= max(0, k) ? max(0, k) : INT_MAX / 2;      // (a diagonal that misses the matrix: nothing is inside)
+    const uint32_t h_span = (uint32_t)max(h_hi - h_lo, 0);
     __builtin_amdgcn_wave_barrier();                        // (one wavefront: LDS operations execute in order)
 
     // run length from (v, h) on this lane's diagonal, 16 bases per step, wave-uniform continuation
@@ -249,8 +256,8 @@ __global__ void __launch_bounds__(64) wfa_short_kernel(const WfaAlignParams p) {
       const int del = max(m_or, d_e);
       const int mis = m_x + 1;
       // !(h > tlen || v > plen), unsigned so that NULLs fail too (wavefront_compute_affine.c:45-87)
-      const bool i_ok = ((unsigned)ins <= (unsigned)tlen) & ((unsigned)(ins - k) <= (unsigned)plen);
-      const bool d_ok = ((unsigned)del <= (unsigned)tlen) & ((unsigned)(del - k) <= (unsigned)plen);
+      const bool i_ok = (uint32_t)(ins - h_lo) <= h_span;
+      const bool d_ok = (uint32_t)(del - h_lo) <= h_span;
       i1 = i_ok ? ins : S_NULL;
       d1 = d_ok ? del : S_NULL;
       const int mv = max(max(d1, i1), mis);
@@ -263,7 +270,7 @@ __global__ void __launch_bounds__(64) wfa_short_kernel(const WfaAlignParams p) {
           lrows[s * L] = (uint8_t)code;
         }
       }
-      const bool ok = !fin & ((unsigned)mv <= (unsigned)tlen) & ((unsigned)(mv - k) <= (unsigned)plen);
+      const bool ok = !fin & ((uint32_t)(mv - h_lo) <= h_span);
       const int h = extend(mv, ok);
       m_out = ok ? h : S_NULL;
       const bool hit = ok && k == kend && h >= tlen;

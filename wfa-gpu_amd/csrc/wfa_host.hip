@@ -771,7 +771,14 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         // (tier 5 hands its work out by a grid-stride loop over items of equal cost: a grid that is not resident as a whole, or whose
         // wavefronts do not all run the same number of iterations, ends in a tail -- 100k configs[1] pairs = 25 000 items on 8192
         // wavefronts of which 7168 were resident: six rounds of iterations for 3.5 rounds of work)
-        if (tp.tier == 5 && grid > 0) grid = (int)cdiv(units, cdiv(units, (uint32_t)grid));
+        // Every wavefront also pays for filling its pipeline (three dependent round trips before its first iteration): with four
+        // iterations each that was a third of the launch.  At least seven iterations per wavefront where the list allows it, but
+        // never fewer than four wavefronts per CU (100k pairs: 28 / 20 / 14 / 10 wavefronts per CU = 4 / 5 / 7 / 10 iterations:
+        // 0.106 / 0.101 / 0.092 / 0.095 ms; 1M pairs, 35 iterations at full residency: 0.508 ms, 0.619 at 20 per CU).
+        if (tp.tier == 5 && grid > 0) {
+          if (c->tuning.max_blocks_per_cu <= 0) grid = std::min(grid, (int)std::max<uint32_t>(units / 7u, 4u * (uint32_t)c->num_cus));
+          grid = (int)cdiv(units, cdiv(units, (uint32_t)std::max(grid, 1)));
+        }
         // (a speculative re-run works on a list whose length only the device knows yet -- a percent of the chain's pairs,
         // usually: every workgroup beyond the work costs a claim atomic per shard)
         if (cur_len_dev) grid = std::min(grid, (int)std::max<uint32_t>(4u * (uint32_t)c->num_cus, n_cur / 64u));

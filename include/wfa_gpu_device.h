@@ -34,7 +34,8 @@ typedef struct {
     int waves_per_simd;    /* one-wave exact kernels: force the instantiation compiled for 8, 7, 6 or 4 waves per SIMD
                               (0: matched to the rings LDS lets a CU hold)                                               */
     int trace_mode;        /* 0: automatic; 1: lane-per-alignment walk + windowed emit whatever the length (the fallback
-                              of the wave-per-alignment kernel); 2: never several alignments per wavefront               */
+                              of the wave-per-alignment kernel); 2: never several alignments per wavefront; 3: never the
+                              one-kernel backtrace of short alignments (walk + emit + compaction instead: A/B)           */
     int timed_barriers;    /* diagnostics: the multi-wave exact CIGAR tiers (1 and 4) run an instantiation in which workgroup 0
                               records when each of its waves reaches and leaves the per-score barrier (s_memtime);
                               wfagpu_amd_debug_times() hands the records out                                              */

@@ -754,6 +754,29 @@ def test_fallback_backtrace_paths(trace_mode):
         al.close()
 
 
+@pytest.mark.parametrize("max_error,pen", [(40, (2, 3, 1)), (124, (2, 3, 1)), (125, (2, 3, 1)), (90, (4, 6, 2)), (60, (3, 1, 4))])
+def test_one_kernel_backtrace_of_short_alignments(max_error, pen):
+    """Chains whose scores are bounded by 124 walk and replay their alignments in ONE kernel (wfa_trace_lane_kernel: op lists in
+    LDS, one text allocation per wavefront); above that bound, and with tuning.trace_mode = 3, walk + emit + compaction run as
+    before.  Same scores and CIGARs either way, and the checker's: short reads over ACGT and with other bytes (byte-compare
+    class), pairs beyond the budget (re-run with a wider one in another chain), empty sequences, a batch big enough for the
+    scratch + compaction path of the three-kernel form."""
+    rng = random.Random(4100 + max_error)
+    pairs = _rand_pairs(rng, 9000, 160, err=0.03) + _rand_pairs(rng, 300, 200, err=0.12)
+    pairs += _rand_pairs(rng, 200, 120, alphabet=b"ACGTN", err=0.04) + [(b"", b"ACGT"), (b"", b""), (b"ACGTNNNN", b""), (b"A" * 150, b"C" * 150)]
+    buf, meta = wfagpu.layout_pairs(pairs)
+    so, co, _ = oracle_lib.oracle_batch(buf, meta, pen, cigar=True, nthreads=8)
+    out = []
+    for mode in (0, 3):
+        al = wfagpu.DeviceAligner(0, trace_mode=mode)
+        try:
+            out.append(_run(al, buf, meta, pen, max_error=max_error))
+        finally:
+            al.close()
+    assert np.array_equal(out[0][0], so) and out[0][1] == co
+    assert np.array_equal(out[1][0], so) and out[1][1] == co
+
+
 @pytest.mark.parametrize("pen,expect_short", [((2, 3, 1), True), ((4, 6, 2), True), ((1, 2, 1), True), ((1, 0, 1), True), ((4, 6, 1), True),
                                               ((3, 4, 1), True), ((7, 7, 1), True), ((8, 2, 1), True), ((6, 9, 3), True),
                                               ((5, 3, 2), False), ((9, 2, 1), False), ((2, 8, 1), False)])

@@ -181,34 +181,14 @@ __device__ __forceinline__ uint32_t replay(const uint8_t* ops, uint32_t nops, co
 
 constexpr int TRACE_THREADS = 64;
 
-// Phase 1 kernel: backward walk over the origin bytes, one lane per alignment, no LDS: it is a
-// chain of dependent HBM reads, so it wants every wave slot of the CU.  Leaves the op list of
-// each pair in the scratch arena (ops_off/nops per pair).
-__global__ void __launch_bounds__(TRACE_THREADS) wfa_walk_kernel(const WfaTraceParams p) {
-  // The walk is bound by memory TRANSACTIONS (one dependent 64-byte access per step, half a million lanes in flight: no
-  // line survives in L2 until its next use), not by bytes.  Per operation it needs a row-table entry, an origin byte and
-  // an op store; two of the three are batched: row-table entries are fetched 8 at a time (one 64-byte line) into this
-  // lane's LDS slot, ops are collected four to a register and stored as one word.
-  __shared__ uint2 tab_cache[TRACE_THREADS][9];          // [lane][entry & 7] (9: bank spread)
-  const uint32_t gid = blockIdx.x * TRACE_THREADS + threadIdx.x;
-  const int lane = threadIdx.x & 63;
-  bool active = gid < p.n_work;
-  uint32_t pair = 0;
-  if (active) pair = p.work ? p.work[gid] : gid;
-  if (active && p.status[pair] != WFA_ST_DONE) active = false;
-  int score = 0, plen = 0, tlen = 0;
-  if (active) {
-    score = p.score[pair];
-    plen = (int)p.meta[pair].pattern_len; tlen = (int)p.meta[pair].text_len;
-  }
-  // every operation costs at least min(x, e) >= 1, so `score` bytes suffice
-  const uint32_t need_ops = active ? (((uint32_t)score + 3u) & ~3u) : 0u;
-  const unsigned long long ops_off = wave_alloc(p.ops_top, need_ops, lane);
-  bool fail = active && (ops_off + need_ops > p.ops_cap);
-  uint8_t* const q_begin = p.ops + ops_off;
-  uint8_t* const q_end = q_begin + need_ops;       // (4-byte aligned: the allocations are multiples of 4)
+// The backward walk of ONE alignment (one lane): follows the origin bytes from the final cell to (0, 0) and leaves the operations
+// as a byte list that grows downwards from q_end (op number n, 0 = last operation of the alignment, is byte q_end[-1-n]; q_end is
+// 4-byte aligned, four ops go out as one word).  tab_cache: this lane's 8 row-table entries of LDS.  false: broken trace.
+__device__ __forceinline__ bool walk_ops(const WfaTraceParams& p, const uint32_t pair, const int score, const int plen, const int tlen,
+                                         uint8_t* const q_end, const uint32_t need_ops, uint2* const tab_cache_lane, uint32_t& nops_out) {
+  bool fail = false;
   uint32_t nops = 0, word = 0;
-  if (active && !fail) {
+  {
     // row table of the pair: [score] = {arena unit of the origin bytes, lo}
     const uint2* tab = reinterpret_cast<const uint2*>(p.arena + (size_t)p.bt_final_row[pair] * 16);
     int k = tlen - plen, s = score;
@@ -220,12 +200,12 @@ __global__ void __launch_bounds__(TRACE_THREADS) wfa_walk_kernel(const WfaTraceP
         cached = s >> 3;
         const uint4* src = reinterpret_cast<const uint4*>(tab + (cached << 3));
         const uint4 a = src[0], b = src[1], c2 = src[2], d = src[3];
-        tab_cache[lane][0] = make_uint2(a.x, a.y); tab_cache[lane][1] = make_uint2(a.z, a.w);
-        tab_cache[lane][2] = make_uint2(b.x, b.y); tab_cache[lane][3] = make_uint2(b.z, b.w);
-        tab_cache[lane][4] = make_uint2(c2.x, c2.y); tab_cache[lane][5] = make_uint2(c2.z, c2.w);
-        tab_cache[lane][6] = make_uint2(d.x, d.y); tab_cache[lane][7] = make_uint2(d.z, d.w);
+        tab_cache_lane[0] = make_uint2(a.x, a.y); tab_cache_lane[1] = make_uint2(a.z, a.w);
+        tab_cache_lane[2] = make_uint2(b.x, b.y); tab_cache_lane[3] = make_uint2(b.z, b.w);
+        tab_cache_lane[4] = make_uint2(c2.x, c2.y); tab_cache_lane[5] = make_uint2(c2.z, c2.w);
+        tab_cache_lane[6] = make_uint2(d.x, d.y); tab_cache_lane[7] = make_uint2(d.z, d.w);
       }
-      const uint2 row = tab_cache[lane][s & 7];
+      const uint2 row = tab_cache_lane[s & 7];
       const uint32_t code = p.arena[(size_t)row.x * 16 + (uint32_t)(k - (int)row.y)];
       uint32_t op;
       if (state == 0) {
@@ -256,7 +236,39 @@ __global__ void __launch_bounds__(TRACE_THREADS) wfa_walk_kernel(const WfaTraceP
       uint8_t* qq = q_end - (nops & ~3u);
       for (int r = (int)(nops & 3u) - 1; r >= 0; --r) *--qq = (uint8_t)(word >> (8 * r));     // (oldest of them first: highest address)
     }
+    }
+  nops_out = nops;
+  return !fail;
+}
+
+// Phase 1 kernel: backward walk over the origin bytes, one lane per alignment, no LDS: it is a
+// chain of dependent HBM reads, so it wants every wave slot of the CU.  Leaves the op list of
+// each pair in the scratch arena (ops_off/nops per pair).
+__global__ void __launch_bounds__(TRACE_THREADS) wfa_walk_kernel(const WfaTraceParams p) {
+  // The walk is bound by memory TRANSACTIONS (one dependent 64-byte access per step, half a million lanes in flight: no
+  // line survives in L2 until its next use), not by bytes.  Per operation it needs a row-table entry, an origin byte and
+  // an op store; two of the three are batched: row-table entries are fetched 8 at a time (one 64-byte line) into this
+  // lane's LDS slot, ops are collected four to a register and stored as one word.
+  __shared__ uint2 tab_cache[TRACE_THREADS][9];          // [lane][entry & 7] (9: bank spread)
+  const uint32_t gid = blockIdx.x * TRACE_THREADS + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  bool active = gid < p.n_work;
+  uint32_t pair = 0;
+  if (active) pair = p.work ? p.work[gid] : gid;
+  if (active && p.status[pair] != WFA_ST_DONE) active = false;
+  int score = 0, plen = 0, tlen = 0;
+  if (active) {
+    score = p.score[pair];
+    plen = (int)p.meta[pair].pattern_len; tlen = (int)p.meta[pair].text_len;
   }
+  // every operation costs at least min(x, e) >= 1, so `score` bytes suffice
+  const uint32_t need_ops = active ? (((uint32_t)score + 3u) & ~3u) : 0u;
+  const unsigned long long ops_off = wave_alloc(p.ops_top, need_ops, lane);
+  bool fail = active && (ops_off + need_ops > p.ops_cap);
+  uint8_t* const q_begin = p.ops + ops_off;
+  uint8_t* const q_end = q_begin + need_ops;       // (4-byte aligned: the allocations are multiples of 4)
+  uint32_t nops = 0;
+  if (active && !fail) fail = !walk_ops(p, pair, score, plen, tlen, q_end, need_ops, tab_cache[lane], nops);
   if (active) {
     // the op list now sits at [q_end - nops, q_end); cigar_off/cigar_len carry it to the emit kernel
     p.cigar_off[pair] = (unsigned long long)(q_end - nops - p.ops);
@@ -319,6 +331,107 @@ __global__ void __launch_bounds__(TRACE_THREADS) wfa_emit_win_kernel(const WfaTr
   }
 }
 
+// The packed sequences of the wavefront's first PPW pairs -> LDS (lane j's pair at seq_lds + j * seq_lds_stride: pattern words,
+// then text words), coalesced: the whole wavefront copies one pair after the other, eight pairs per round with all sixteen loads
+// in flight before the first LDS store (one pair per iteration waited a full memory round trip per load: 128 of them in a row,
+// half of the emit kernel's time).  Pw / Tw come in as the lanes' global addresses and leave as their LDS addresses.
+__device__ __forceinline__ void stage_pairs(const WfaTraceParams& p, const int PPW, const int lane, const bool active, const int plen, const int tlen,
+                                            const uint32_t*& Pw, const uint32_t*& Tw, uint32_t* const seq_lds) {
+  const int sh = p.raw ? 2 : 4;
+  const int pw = active ? ((plen + (1 << sh) - 1) >> sh) + 1 : 0, tw = active ? ((tlen + (1 << sh) - 1) >> sh) + 1 : 0;
+  const int stride = p.seq_lds_stride;   // odd number of words per lane
+  constexpr int SG = 8;
+  for (int j0 = 0; j0 < PPW; j0 += SG) {      // (PPW is a multiple of SG)
+    const uint32_t* gp[SG]; const uint32_t* gt[SG]; int pwj[SG], twj[SG];
+    int maxw = 0;
+#pragma unroll
+    for (int u = 0; u < SG; ++u) {
+      const int j = j0 + u;     // (uniform: the lanes' values come over as scalars)
+      gp[u] = reinterpret_cast<const uint32_t*>(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(reinterpret_cast<unsigned long long>(Pw) >> 32), j) << 32) |
+                                                (uint32_t)__builtin_amdgcn_readlane((int)reinterpret_cast<unsigned long long>(Pw), j));
+      gt[u] = reinterpret_cast<const uint32_t*>(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(reinterpret_cast<unsigned long long>(Tw) >> 32), j) << 32) |
+                                                (uint32_t)__builtin_amdgcn_readlane((int)reinterpret_cast<unsigned long long>(Tw), j));
+      pwj[u] = __builtin_amdgcn_readlane(pw, j); twj[u] = __builtin_amdgcn_readlane(tw, j);
+      maxw = max(maxw, max(pwj[u], twj[u]));
+    }
+    for (int i0 = 0; i0 < maxw; i0 += 64) {
+      const int i = i0 + lane;
+      uint32_t a[SG], b[SG];
+#pragma unroll
+      for (int u = 0; u < SG; ++u) { a[u] = i < pwj[u] ? gp[u][i] : 0u; b[u] = i < twj[u] ? gt[u][i] : 0u; }
+#pragma unroll
+      for (int u = 0; u < SG; ++u) {
+        uint32_t* dst = seq_lds + (size_t)(j0 + u) * stride;
+        if (i < pwj[u]) dst[i] = a[u];
+        if (i < twj[u]) dst[pwj[u] + i] = b[u];
+      }
+    }
+  }
+  __syncthreads();
+  Pw = seq_lds + (size_t)lane * stride;
+  Tw = Pw + pw;
+}
+
+// SHORT alignments, everything in one kernel (round 4): one lane per alignment; the wavefront stages its pairs' sequences in LDS,
+// every lane walks its origin bytes backwards into an op list in LDS (ops_lds_bytes per lane: the chain's largest score, one byte
+// per operation), replays it once to size the text, buys the text's place in the dense arena (one atomic per wavefront) and
+// replays it again straight into it.  Against walk + emit + compaction: no op list and no text scratch in global memory, one
+// allocation instead of three (every one of them a returning atomic per wavefront on one counter: ~11 ns each, 17 us per
+// 100k-pair kernel just for those), one launch instead of three.
+template <bool RAW>
+__global__ void __launch_bounds__(TRACE_THREADS) wfa_trace_lane_kernel(const WfaTraceParams p) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t seq_lds[];
+  const int PPW = p.emit_pairs;
+  const int lane = threadIdx.x & 63;
+  const uint32_t gid = blockIdx.x * (uint32_t)PPW + (uint32_t)lane;
+  uint8_t* const ops_lds = reinterpret_cast<uint8_t*>(seq_lds + (size_t)PPW * p.seq_lds_stride);
+  uint2* const tab_cache = reinterpret_cast<uint2*>(ops_lds + (size_t)PPW * p.ops_lds_bytes);      // [lane][9]
+  bool active = lane < PPW && gid < p.n_work;
+  uint32_t pair = 0;
+  if (active) pair = p.work ? p.work[gid] : gid;
+  if (active && p.status[pair] != WFA_ST_DONE) active = false;
+  int plen = 0, tlen = 0, score = 0;
+  const uint32_t* Pw = nullptr; const uint32_t* Tw = nullptr;
+  if (active) {
+    const WfaSeqPair mp = p.meta[pair];
+    plen = (int)mp.pattern_len; tlen = (int)mp.text_len;
+    Pw = p.packed + ((RAW ? mp.pattern_offset : mp.pattern_offset_packed) >> 2);
+    Tw = p.packed + ((RAW ? mp.text_offset : mp.text_offset_packed) >> 2);
+    score = p.score[pair];
+  }
+  stage_pairs(p, PPW, lane, active, plen, tlen, Pw, Tw, seq_lds);
+  const uint32_t need_ops = active ? (((uint32_t)score + 3u) & ~3u) : 0u;
+  bool fail = active && need_ops > (uint32_t)p.ops_lds_bytes;
+  uint8_t* const q_end = ops_lds + (size_t)lane * p.ops_lds_bytes + need_ops;      // (the lane's slot: 4-byte aligned, like need_ops)
+  uint32_t nops = 0;
+  if (active && !fail) fail = !walk_ops(p, pair, score, plen, tlen, q_end, need_ops, tab_cache + (size_t)lane * 9, nops);
+  const uint8_t* const q = q_end - nops;
+  uint32_t len = 0;
+  if (active && !fail) {
+    len = replay<RAW>(q, nops, Pw, Tw, plen, tlen, nullptr, 0, 0, 0, nullptr);
+    if (len == 0xFFFFFFFFu) fail = true;
+  }
+  const uint32_t need_txt = (active && !fail) ? len + 1u : 0u;
+  const unsigned long long txt_off = wave_alloc(p.text_top, need_txt, lane);
+  if (active && !fail && txt_off + need_txt > p.text_cap) fail = true;
+  if (active) {
+    if (!fail) {
+      int cost = 0;
+      replay<RAW>(q, nops, Pw, Tw, plen, tlen, p.text + txt_off, p.x, p.oe - p.e, p.e, &cost);
+      p.cigar_off[pair] = txt_off;
+      p.cigar_len[pair] = len;
+      // (the text's own gap-affine cost must equal the score; adaptive band: the score follows the text -- see wfa_emit_kernel)
+      if (cost != score) {
+        if (p.score_fix) p.score_fix[pair] = cost;
+        else p.cigar_len[pair] = 0xFFFFFFFFu;
+      }
+    } else {
+      p.cigar_off[pair] = 0;
+      p.cigar_len[pair] = 0xFFFFFFFFu;
+    }
+  }
+}
+
 // Forward replay, the default for short alignments: the 64 pairs of a block are first copied into LDS (coalesced, one
 // pair at a time by the whole wavefront), so the many small reads of the replay never leave the CU.  (Reading the packed
 // sequences straight from global memory made every 4-byte read miss L1 and L2 -- the working set of all resident lanes
@@ -351,43 +464,7 @@ __global__ void __launch_bounds__(TRACE_THREADS) wfa_emit_kernel(const WfaTraceP
     nops = p.cigar_len[pair];
     fail = nops == 0xFFFFFFFFu;
   }
-  if constexpr (SEQ_LDS) {
-    const int sh = p.raw ? 2 : 4;
-    const int pw = active ? ((plen + (1 << sh) - 1) >> sh) + 1 : 0, tw = active ? ((tlen + (1 << sh) - 1) >> sh) + 1 : 0;
-    const int stride = p.seq_lds_stride;   // odd number of words per lane
-    // Eight pairs at a time: all sixteen loads of a round are issued before the first LDS store (one pair per
-    // iteration waited a full memory round trip per load: 128 of them in a row, half of this kernel's time).
-    constexpr int SG = 8;
-    for (int j0 = 0; j0 < PPW; j0 += SG) {      // (PPW is a multiple of SG)
-      const uint32_t* gp[SG]; const uint32_t* gt[SG]; int pwj[SG], twj[SG];
-      int maxw = 0;
-#pragma unroll
-      for (int u = 0; u < SG; ++u) {
-        const int j = j0 + u;     // (uniform: the lanes' values come over as scalars)
-        gp[u] = reinterpret_cast<const uint32_t*>(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(reinterpret_cast<unsigned long long>(Pw) >> 32), j) << 32) |
-                                                  (uint32_t)__builtin_amdgcn_readlane((int)reinterpret_cast<unsigned long long>(Pw), j));
-        gt[u] = reinterpret_cast<const uint32_t*>(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(reinterpret_cast<unsigned long long>(Tw) >> 32), j) << 32) |
-                                                  (uint32_t)__builtin_amdgcn_readlane((int)reinterpret_cast<unsigned long long>(Tw), j));
-        pwj[u] = __builtin_amdgcn_readlane(pw, j); twj[u] = __builtin_amdgcn_readlane(tw, j);
-        maxw = max(maxw, max(pwj[u], twj[u]));
-      }
-      for (int i0 = 0; i0 < maxw; i0 += 64) {
-        const int i = i0 + lane;
-        uint32_t a[SG], b[SG];
-#pragma unroll
-        for (int u = 0; u < SG; ++u) { a[u] = i < pwj[u] ? gp[u][i] : 0u; b[u] = i < twj[u] ? gt[u][i] : 0u; }
-#pragma unroll
-        for (int u = 0; u < SG; ++u) {
-          uint32_t* dst = seq_lds + (size_t)(j0 + u) * stride;
-          if (i < pwj[u]) dst[i] = a[u];
-          if (i < twj[u]) dst[pwj[u] + i] = b[u];
-        }
-      }
-    }
-    __syncthreads();
-    Pw = seq_lds + (size_t)lane * stride;
-    Tw = Pw + pw;
-  }
+  if constexpr (SEQ_LDS) stage_pairs(p, PPW, lane, active, plen, tlen, Pw, Tw, seq_lds);
   if (p.text_scratch) {
     // single replay: the text goes to this lane's slot of the scratch (sized by the same bound the host sizes the arenas
     // with: at most score / min(x, e) operations, each with a match run, item_chars characters per item); wfa_text_compact_kernel
@@ -818,6 +895,16 @@ bool wfa_launch_trace(const WfaTraceParams& p, hipStream_t stream, hipEvent_t ev
     return true;
   }
   const dim3 grid((p.n_work + TRACE_THREADS - 1) / TRACE_THREADS), block(TRACE_THREADS);
+  if (p.lane_fused) {
+    // short alignments: walk + both replays in one kernel, op lists in LDS (sequences, then ops_lds_bytes per lane, then 72 bytes of
+    // row-table cache per lane)
+    const size_t lds = (size_t)p.emit_pairs * p.seq_lds_stride * 4 + (size_t)p.emit_pairs * p.ops_lds_bytes + (size_t)64 * 9 * 8;
+    const dim3 grid_f((p.n_work + (uint32_t)p.emit_pairs - 1) / (uint32_t)p.emit_pairs);
+    static thread_local size_t allowed[2][16] = {{0}};
+    if (p.raw) { allow_lds(wfa_trace_lane_kernel<true>, lds, allowed[1]); wfa_launch_timed(wfa_trace_lane_kernel<true>, grid_f, block, lds, stream, ev0, ev1, p); }
+    else { allow_lds(wfa_trace_lane_kernel<false>, lds, allowed[0]); wfa_launch_timed(wfa_trace_lane_kernel<false>, grid_f, block, lds, stream, ev0, ev1, p); }
+    return true;
+  }
   wfa_launch_timed(wfa_walk_kernel, grid, block, 0, stream, ev0, (hipEvent_t) nullptr, p);
   if (p.seq_lds_stride == 0) {      // (sequences too long to stage 64 pairs, or tuning.trace_mode 1: 8-word LDS windows)
     wfa_launch_timed(wfa_emit_win_kernel, grid, block, 0, stream, (hipEvent_t) nullptr, ev1, p);

@@ -886,6 +886,16 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
             for (int g = 8; g >= 2; g >>= 1)
               if ((share + (size_t)(64 / g) * 16 + 16) * g <= (40u << 10) && n_chain >= (uint32_t)g * 1024u) { tp.group = g; break; }
         }
+        // SHORT alignments (no pair of the chain finished above a score of 124): walk and replay in one kernel, op lists in LDS
+        tp.lane_fused = 0;
+        if (!tp.wave_kernel && tp.seq_lds_stride > 0 && s_hi >= 0 && s_hi <= 124 && c->tuning.trace_mode != 3) {
+          tp.lane_fused = 1;
+          tp.ops_lds_bytes = (int)((s_hi + 3) & ~3ll);
+          if (!(c->tuning.emit_pairs >= 8 && c->tuning.emit_pairs <= 64)) {
+            tp.emit_pairs = 64;
+            while (tp.emit_pairs > 16 && c->lds_per_block_max / ((size_t)tp.emit_pairs * (stride * 4 + (size_t)tp.ops_lds_bytes) + 64 * 72) < 8) tp.emit_pairs -= 8;
+          }
+        }
         tp.packed = ap.packed; tp.meta = ap.meta; tp.work = chain_list; tp.n_work = n_chain;
         tp.x = pen.x; tp.oe = oe; tp.e = pen.e;
         tp.score = d_scores; tp.status = static_cast<const uint32_t*>(c->status.p);
@@ -897,7 +907,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         tp.item_chars = item_chars;
         // lane-per-alignment emit with whole sequences staged: one replay into a scratch + compaction (big passes only: the
         // scratch holds the upper bounds, ~3x the text)
-        if (!tp.wave_kernel && tp.seq_lds_stride > 0 && n_chain >= 8192u) {
+        if (!tp.wave_kernel && !tp.lane_fused && tp.seq_lds_stride > 0 && n_chain >= 8192u) {
           if (c->text_scratch.ensure(text_sum + 4096, st)) return -1;
           if (zero_counter(c, CT_SCRATCH)) return -1;
           tp.text_scratch = static_cast<char*>(c->text_scratch.p); tp.text_scratch_cap = c->text_scratch.cap; tp.scratch_top = ct + CT_SCRATCH;

@@ -61,8 +61,11 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 def kernel_source_hash():
     """Identifies the kernels a PMC summary was taken with (profiles/*/..._pmc_counters.csv carry it in a '#' line)."""
     h = hashlib.sha1()
-    for f in ("align_kernel.hip", "short_kernel.hip", "trace_kernel.hip", "pack_kernel.hip", "wfa_device.h"):
-        h.update(open(os.path.join(ROOT, "wfa-gpu_amd", "csrc", f), "rb").read())
+    import glob
+    csrc = os.path.join(ROOT, "wfa-gpu_amd", "csrc")
+    files = [os.path.join(csrc, f) for f in ("align_kernel.hip", "short_kernel.hip", "trace_kernel.hip", "pack_kernel.hip", "wfa_device.h")]
+    for f in files + sorted(glob.glob(os.path.join(csrc, "align", "*.inc"))):      # (the score loops and cells of align_kernel.hip)
+        h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 
 

@@ -754,6 +754,39 @@ def test_fallback_backtrace_paths(trace_mode):
         al.close()
 
 
+@pytest.mark.parametrize("cigar", [False, True])
+def test_misses_after_a_batch_without_any(cigar):
+    """A stream of batches under inherited budgets: the speculative re-run launch of budget misses is left out once a batch had
+    no miss at all (short reads under budgets with room); pairs that miss in a LATER batch are then re-run by a chain of their
+    own.  Batch 1 tunes the budgets on its sample, batch 2 (the same reads) has no miss, batch 3 holds 1 % of reads at 15 %
+    error far beyond their budgets, batch 4 sees those again with the re-run launch back in place: every score (and CIGAR)
+    equals the checker's, and the misses are counted."""
+    n = 12000
+    clean, mc = wfagpu.generate_pairs(n, 150, 0.02, seed=611)
+    hard, mh = wfagpu.generate_pairs(n // 100, 150, 0.15, seed=612)
+    pairs = wfagpu.pairs_from_layout(clean, mc)
+    mixed = list(pairs)
+    for j, p in enumerate(wfagpu.pairs_from_layout(hard, mh)):
+        mixed[97 * j + 5] = p
+    al = wfagpu.DeviceAligner(0)
+    try:
+        missed = []
+        for batch_pairs in (pairs, pairs, mixed, mixed):
+            buf, meta = wfagpu.layout_pairs(batch_pairs)
+            so, co, _ = oracle_lib.oracle_batch(buf, meta, (2, 3, 1), cigar=cigar, nthreads=8)
+            s, cg = _run(al, buf, meta, (2, 3, 1), max_error=60, cigar=cigar)
+            st = al.stats()
+            assert np.array_equal(s, so)
+            if cigar:
+                assert cg == co
+            assert st.auto_budget > 0
+            missed.append(int(st.pairs_budget_missed))
+            al.hint_same_stream(True)
+        assert missed[1] == 0 and missed[2] >= n // 200 and missed[3] == missed[2], missed
+    finally:
+        al.close()
+
+
 @pytest.mark.parametrize("max_error,pen", [(40, (2, 3, 1)), (124, (2, 3, 1)), (125, (2, 3, 1)), (90, (4, 6, 2)), (60, (3, 1, 4))])
 def test_one_kernel_backtrace_of_short_alignments(max_error, pen):
     """Chains whose scores are bounded by 124 walk and replay their alignments in ONE kernel (wfa_trace_lane_kernel: op lists in

@@ -281,7 +281,7 @@ struct wfagpu_amd_ctx {
   bool same_stream = false;
   // (keyed by the length CLASS of the bucket -- the power of two above its longest pair: the budget is a score per 1024
   // bases, it carries over between batches whose longest reads differ by a few bases)
-  struct SavedQ { unsigned bucket_hi; int q; int x, o, e, max_error; } saved_q[8] = {};
+  struct SavedQ { unsigned bucket_hi; int q; int x, o, e, max_error; unsigned last_missed; } saved_q[8] = {};      // (last_missed: pairs of the last batch that exceeded these budgets)
   static unsigned length_class(unsigned len) { unsigned c = 1; while (c < len && c < (1u << 31)) c <<= 1; return c; }
   int n_saved_q = 0;
   uint32_t ct_used = 0;      // counters (bit = index) used since the call zeroed them all: zero_counter re-zeroes only those
@@ -688,7 +688,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   // synchronisation.  Further chains (wider tiers) follow only for pairs that are still unfinished then.  (Six round
   // trips per batch before: with two lanes per device the lanes fell into lockstep, both waiting on the host at once.)
   auto run_list = [&](uint32_t* pending, uint32_t n_pending, const bool raw, const int32_t* budgets, const int budget_cap,
-                      uint32_t* alt0, uint32_t* alt1, const bool allow_band = true) -> int {
+                      uint32_t* alt0, uint32_t* alt1, const bool allow_band = true, const bool speculate = true) -> int {
   grid_cap = UINT32_MAX;
   const bool unfiltered = pending == nullptr;
   if (budgets) {
@@ -814,8 +814,11 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
           else if (max_score >= 30000 || max_len > 32766u) max_score = INT_MAX;
           else max_score = (int)std::min<long long>(30000, std::max<long long>(16, 4ll * max_score));   // (a budget of 0 must grow too)
         }
-        // the re-run of budget misses follows without a round trip; every other escalation waits for the counts
-        if (!(L.budgeted && n_links == 1)) break;
+        // the re-run of budget misses follows without a round trip; every other escalation waits for the counts.  (speculate: off
+        // when the last batch of the stream had no miss at all -- short reads under budgets with room: an empty launch, its
+        // compaction and the gaps around them are 17 us of a 190 us BASELINE configs[1] step; should a pair miss after all, the
+        // next chain re-runs it after this one's synchronisation)
+        if (!(L.budgeted && n_links == 1 && speculate)) break;
       }
       // (whatever the budget, no optimal alignment costs more than mismatching the shorter sequence and one gap for the rest)
       s_hi = std::min<long long>(s_hi, (long long)pen.x * max_len + oe + (long long)pen.e * max_len);
@@ -1144,7 +1147,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
           int slot = -1;
           for (int i = 0; i < c->n_saved_q; ++i) if (c->saved_q[i].bucket_hi == wfagpu_amd_ctx::length_class(bucket_hi)) slot = i;
           if (slot < 0 && c->n_saved_q < 8) slot = c->n_saved_q++;
-          if (slot >= 0) c->saved_q[slot] = {wfagpu_amd_ctx::length_class(bucket_hi), q, pen.x, pen.o, pen.e, max_error};
+          if (slot >= 0) c->saved_q[slot] = {wfagpu_amd_ctx::length_class(bucket_hi), q, pen.x, pen.o, pen.e, max_error, 0xFFFFFFFFu};      // (misses under it: not known yet)
         }
         if (sample_again) {
           // the sampled pairs go through the bucket's run like everybody else
@@ -1167,7 +1170,9 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       const bool use_band = want_band && (!budgets || c->tuning.force_band ||
                                           2 * window_width(budget_cap, pen.o, pen.e, max_len) > 5 * band_width);
       const unsigned missed_before = c->stats.pairs_budget_missed;
-      if (n_pending && run_list(pending, n_pending, raw, budgets, budget_cap, static_cast<uint32_t*>(c->list_d.p), bucket_list, use_band)) return -1;
+      const bool speculate = !(saved_idx >= 0 && c->saved_q[saved_idx].last_missed == 0);
+      if (n_pending && run_list(pending, n_pending, raw, budgets, budget_cap, static_cast<uint32_t*>(c->list_d.p), bucket_list, use_band, speculate)) return -1;
+      if (saved_idx >= 0) c->saved_q[saved_idx].last_missed = c->stats.pairs_budget_missed - missed_before;
       if (saved_idx >= 0 && (c->stats.pairs_budget_missed - missed_before) * 20u > n_pending) {
         // more than 5 % of the batch missed the inherited budgets: the stream has drifted, sample again next time
         c->saved_q[saved_idx] = c->saved_q[--c->n_saved_q];

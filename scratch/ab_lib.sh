@@ -1,0 +1,6 @@
+# A/B of two builds of the library on one box: scratch/lib_old.so against scratch/lib_new.so, alternating, cfg3 resident step
+for i in 1 2 3; do for v in old new; do
+  cp scratch/lib_$v.so wfa-gpu_amd/libwfagpu.so
+  python3 bench.py --workload ${1:-cfg3} --steps ${2:-20} --warmup 3 --no-configs --no-cpu-baseline --no-host-to-host 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', d['value'], d['ms_per_step'], d['stage_ms_per_step'], d['roofline']['kernel_ms'])"
+done; done
+cp scratch/lib_new.so wfa-gpu_amd/libwfagpu.so

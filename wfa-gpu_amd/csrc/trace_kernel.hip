@@ -94,6 +94,27 @@ __device__ __forceinline__ unsigned long long wave_alloc(unsigned long long* top
   return base + incl - need;
 }
 
+// The same for a workgroup of W wavefronts: ONE atomic per workgroup (a returning atomic on the one bump counter costs ~11 ns
+// whoever issues it: at a kernel's start every resident wavefront queues for it).  All threads must call; two barriers.
+template <int W>
+__device__ __forceinline__ unsigned long long block_alloc(unsigned long long* top, uint32_t need, uint32_t* wave_total, unsigned long long* block_base) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint32_t incl = need;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+  if (lane == 63) wave_total[wv] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t tot = 0;
+    for (int w = 0; w < W; ++w) tot += wave_total[w];
+    *block_base = tot ? atomicAdd(top, (unsigned long long)tot) : 0ull;
+  }
+  __syncthreads();
+  uint32_t before = 0;
+  for (int w = 0; w < wv; ++w) before += wave_total[w];
+  return *block_base + before + incl - need;
+}
+
 __device__ __forceinline__ int dec_digits(uint32_t n) {
   return n < 10 ? 1 : n < 100 ? 2 : n < 1000 ? 3 : n < 10000 ? 4 : n < 100000 ? 5 : n < 1000000 ? 6 : n < 10000000 ? 7 :
          n < 100000000 ? 8 : n < 1000000000 ? 9 : 10;
@@ -244,14 +265,16 @@ __device__ __forceinline__ bool walk_ops(const WfaTraceParams& p, const uint32_t
 // Phase 1 kernel: backward walk over the origin bytes, one lane per alignment, no LDS: it is a
 // chain of dependent HBM reads, so it wants every wave slot of the CU.  Leaves the op list of
 // each pair in the scratch arena (ops_off/nops per pair).
-__global__ void __launch_bounds__(TRACE_THREADS) wfa_walk_kernel(const WfaTraceParams p) {
+constexpr int WALK_WAVES = 4;      // (wavefronts per workgroup: they share the allocation of their op lists, block_alloc)
+__global__ void __launch_bounds__(WALK_WAVES * 64) wfa_walk_kernel(const WfaTraceParams p) {
   // The walk is bound by memory TRANSACTIONS (one dependent 64-byte access per step, half a million lanes in flight: no
   // line survives in L2 until its next use), not by bytes.  Per operation it needs a row-table entry, an origin byte and
   // an op store; two of the three are batched: row-table entries are fetched 8 at a time (one 64-byte line) into this
   // lane's LDS slot, ops are collected four to a register and stored as one word.
-  __shared__ uint2 tab_cache[TRACE_THREADS][9];          // [lane][entry & 7] (9: bank spread)
-  const uint32_t gid = blockIdx.x * TRACE_THREADS + threadIdx.x;
-  const int lane = threadIdx.x & 63;
+  __shared__ uint2 tab_cache[WALK_WAVES * 64][9];          // [thread][entry & 7] (9: bank spread)
+  __shared__ uint32_t wave_total[WALK_WAVES];
+  __shared__ unsigned long long block_base;
+  const uint32_t gid = blockIdx.x * (WALK_WAVES * 64) + threadIdx.x;
   bool active = gid < p.n_work;
   uint32_t pair = 0;
   if (active) pair = p.work ? p.work[gid] : gid;
@@ -263,12 +286,12 @@ __global__ void __launch_bounds__(TRACE_THREADS) wfa_walk_kernel(const WfaTraceP
   }
   // every operation costs at least min(x, e) >= 1, so `score` bytes suffice
   const uint32_t need_ops = active ? (((uint32_t)score + 3u) & ~3u) : 0u;
-  const unsigned long long ops_off = wave_alloc(p.ops_top, need_ops, lane);
+  const unsigned long long ops_off = block_alloc<WALK_WAVES>(p.ops_top, need_ops, wave_total, &block_base);
   bool fail = active && (ops_off + need_ops > p.ops_cap);
   uint8_t* const q_begin = p.ops + ops_off;
   uint8_t* const q_end = q_begin + need_ops;       // (4-byte aligned: the allocations are multiples of 4)
   uint32_t nops = 0;
-  if (active && !fail) fail = !walk_ops(p, pair, score, plen, tlen, q_end, need_ops, tab_cache[lane], nops);
+  if (active && !fail) fail = !walk_ops(p, pair, score, plen, tlen, q_end, need_ops, tab_cache[threadIdx.x], nops);
   if (active) {
     // the op list now sits at [q_end - nops, q_end); cigar_off/cigar_len carry it to the emit kernel
     p.cigar_off[pair] = (unsigned long long)(q_end - nops - p.ops);
@@ -522,8 +545,13 @@ __global__ void __launch_bounds__(TRACE_THREADS) wfa_emit_kernel(const WfaTraceP
 
 // Texts from their scratch slots (cigar_off = scratch offset, cigar_len = length) to the dense arena: one wavefront per
 // 64 alignments, space bought with one atomic per wavefront, every text copied by all 64 lanes.
-__global__ void __launch_bounds__(TRACE_THREADS) wfa_text_compact_kernel(const WfaTraceParams p) {
-  const uint32_t gid = blockIdx.x * TRACE_THREADS + threadIdx.x;
+// (four wavefronts per workgroup share ONE atomic: a returning atomic on the one bump counter costs ~11 ns whoever issues it, and
+// one per wavefront was 0.17 of this kernel's 0.34 ms per 1M texts)
+constexpr int COMPACT_WAVES = 4;
+__global__ void __launch_bounds__(COMPACT_WAVES * 64) wfa_text_compact_kernel(const WfaTraceParams p) {
+  __shared__ uint32_t wave_total[COMPACT_WAVES];
+  __shared__ unsigned long long block_base;
+  const uint32_t gid = blockIdx.x * (COMPACT_WAVES * 64) + threadIdx.x;
   const int lane = threadIdx.x & 63;
   bool active = gid < p.n_work;
   uint32_t pair = 0;
@@ -532,7 +560,7 @@ __global__ void __launch_bounds__(TRACE_THREADS) wfa_text_compact_kernel(const W
   uint32_t len = active ? p.cigar_len[pair] : 0xFFFFFFFFu;
   const unsigned long long src = active ? p.cigar_off[pair] : 0ull;
   const uint32_t need = len != 0xFFFFFFFFu ? len + 1u : 0u;
-  const unsigned long long dst = wave_alloc(p.text_top, need, lane);
+  const unsigned long long dst = block_alloc<COMPACT_WAVES>(p.text_top, need, wave_total, &block_base);
   if (need && dst + need > p.text_cap) len = 0xFFFFFFFFu;
   // Eight texts at a time, eight lanes each, 32-bit words (unaligned on both sides), up to eight words per lane loaded
   // before the first store: a text was copied byte-wise by the whole wavefront, one load-store round trip after the other.
@@ -905,7 +933,7 @@ bool wfa_launch_trace(const WfaTraceParams& p, hipStream_t stream, hipEvent_t ev
     else { allow_lds(wfa_trace_lane_kernel<false>, lds, allowed[0]); wfa_launch_timed(wfa_trace_lane_kernel<false>, grid_f, block, lds, stream, ev0, ev1, p); }
     return true;
   }
-  wfa_launch_timed(wfa_walk_kernel, grid, block, 0, stream, ev0, (hipEvent_t) nullptr, p);
+  wfa_launch_timed(wfa_walk_kernel, dim3((p.n_work + WALK_WAVES * 64 - 1) / (WALK_WAVES * 64)), dim3(WALK_WAVES * 64), 0, stream, ev0, (hipEvent_t) nullptr, p);
   if (p.seq_lds_stride == 0) {      // (sequences too long to stage 64 pairs, or tuning.trace_mode 1: 8-word LDS windows)
     wfa_launch_timed(wfa_emit_win_kernel, grid, block, 0, stream, (hipEvent_t) nullptr, ev1, p);
     return true;
@@ -915,7 +943,8 @@ bool wfa_launch_trace(const WfaTraceParams& p, hipStream_t stream, hipEvent_t ev
   allow_lds(wfa_emit_kernel<true>, lds, allowed);
   const dim3 grid_e((p.n_work + (uint32_t)p.emit_pairs - 1) / (uint32_t)p.emit_pairs);
   wfa_launch_timed(wfa_emit_kernel<true>, grid_e, block, lds, stream, (hipEvent_t) nullptr, p.text_scratch ? (hipEvent_t) nullptr : ev1, p);
-  if (p.text_scratch) wfa_launch_timed(wfa_text_compact_kernel, grid, block, 0, stream, (hipEvent_t) nullptr, ev1, p);
+  if (p.text_scratch)
+    wfa_launch_timed(wfa_text_compact_kernel, dim3((p.n_work + COMPACT_WAVES * 64 - 1) / (COMPACT_WAVES * 64)), dim3(COMPACT_WAVES * 64), 0, stream, (hipEvent_t) nullptr, ev1, p);
   return true;
 }
 

@@ -175,10 +175,11 @@ __device__ __forceinline__ uint32_t replay_views(const uint8_t* ops, uint32_t no
   for (uint32_t i = 0; i < nops; ++i) {
     const uint32_t op = word & 0xFFu;
     if (((i + 1 + skip) & 3u) == 0u) { if (i + 1 < nops) word = ops4[(i + 1 + skip) >> 2]; } else word >>= 8;
-    switch (op & 3) {
-      case OP_X: sink.push('X', 1); ++v; ++h; break;
-      case OP_I: sink.push('I', 1); ++h; break;
-      default:   sink.push('D', 1); ++v; break;
+    {
+      // (one push for the three kinds of operation: the lanes of a wavefront hold all of them at once)
+      const uint32_t k3 = op & 3u;
+      sink.push(k3 == OP_X ? 'X' : (k3 == OP_I ? 'I' : 'D'), 1);
+      v += (k3 != OP_I) ? 1 : 0; h += (k3 != OP_D) ? 1 : 0;
     }
     if (op & OP_EXT_AFTER) {
       n = lcp_seq<RAW>(Pw, Tw, plen, tlen, v, h);

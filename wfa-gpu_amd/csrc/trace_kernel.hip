@@ -21,6 +21,7 @@
 // Scratch and text space come from wave-aggregated bump allocations (one atomic per wavefront), so the text arena is
 // dense and can be copied to the host in one piece.
 #include <cstdlib>
+#include <type_traits>
 
 #include "wfa_device.h"
 
@@ -61,6 +62,25 @@ __device__ __forceinline__ int lcp_seq(PV& Pw, TV& Tw, int plen, int tlen, int v
   constexpr int BITS = RAW ? 3 : 1;
   int n_total = 0;
   int rem = min(plen - v, tlen - h);
+  if constexpr (std::is_same<PV, SeqDirect>::value && std::is_same<TV, SeqDirect>::value) {
+    // whole sequences addressable (LDS): THREE words per step -- every step is a dependent LDS round trip, and the runs between
+    // the operations of reads at a few per cent of error are two or three words long.  (Trace per batch, BASELINE configs[2] /
+    // configs[3], one, two, three, four words per step: 3.30 / 3.20 / 3.15 / 3.15 ms and 2.33 / 2.20 / 2.16 / 2.27 ms.)
+    while (rem > 0) {
+      const uint32_t* pw = Pw.w + (v >> SH); const uint32_t* tw = Tw.w + (h >> SH);
+      const uint32_t p0 = pw[0], p1 = pw[1], p2 = pw[2], p3 = pw[3], t0 = tw[0], t1 = tw[1], t2 = tw[2], t3 = tw[3];
+      const uint32_t sa = (uint32_t)(v & (PER - 1)) << BITS, sb = (uint32_t)(h & (PER - 1)) << BITS;
+      const uint32_t d0 = __builtin_amdgcn_alignbit(p1, p0, sa) ^ __builtin_amdgcn_alignbit(t1, t0, sb);
+      const uint32_t d1 = __builtin_amdgcn_alignbit(p2, p1, sa) ^ __builtin_amdgcn_alignbit(t2, t1, sb);
+      const uint32_t d2 = __builtin_amdgcn_alignbit(p3, p2, sa) ^ __builtin_amdgcn_alignbit(t3, t2, sb);
+      // (nested, first word first: a chain of selects from the last word down measured 2 % slower)
+      int n = d0 ? (__builtin_ctz(d0) >> BITS) : PER + (d1 ? (__builtin_ctz(d1) >> BITS) : PER + (d2 ? (__builtin_ctz(d2) >> BITS) : PER));
+      n = min(n, rem);
+      n_total += n; h += n; v += n; rem -= n;
+      if (n < 3 * PER) break;
+    }
+    return n_total;
+  }
   while (rem > 0) {
     const uint2 pw = Pw.pair(v >> SH), tw = Tw.pair(h >> SH);
     const uint32_t a = __builtin_amdgcn_alignbit(pw.y, pw.x, (v & (PER - 1)) << BITS);

@@ -220,12 +220,20 @@ __global__ void k_budget(const WfaSeqPair* __restrict__ meta, uint32_t n, int q,
   out[gid] = (int32_t)min(0x3FFFFFFFll, ((long long)q * len * margin_pct / 100) / 1024 + slack);
 }
 
-// pairs that are not DONE at the end of a call (must be none: every list is run to completion)
-__global__ void k_count_unfinished(uint32_t n, const uint32_t* __restrict__ status, unsigned long long* __restrict__ count) {
-  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool bad = gid < n && status[gid] != WFA_ST_DONE;
-  const unsigned long long bal = __ballot(bad);
-  if (bal && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(bal)) atomicAdd(count, (unsigned long long)__builtin_popcountll(bal));
+// pairs that are not DONE at the end of a call (must be none: every list is run to completion).  Grid-stride, four statuses per
+// load: one thread per status took 41 us for 1M pairs -- a million threads for 4 MB.
+__global__ void __launch_bounds__(256) k_count_unfinished(uint32_t n, const uint32_t* __restrict__ status, unsigned long long* __restrict__ count) {
+  uint32_t bad = 0;
+  for (uint32_t i = (blockIdx.x * 256u + threadIdx.x) * 4u; i < n; i += gridDim.x * 1024u) {
+    if (i + 3u < n) {
+      const uint4 v = *reinterpret_cast<const uint4*>(status + i);      // (the status array is 16-byte aligned, i a multiple of 4)
+      bad += (v.x != WFA_ST_DONE) + (v.y != WFA_ST_DONE) + (v.z != WFA_ST_DONE) + (v.w != WFA_ST_DONE);
+    } else {
+      for (uint32_t j = i; j < n; ++j) bad += status[j] != WFA_ST_DONE;
+    }
+  }
+  for (int d = 32; d > 0; d >>= 1) bad += __shfl_down(bad, d);
+  if ((threadIdx.x & 63) == 0 && bad) atomicAdd(count, (unsigned long long)bad);
 }
 
 // scores of a run with penalties divided by their common factor g -> scores under the caller's penalties
@@ -928,7 +936,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       // (with it comes the number of pairs of the whole batch that are not finished yet: when this turns out to have been the
       // call's last chain, that IS the end-of-call check -- no launch and no round trip of its own)
       if (zero_counter(c, CT_UNFIN)) return -1;
-      LAUNCH_K(k_count_unfinished, dim3(cdiv(n, 256)), dim3(256), 0, st, n, static_cast<const uint32_t*>(c->status.p), ct + CT_UNFIN);
+      LAUNCH_K(k_count_unfinished, dim3(std::min<uint32_t>(cdiv(n, 1024), 1024u)), dim3(256), 0, st, n, static_cast<const uint32_t*>(c->status.p), ct + CT_UNFIN);
       HIP_TRY(hipEventRecord(c->ev_end, st));
       if (read_counters(c)) return -1;
       unfinished_at_sync = (long long)c->h_counters[CT_UNFIN];
@@ -1189,7 +1197,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
     // (something was queued behind the last chain's synchronisation -- list bookkeeping of a pass that turned out to be the
     // last, the score scaling: count again and drain the stream, the call is blocking)
     if (zero_counter(c, CT_UNFIN)) return -1;
-    LAUNCH_K(k_count_unfinished, dim3(cdiv(n, 256)), dim3(256), 0, st, n, static_cast<const uint32_t*>(c->status.p), ct + CT_UNFIN);
+    LAUNCH_K(k_count_unfinished, dim3(std::min<uint32_t>(cdiv(n, 1024), 1024u)), dim3(256), 0, st, n, static_cast<const uint32_t*>(c->status.p), ct + CT_UNFIN);
     HIP_TRY(hipEventRecord(c->ev_end, st));
     if (read_counters(c)) return -1;
     unfinished_at_sync = (long long)c->h_counters[CT_UNFIN];

@@ -40,6 +40,8 @@ typedef struct {
                               records when each of its waves reaches and leaves the per-score barrier (s_memtime);
                               wfagpu_amd_debug_times() hands the records out                                              */
     int no_short_cigar;    /* A/B and test hook: CIGAR calls never take tier 5 (several alignments per wavefront)               */
+    int no_fused_pack;     /* A/B: always run the pack kernel (default: reads of 512 bases and more are packed by the wavefront
+                              kernels while they stage them)                                                                    */
     int emit_pairs;        /* lane-per-alignment CIGAR replay with the sequences staged in LDS: alignments per wavefront
                               (8..64; 0: automatic -- as many as keep the most lanes resident per CU)                          */
 } wfagpu_amd_tuning_t;

@@ -66,6 +66,7 @@
 #include <type_traits>
 
 #include "wfa_device.h"
+#include "pack_device.h"
 
 namespace {
 
@@ -315,8 +316,37 @@ wfa_align_kernel(const WfaAlignParams p) {
       const uint32_t* packed = cold_params()->packed;
       const uint32_t* __restrict__ gp = packed + ((RAW ? mp.pattern_offset : mp.pattern_offset_packed) >> 2);
       const uint32_t* __restrict__ gt = packed + ((RAW ? mp.text_offset : mp.text_offset_packed) >> 2);
-      for (int i = tid; i < pwords; i += NT) Pw[i] = gp[i];
-      for (int i = tid; i < twords; i += NT) Tw[i] = gt[i];
+      const char* const ascii = RAW ? nullptr : cold_params()->ascii;
+      if (!RAW && ascii != nullptr) {
+        // The batch is still ASCII (a resident batch that nobody packed): pack while staging -- 16 bytes in, one word to LDS and the
+        // same word to the packed buffer, where the backtrace kernels will look for it.  (A pack kernel of its own reads 2 GB and
+        // writes 0.5 GB per 1M x 1 kbp pairs before the first wavefront kernel can start: 0.63 ms; here the bytes arrive under the
+        // arithmetic of the other wavefronts.)  Every launch does it for the pairs it stages: packing twice is harmless.
+        const uint32_t* pa = plen ? reinterpret_cast<const uint32_t*>(ascii + mp.pattern_offset) : packed;      // (empty: fully masked loads, any safe address)
+        const uint32_t* ta = tlen ? reinterpret_cast<const uint32_t*>(ascii + mp.text_offset) : packed;
+        uint32_t* const wp = const_cast<uint32_t*>(gp); uint32_t* const wt = const_cast<uint32_t*>(gt);
+        uint32_t bad = 0;
+        for (int i = tid; i < pwords; i += NT) { const uint32_t w = wfa_pack::pack_word(wfa_pack::load_word(pa, (uint32_t)plen, (uint32_t)i), (uint32_t)plen, (uint32_t)i, bad); Pw[i] = w; wp[i] = w; }
+        for (int i = tid; i < twords; i += NT) { const uint32_t w = wfa_pack::pack_word(wfa_pack::load_word(ta, (uint32_t)tlen, (uint32_t)i), (uint32_t)tlen, (uint32_t)i, bad); Tw[i] = w; wt[i] = w; }
+        bool any_bad;
+        if constexpr (NW == 1) any_bad = __builtin_amdgcn_ballot_w64(bad != 0u) != 0ull;
+        else any_bad = __builtin_amdgcn_readfirstlane(__syncthreads_or(bad != 0u)) != 0;      // (the same in every thread: a scalar)
+        if (any_bad) {
+          // WFA2 compares raw bytes: this pair belongs to the byte-compare class, which runs after the packed one
+          if (tid == 0) {
+            ColdParams cp = cold_params();
+            atomicAdd(cp->n_raw, 1ull);
+            cp->score[pair] = -1;
+            cp->status[pair] = WFA_ST_ALPHABET;
+            if (cp->cells) cp->cells[pair] = 0;
+          }
+          block_sync<NW>();
+          continue;
+        }
+      } else {
+        for (int i = tid; i < pwords; i += NT) Pw[i] = gp[i];
+        for (int i = tid; i < twords; i += NT) Tw[i] = gt[i];
+      }
       {
         // Ring invariant: a row holds NULL everywhere outside the limits it was last written
         // with, so reads next to a row's ends need no predicate and no per-score guard fill.  It starts

@@ -59,6 +59,10 @@ enum : uint32_t { BT_M_NONE = 0, BT_M_X = 12, BT_M_D = 8, BT_M_I = 4, BT_M_MASK 
 // row of origin bytes per score (byte j = diagonal lo + j).
 struct WfaAlignParams {
   const uint32_t* packed;        // packed sequences (word base); RAW kernels: the ASCII buffer
+  const char* ascii;             // non-null (packed kernels only): the sequences are still ASCII -- pack them while they are staged: the words go
+                                 // to LDS and to `packed` (for the backtrace kernels); a pair with a byte outside ACGT leaves with status
+                                 // ALPHABET (counted in *n_raw) and is aligned by the byte-compare class afterwards
+  unsigned long long* n_raw;
   const WfaSeqPair* meta;
   const uint32_t* work;          // pair indices to process (NULL: identity)
   uint32_t n_work;

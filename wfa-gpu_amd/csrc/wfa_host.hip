@@ -464,7 +464,7 @@ bool plan_tier(const wfagpu_amd_ctx* c, WfaAlignParams& p, int max_score, unsign
   // Short wavefronts, score only (tier 5, short_kernel.hip): when the diagonal window of the budget fits 16 or 32 lanes, four or two
   // alignments share a wavefront and the rings live in registers (BASELINE configs[1]: 150 bp reads, budgets of ~14 once
   // they are tuned).  Pairs whose own window is wider (large |tlen - plen|) come back as BAND failures and go on as always.
-  if (!raw && c->tuning.min_tier == 0 && !(bt && c->tuning.no_short_cigar) && wfa_short_supported(p.x, p.oe, p.e) && width + 1 <= 32 && max_score <= 30000) {
+  if (!raw && !p.ascii && c->tuning.min_tier == 0 && !(bt && c->tuning.no_short_cigar) && wfa_short_supported(p.x, p.oe, p.e) && width + 1 <= 32 && max_score <= 30000) {
     const int lanes = width + 1 <= 16 ? 16 : 32;
     p.rs = 0;
     const size_t lds = wfa_short_lds_bytes(p, lanes, bt);
@@ -666,7 +666,13 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   HIP_TRY(hipMemsetAsync(c->counters.p, 0, CT_BYTES + 8 * 64, st));
   c->ct_used = 0;
   HIP_TRY(hipEventRecord(c->ev_start, st));
-  if (!prepacked) {
+  // Long enough reads are packed by the wavefront kernels themselves while they stage them (WfaAlignParams::ascii): no pack
+  // kernel in front of the first wavefront launch (0.63 ms per 1M x 1 kbp pairs).  Short reads keep the pack kernel: their tier
+  // (several alignments per wavefront, short_kernel.hip) prefetches packed words.
+  const bool fused_pack = !prepacked && b->max_seq_len >= 512u && !c->tuning.no_fused_pack;
+  ap.ascii = fused_pack ? b->d_sequences : nullptr;
+  ap.n_raw = ct + CT_NRAW;
+  if (!prepacked && !fused_pack) {
     // (ev_pack: the end of the pack kernel, stamped by its own dispatch packet -- wfa_launch_timed, wfa_device.h)
     wfa_launch_pack(b->d_sequences, ap.meta, n, static_cast<uint32_t*>(c->packed.p), static_cast<uint8_t*>(c->flags.p), st, b->max_seq_len, nullptr, c->ev_pack);
     LAUNCH_K(k_flag_alphabet, dim3(cdiv(n, 256)), dim3(256), 0, st, static_cast<const uint8_t*>(c->flags.p), n,
@@ -1208,7 +1214,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   }
   c->stats.cells = c->h_counters[CT_CELLS] - sample_cells_call;
   float ms = 0.f;
-  if (!prepacked) HIP_TRY(hipEventElapsedTime(&ms, c->ev_start, c->ev_pack));
+  if (!prepacked && !fused_pack) HIP_TRY(hipEventElapsedTime(&ms, c->ev_start, c->ev_pack));
   c->stats.pack_ms = ms;
   HIP_TRY(hipEventElapsedTime(&ms, c->ev_start, c->ev_end)); c->stats.total_ms = ms;
   // several arena-bound passes under a growable cap: the next call may use twice the arena

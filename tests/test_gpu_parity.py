@@ -754,6 +754,42 @@ def test_fallback_backtrace_paths(trace_mode):
         al.close()
 
 
+@pytest.mark.parametrize("min_tier", [0, 1, 2])
+def test_packing_while_staging(min_tier):
+    """Resident ASCII batches of reads of 512 bases and more have no pack kernel: the wavefront kernels pack the pairs they stage
+    (one wave, four waves, sixteen waves per alignment: tuning.min_tier) and send pairs with bytes outside ACGT -- N, lower case,
+    in the first word, the last one, in either sequence -- to the byte-compare class.  Same scores, CIGARs and byte-compare
+    counts as with the pack kernel (tuning.no_fused_pack), and the checker's."""
+    rng = random.Random(8800 + min_tier)
+    pairs = _rand_pairs(rng, 700, 1400, err=0.04)
+    pairs = [(p, t) for p, t in pairs if max(len(p), len(t)) >= 520][:500]
+    def spoil(seq, where):
+        b = bytearray(seq)
+        if b:
+            b[where % len(b)] = rng.choice(b"Nnacgt")
+        return bytes(b)
+    for i in range(0, len(pairs), 9):
+        p, t = pairs[i]
+        k = (i // 9) % 4
+        pairs[i] = (spoil(p, 0), t) if k == 0 else (p, spoil(t, len(t) - 1)) if k == 1 else (spoil(p, len(p) - 1), spoil(t, 3)) if k == 2 else (p, spoil(t, len(t) // 2))
+    pairs += [(b"", b"ACGT" * 150), (b"ACGT" * 150, b"")]
+    buf, meta = wfagpu.layout_pairs(pairs)
+    so, co, _ = oracle_lib.oracle_batch(buf, meta, (2, 3, 1), cigar=True, nthreads=8)
+    out, raws, packs = [], [], []
+    for no_fused in (0, 1):
+        al = wfagpu.DeviceAligner(0, min_tier=min_tier, no_fused_pack=no_fused)
+        try:
+            out.append(_run(al, buf, meta, (2, 3, 1), max_error=400))
+            st = al.stats()
+            raws.append(int(st.pairs_raw)); packs.append(float(st.pack_ms))
+        finally:
+            al.close()
+    for s, cg in out:
+        assert np.array_equal(s, so) and cg == co
+    assert raws[0] == raws[1] and raws[0] >= len(pairs) // 12, raws
+    assert packs[0] == 0.0 and packs[1] > 0.0, packs
+
+
 @pytest.mark.parametrize("cigar", [False, True])
 def test_misses_after_a_batch_without_any(cigar):
     """A stream of batches under inherited budgets: the speculative re-run launch of budget misses is left out once a batch had

@@ -754,6 +754,30 @@ def test_fallback_backtrace_paths(trace_mode):
         al.close()
 
 
+def test_rings_that_fill_lds_to_the_last_bytes():
+    """Score budgets swept in small steps across the point where the sixteen-wave ring stops fitting a CU's LDS: every plan on
+    either side must launch (a ring within the last 256 bytes of LDS once did not -- a static LDS word had crept into the
+    kernels -- and the failed occupancy query left an error behind that the next, perfectly good launch reported: found by
+    scratch/soak.py), scores exact."""
+    rng = random.Random(9090)
+    pairs = _rand_pairs(rng, 6, 2500, err=0.03)
+    pairs = [(p, t) for p, t in pairs if len(p) > 2000 and len(t) > 2000][:4] or pairs[:4]
+    buf, meta = wfagpu.layout_pairs(pairs)
+    pen = (3, 2, 5)
+    so, _, _ = oracle_lib.oracle_batch(buf, meta, pen, cigar=False, nthreads=4)
+    al = wfagpu.DeviceAligner(0, min_tier=2)
+    try:
+        batch = al.upload(buf, meta)
+        tiers = set()
+        for max_error in range(18600, 21400, 20):      # (20 scores = 4 diagonals = 160 bytes of ring: no 256-byte window is skipped)
+            s, _ = al.align(batch, pen, max_error=max_error, compute_cigar=False)
+            assert np.array_equal(s, so), max_error
+            tiers.add(int(al.stats().main_launch_tier))
+        assert len(tiers) >= 2, tiers      # (the sweep crossed from the whole ring in LDS to the hybrid ring)
+    finally:
+        al.close()
+
+
 @pytest.mark.parametrize("min_tier", [0, 1, 2])
 def test_packing_while_staging(min_tier):
     """Resident ASCII batches of reads of 512 bases and more have no pack kernel: the wavefront kernels pack the pairs they stage

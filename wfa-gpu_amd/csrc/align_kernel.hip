@@ -330,7 +330,15 @@ wfa_align_kernel(const WfaAlignParams p) {
         for (int i = tid; i < twords; i += NT) { const uint32_t w = wfa_pack::pack_word(wfa_pack::load_word(ta, (uint32_t)tlen, (uint32_t)i), (uint32_t)tlen, (uint32_t)i, bad); Tw[i] = w; wt[i] = w; }
         bool any_bad;
         if constexpr (NW == 1) any_bad = __builtin_amdgcn_ballot_w64(bad != 0u) != 0ull;
-        else any_bad = __builtin_amdgcn_readfirstlane(__syncthreads_or(bad != 0u)) != 0;      // (the same in every thread: a scalar)
+        else {
+          // (through a word of the workgroup's own LDS: __syncthreads_or brings 256 bytes of STATIC LDS with it, and a ring that
+          // fills the CU's LDS to the last bytes no longer fits -- found by the soak: the occupancy query of such a launch failed)
+          if (tid == 0) bslot[1] = 0u;
+          __syncthreads();
+          if (bad != 0u) bslot[1] = 1u;
+          __syncthreads();
+          any_bad = __builtin_amdgcn_readfirstlane(bslot[1]) != 0u;      // (the same in every thread: a scalar)
+        }
         if (any_bad) {
           // WFA2 compares raw bytes: this pair belongs to the byte-compare class, which runs after the packed one
           if (tid == 0) {
@@ -536,7 +544,10 @@ int occ_inst(size_t lds) {
   auto k = wfa_align_kernel<NW, BT, OffT, GR, RAW, BANDED, HYBRID, WPE>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k), NW * 64, lds) != hipSuccess) nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k), NW * 64, lds) != hipSuccess) {
+    nb = 0;
+    (void)hipGetLastError();      // (a plan that does not fit is an answer, not an error the next launch should trip over)
+  }
   return nb;
 }
 

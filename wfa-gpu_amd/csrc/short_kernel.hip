@@ -337,7 +337,7 @@ void launch_short(const WfaAlignParams& p, int grid, hipStream_t stream, hipEven
 template <int L, int X, int OE, bool BT>
 int occ_short(size_t lds) {
   int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(wfa_short_kernel<L, X, OE, BT>), 64, lds) != hipSuccess) nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(wfa_short_kernel<L, X, OE, BT>), 64, lds) != hipSuccess) { nb = 0; (void)hipGetLastError(); }
   return nb;
 }
 

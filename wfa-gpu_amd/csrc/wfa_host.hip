@@ -809,7 +809,14 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
           if (cigar_now) LAUNCH_K(k_bump, dim3(1), dim3(64), 0, st, ap.arena_top, (unsigned long long)n_cur * wfa_short_bt_slot_units(ap.max_score, tp.wpe), ap.arena_units);
         }
         else wfa_launch_align(ap, tp.tier, cigar_now, raw, grid, st, tp.wpe, L.e0, L.e1);
-        HIP_TRY(hipGetLastError());
+        {
+          const hipError_t le = hipGetLastError();
+          if (le != hipSuccess) {
+            fprintf(stderr, "[!] ERROR: wavefront launch failed: %s (tier %d, grid %d, LDS %zu bytes, %u pairs, score limit %d, window %d, band %d, cigar %d, raw %d)\n",
+                    hipGetErrorString(le), tp.tier, grid, tp.lds, n_cur, max_score, tp.width, ap.band_width, (int)cigar_now, (int)raw);
+            return -1;
+          }
+        }
         uint32_t* nxt = spare[flip]; flip ^= 1;
         LAUNCH_K(k_compact, dim3(cdiv(n_cur, compact_block(n_cur))), dim3(compact_block(n_cur)), 0, st, (const uint32_t*)cur, n_cur, cur_len_dev,
                            static_cast<const uint32_t*>(c->status.p), MASK(WFA_ST_BAND) | MASK(WFA_ST_SCORE), nxt, ct + L.ct_list, ap.work_counter);

@@ -34,8 +34,11 @@ typedef struct {
     int waves_per_simd;    /* one-wave exact kernels: force the instantiation compiled for 8, 7, 6 or 4 waves per SIMD
                               (0: matched to the rings LDS lets a CU hold)                                               */
     int trace_mode;        /* 0: automatic; 1: lane-per-alignment walk + windowed emit whatever the length (the fallback
-                              of the wave-per-alignment kernel); 2: never several alignments per wavefront; 3: never the
-                              one-kernel backtrace of short alignments (walk + emit + compaction instead: A/B)           */
+                              of the wave-per-alignment kernel); 2: the wave-per-alignment kernel does the whole backtrace
+                              (never several alignments per wavefront, never walk there + replay in the lane kernel); 3: never
+                              the one-kernel backtrace of short alignments (walk + emit + compaction instead: A/B); 4: long
+                              alignments walked by the wave-per-alignment kernel and replayed by the lane kernel whatever the
+                              size of the pass (default: passes of 8192 alignments and more)                              */
     int timed_barriers;    /* diagnostics: the multi-wave exact CIGAR tiers (1 and 4) run an instantiation in which workgroup 0
                               records when each of its waves reaches and leaves the per-score barrier (s_memtime);
                               wfagpu_amd_debug_times() hands the records out                                              */
@@ -107,6 +110,8 @@ typedef struct {
     int sample_launches;
     unsigned int sample_passes;
     int waves_per_simd_tier0;          /* instantiation the first wavefront launch used (one-wave exact kernels: 8, 7, 6 or 4) */
+    unsigned int pairs_trace_split;    /* long alignments whose backtrace was walked by the wave-per-alignment kernel and replayed by
+                                          the lane-per-alignment kernel (passes of 8192 and more; tuning.trace_mode 4: any)        */
 } wfagpu_amd_stats_t;
 
 /* 0 on success, negative on error (message on stderr). */

@@ -52,7 +52,8 @@ for it in range(iters):
     buf, meta = wfagpu.layout_pairs(pairs)
     so, co, _ = oracle_lib.oracle_batch(buf, meta, pen, cigar=True, nthreads=16)
     min_tier = rng.randint(1, 4) if rng.random() < 0.25 else 0
-    al.set_tuning(min_tier=min_tier)
+    # (the backtrace of long alignments: automatic, all of it in the wave-per-alignment kernel, or walk there + replay by lanes)
+    al.set_tuning(min_tier=min_tier, trace_mode=rng.choice([0, 0, 2, 4, 4]))
     # (every other clean set arrives packed on the host: wfagpu_amd_batch_t::d_packed, no ASCII on the device)
     clean = all(set(p) <= set(b"ACGT") and set(t) <= set(b"ACGT") for p, t in pairs)
     batch = al.upload_packed(buf, meta) if clean and rng.random() < 0.5 else al.upload(buf, meta)

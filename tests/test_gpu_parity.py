@@ -754,6 +754,28 @@ def test_fallback_backtrace_paths(trace_mode):
         al.close()
 
 
+def test_long_alignments_walked_by_wavefronts_and_replayed_by_lanes():
+    """Big passes of long alignments (8192 and more; tuning.trace_mode 4: any size): the wave-per-alignment kernel only walks and
+    leaves its op lists in slots of the global scratch, the lane kernel replays eight and more alignments per wavefront with
+    sequences AND op lists staged in LDS, the texts are compacted.  Ragged lengths, scores from 0 to thousands, an empty
+    pattern, a budget most pairs miss (they finish in the wider tiers, in passes of their own); penalties with a costly
+    extension.  Same scores and CIGARs as WFA2."""
+    rng = random.Random(424242)
+    pairs = (_rand_pairs(rng, 150, 4000, err=0.08) + _rand_pairs(rng, 60, 2000, err=0.15) + _rand_pairs(rng, 40, 3000, err=0.0)
+             + [(b"", b"ACGT" * 600), (b"ACGT" * 900, b"ACGT" * 650), (b"A" * 3000, b"C" * 3000)])
+    buf, meta = wfagpu.layout_pairs(pairs)
+    for pen, max_error in (((2, 3, 1), 4000), ((4, 6, 2), 20000), ((2, 3, 1), 700)):
+        so, co, _ = oracle_lib.oracle_batch(buf, meta, pen, cigar=True, nthreads=8)
+        al = wfagpu.DeviceAligner(0, trace_mode=4)
+        try:
+            s, cg = _run(al, buf, meta, pen, max_error=max_error)
+            assert np.array_equal(s, so), (pen, max_error)
+            assert cg == co, (pen, max_error)
+            assert al.stats().pairs_trace_split >= len(pairs) // 2
+        finally:
+            al.close()
+
+
 def test_rings_that_fill_lds_to_the_last_bytes():
     """Score budgets swept in small steps across the point where the sixteen-wave ring stops fitting a CU's LDS: every plan on
     either side must launch (a ring within the last 256 bytes of LDS once did not -- a static LDS word had crept into the

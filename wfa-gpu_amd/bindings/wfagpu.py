@@ -84,7 +84,7 @@ class Stats(C.Structure):  # wfagpu_amd_stats_t
                 ("main_launch_ms", C.c_float), ("main_launch_tier", C.c_int), ("main_launch_pairs", C.c_uint),
                 ("main_launch_cells", C.c_ulonglong), ("main_launch_seq_bytes", C.c_ulonglong),
                 ("sample_cells", C.c_ulonglong), ("sample_launches", C.c_int), ("sample_passes", C.c_uint),
-                ("waves_per_simd_tier0", C.c_int)]
+                ("waves_per_simd_tier0", C.c_int), ("pairs_trace_split", C.c_uint)]
 
 
 ABI_SYMBOLS = [

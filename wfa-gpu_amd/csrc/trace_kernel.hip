@@ -179,7 +179,8 @@ struct RleSink {
   }
 };
 
-template <bool RAW, typename PV, typename TV>
+// (OPS_LDS: the op list is in LDS -- said explicitly, a pointer that was global or LDS by a run-time choice loads with flat_load)
+template <bool RAW, bool OPS_LDS = false, typename PV, typename TV>
 __device__ __forceinline__ uint32_t replay_views(const uint8_t* ops, uint32_t nops, PV& Pw, TV& Tw,
                                                  int plen, int tlen, char* out, int x, int o, int e, int* cost,
                                                  uint32_t out_cap = 0xFFFFFFFFu, bool words = false) {
@@ -189,12 +190,17 @@ __device__ __forceinline__ uint32_t replay_views(const uint8_t* ops, uint32_t no
   sink.push('M', (uint32_t)n); v += n; h += n;
   // The op list is consumed four ops per aligned 32-bit load: with one byte load per step every iteration of every lane
   // waited a full round trip to L2 (that, not the LCPs, was most of the emit kernel's time).
-  const uint32_t* ops4 = reinterpret_cast<const uint32_t*>(reinterpret_cast<uintptr_t>(ops) & ~(uintptr_t)3);
+  // (the aligned pointer by pointer arithmetic: through an integer it loses its address space and every load becomes a flat_load)
   const uint32_t skip = (uint32_t)(reinterpret_cast<uintptr_t>(ops) & 3);
-  uint32_t word = nops ? (*ops4 >> (8 * skip)) : 0u;
+  const uint32_t* ops4 = reinterpret_cast<const uint32_t*>(ops - skip);
+  auto op_word = [&](uint32_t idx) -> uint32_t {
+    if constexpr (OPS_LDS) return ((const __attribute__((address_space(3))) uint32_t*)ops4)[idx];
+    else return ops4[idx];
+  };
+  uint32_t word = nops ? (op_word(0) >> (8 * skip)) : 0u;
   for (uint32_t i = 0; i < nops; ++i) {
     const uint32_t op = word & 0xFFu;
-    if (((i + 1 + skip) & 3u) == 0u) { if (i + 1 < nops) word = ops4[(i + 1 + skip) >> 2]; } else word >>= 8;
+    if (((i + 1 + skip) & 3u) == 0u) { if (i + 1 < nops) word = op_word((i + 1 + skip) >> 2); } else word >>= 8;
     {
       // (one push for the three kinds of operation: the lanes of a wavefront hold all of them at once)
       const uint32_t k3 = op & 3u;
@@ -213,12 +219,12 @@ __device__ __forceinline__ uint32_t replay_views(const uint8_t* ops, uint32_t no
   return (v == plen && h == tlen) ? sink.len : 0xFFFFFFFFu;
 }
 
-template <bool RAW>
+template <bool RAW, bool OPS_LDS = false>
 __device__ __forceinline__ uint32_t replay(const uint8_t* ops, uint32_t nops, const uint32_t* Pw, const uint32_t* Tw,
                                            int plen, int tlen, char* out, int x, int o, int e, int* cost,
                                            uint32_t out_cap = 0xFFFFFFFFu, bool words = false) {
   SeqDirect pv{Pw}, tv{Tw};
-  return replay_views<RAW>(ops, nops, pv, tv, plen, tlen, out, x, o, e, cost, out_cap, words);
+  return replay_views<RAW, OPS_LDS>(ops, nops, pv, tv, plen, tlen, out, x, o, e, cost, out_cap, words);
 }
 
 constexpr int TRACE_THREADS = 64;
@@ -401,8 +407,10 @@ __device__ __forceinline__ void stage_pairs(const WfaTraceParams& p, const int P
     for (int i0 = 0; i0 < maxw; i0 += 64) {
       const int i = i0 + lane;
       uint32_t a[SG], b[SG];
+      // (pointers rebuilt from two scalars have no address space: said here, or every one of these loads is a flat_load)
+      using GlobalWords = const __attribute__((address_space(1))) uint32_t*;
 #pragma unroll
-      for (int u = 0; u < SG; ++u) { a[u] = i < pwj[u] ? gp[u][i] : 0u; b[u] = i < twj[u] ? gt[u][i] : 0u; }
+      for (int u = 0; u < SG; ++u) { a[u] = i < pwj[u] ? ((GlobalWords)gp[u])[i] : 0u; b[u] = i < twj[u] ? ((GlobalWords)gt[u])[i] : 0u; }
 #pragma unroll
       for (int u = 0; u < SG; ++u) {
         uint32_t* dst = seq_lds + (size_t)(j0 + u) * stride;
@@ -480,7 +488,7 @@ __global__ void __launch_bounds__(TRACE_THREADS) wfa_trace_lane_kernel(const Wfa
 // pair at a time by the whole wavefront), so the many small reads of the replay never leave the CU.  (Reading the packed
 // sequences straight from global memory made every 4-byte read miss L1 and L2 -- the working set of all resident lanes
 // is far larger than both: 57 GB fetched per 1M pairs in round 1.)
-template <bool SEQ_LDS>
+template <bool SEQ_LDS, bool OPS_LDS>
 __global__ void __launch_bounds__(TRACE_THREADS) wfa_emit_kernel(const WfaTraceParams p) {
   static_assert(SEQ_LDS, "sequences that do not fit LDS go through wfa_emit_win_kernel or wfa_trace_wave_kernel");
   extern __shared__ __attribute__((aligned(16))) uint32_t seq_lds[];
@@ -509,6 +517,26 @@ __global__ void __launch_bounds__(TRACE_THREADS) wfa_emit_kernel(const WfaTraceP
     fail = nops == 0xFFFFFFFFu;
   }
   if constexpr (SEQ_LDS) stage_pairs(p, PPW, lane, active, plen, tlen, Pw, Tw, seq_lds);
+  const uint8_t* q_lds = nullptr;
+  if constexpr (OPS_LDS) {
+    // long alignments (the wavefront kernel walked): the op lists -- thousands of operations, read four per load by ONE lane, a
+    // round trip to L2 each time -- come into LDS too, after the sequences, copied by the whole wavefront
+    uint32_t* const ops_l = seq_lds + (size_t)PPW * p.seq_lds_stride;
+    const uint32_t lwords = ((p.ops_slot >> 2) + 1u) | 1u;
+    const uint32_t my_words = (active && !fail) ? (nops + (uint32_t)(reinterpret_cast<uintptr_t>(q) & 3) + 3u) >> 2 : 0u;
+    const uint32_t* const my_src = reinterpret_cast<const uint32_t*>(reinterpret_cast<uintptr_t>(q) & ~(uintptr_t)3);
+    using GlobalWords = const __attribute__((address_space(1))) uint32_t*;
+    for (int j = 0; j < PPW; ++j) {
+      const uint32_t nw = __builtin_amdgcn_readlane(my_words, j);
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(reinterpret_cast<unsigned long long>(my_src) >> 32), j) << 32) |
+                                                              (uint32_t)__builtin_amdgcn_readlane((int)reinterpret_cast<unsigned long long>(my_src), j));
+      uint32_t* dst = ops_l + (size_t)j * lwords;
+      for (uint32_t i = lane; i < nw; i += 64) dst[i] = ((GlobalWords)src)[i];
+    }
+    __syncthreads();
+    // (a variable of its own: `q` stays a pointer to global memory for the compiler, this one a pointer to LDS)
+    q_lds = reinterpret_cast<const uint8_t*>(ops_l + (size_t)lane * lwords) + (reinterpret_cast<uintptr_t>(q) & 3);
+  }
   if (p.text_scratch) {
     // single replay: the text goes to this lane's slot of the scratch (sized by the same bound the host sizes the arenas
     // with: at most score / min(x, e) operations, each with a match run, item_chars characters per item); wfa_text_compact_kernel
@@ -520,8 +548,12 @@ __global__ void __launch_bounds__(TRACE_THREADS) wfa_emit_kernel(const WfaTraceP
       uint32_t len = 0xFFFFFFFFu;
       if (!fail) {
         int cost = 0;
-        len = p.raw ? replay<true>(q, nops, Pw, Tw, plen, tlen, p.text_scratch + s_off, p.x, p.oe - p.e, p.e, &cost, bound, true)
-                    : replay<false>(q, nops, Pw, Tw, plen, tlen, p.text_scratch + s_off, p.x, p.oe - p.e, p.e, &cost, bound, true);
+        if constexpr (OPS_LDS)
+          len = p.raw ? replay<true, true>(q_lds, nops, Pw, Tw, plen, tlen, p.text_scratch + s_off, p.x, p.oe - p.e, p.e, &cost, bound, true)
+                      : replay<false, true>(q_lds, nops, Pw, Tw, plen, tlen, p.text_scratch + s_off, p.x, p.oe - p.e, p.e, &cost, bound, true);
+        else
+          len = p.raw ? replay<true>(q, nops, Pw, Tw, plen, tlen, p.text_scratch + s_off, p.x, p.oe - p.e, p.e, &cost, bound, true)
+                      : replay<false>(q, nops, Pw, Tw, plen, tlen, p.text_scratch + s_off, p.x, p.oe - p.e, p.e, &cost, bound, true);
         if (len != 0xFFFFFFFFu && len + 1u > bound) len = 0xFFFFFFFFu;
         if (len != 0xFFFFFFFFu && cost != p.score[pair]) {
           if (p.score_fix) p.score_fix[pair] = cost;
@@ -631,9 +663,15 @@ template <bool RAW>
 __global__ void __launch_bounds__(TRACE_THREADS) wfa_trace_wave_kernel(const WfaTraceParams p) {
   extern __shared__ __attribute__((aligned(16))) uint32_t wlds[];
   const int lane = threadIdx.x & 63;
+  // WALK ONLY (p.walk_only): the wavefront walks -- tiles, below -- and leaves the op list in the global scratch (slot w of
+  // p.ops_slot bytes, no allocation); the replay is the lane-per-alignment kernel's, with the sequences of a few pairs per
+  // wavefront staged in LDS (wfa_emit_kernel).  A replay is one serial chain per alignment: here every one of the 64 lanes
+  // executed it (lane 0 stored), five such wavefronts per SIMD taking turns on the vector pipe; there, 8-16 alignments share a
+  // wavefront and the pipe is nearly idle.  No sequences in this kernel's LDS then: 1 KB of tile + the op list.
+  const int seq_cap = p.walk_only ? 0 : p.seq_words_cap;
   uint32_t* Pw = wlds;
-  uint32_t* Tw = Pw + p.seq_words_cap;
-  uint8_t* tile = reinterpret_cast<uint8_t*>(Tw + p.seq_words_cap);     // [64 rows][16 bytes]
+  uint32_t* Tw = Pw + seq_cap;
+  uint8_t* tile = reinterpret_cast<uint8_t*>(Tw + seq_cap);     // [64 rows][16 bytes]
   uint8_t* ops_lds = tile + 64 * 16;                                    // [ops_lds_bytes]
   char* text_lds = reinterpret_cast<char*>(ops_lds + p.ops_lds_bytes);  // [text_lds_bytes]
   constexpr int TILE_W = 16, TILE_H = 64;
@@ -645,7 +683,7 @@ __global__ void __launch_bounds__(TRACE_THREADS) wfa_trace_wave_kernel(const Wfa
     const int score = __builtin_amdgcn_readfirstlane(p.score[pair]);
     const int sh = RAW ? 2 : 4;
     const int pwords = ((plen + (1 << sh) - 1) >> sh) + 1, twords = ((tlen + (1 << sh) - 1) >> sh) + 1;
-    {
+    if (!p.walk_only) {
       const uint32_t* gp = p.packed + ((RAW ? mp.pattern_offset : mp.pattern_offset_packed) >> 2);
       const uint32_t* gt = p.packed + ((RAW ? mp.text_offset : mp.text_offset_packed) >> 2);
       for (int i = lane; i < pwords; i += 64) Pw[i] = gp[i];
@@ -658,12 +696,15 @@ __global__ void __launch_bounds__(TRACE_THREADS) wfa_trace_wave_kernel(const Wfa
     bool fail = false;
     uint8_t* q_begin = ops_lds;
     if (need_ops > (uint32_t)p.ops_lds_bytes) {
-      unsigned long long ops_off = 0;
-      if (lane == 0) ops_off = atomicAdd(p.ops_top, (unsigned long long)need_ops);
-      ops_off = shfl64(ops_off, 0);
+      unsigned long long ops_off = (unsigned long long)w * p.ops_slot;       // (walk only: slot w, no allocation)
+      if (!p.walk_only) {
+        if (lane == 0) ops_off = atomicAdd(p.ops_top, (unsigned long long)need_ops);
+        ops_off = shfl64(ops_off, 0);
+      }
       fail = ops_off + need_ops > p.ops_cap;
       q_begin = p.ops + ops_off;
     }
+    if (p.walk_only && need_ops > p.ops_slot) fail = true;
     uint8_t* const q_end = q_begin + need_ops;
     uint8_t* q = q_end;
     if (!fail) {
@@ -720,6 +761,17 @@ __global__ void __launch_bounds__(TRACE_THREADS) wfa_trace_wave_kernel(const Wfa
     __threadfence_block();
     __builtin_amdgcn_wave_barrier();
     const uint32_t nops = (uint32_t)(q_end - q);
+    if (p.walk_only) {
+      // the list goes to (or is already in) this work item's slot of the global scratch, where wfa_emit_kernel looks for it
+      uint8_t* const g_end = p.ops + (size_t)w * p.ops_slot + need_ops;
+      if (!fail && q_begin == ops_lds) { for (uint32_t i = lane; i < nops; i += 64) g_end[(long)i - (long)nops] = q[i]; }
+      if (lane == 0) {
+        p.cigar_off[pair] = fail ? 0ull : (unsigned long long)(g_end - nops - p.ops);
+        p.cigar_len[pair] = fail ? 0xFFFFFFFFu : nops;
+      }
+      __builtin_amdgcn_wave_barrier();
+      continue;
+    }
     // One replay writes the text into LDS (every lane follows along, lane 0 stores); its length then buys the space
     // in the dense text arena and all 64 lanes copy it out.  A text longer than the LDS buffer is replayed once more,
     // straight into the arena.
@@ -918,7 +970,8 @@ void launch_group(const WfaTraceParams& p, hipStream_t stream, hipEvent_t ev0, h
 
 template <bool RAW>
 void launch_wave(const WfaTraceParams& p, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
-  const size_t lds = (size_t)2 * p.seq_words_cap * 4 + 64 * 16 + (size_t)p.ops_lds_bytes + (size_t)p.text_lds_bytes;
+  const size_t lds = p.walk_only ? (size_t)64 * 16 + (size_t)p.ops_lds_bytes
+                                 : (size_t)2 * p.seq_words_cap * 4 + 64 * 16 + (size_t)p.ops_lds_bytes + (size_t)p.text_lds_bytes;
   const uint32_t grid = p.n_work < 8192u ? p.n_work : 8192u;
   static thread_local size_t allowed[16] = {0};
   allow_lds(wfa_trace_wave_kernel<RAW>, lds, allowed);
@@ -939,8 +992,20 @@ bool wfa_launch_trace(const WfaTraceParams& p, hipStream_t stream, hipEvent_t ev
     }
     return true;
   }
-  if (p.wave_kernel) {
+  if (p.wave_kernel && !p.walk_only) {
     if (p.raw) launch_wave<true>(p, stream, ev0, ev1); else launch_wave<false>(p, stream, ev0, ev1);
+    return true;
+  }
+  if (p.wave_kernel) {
+    // long alignments: the wavefront kernel walks, the lane kernel replays (a few pairs per wavefront staged in LDS)
+    if (p.raw) launch_wave<true>(p, stream, ev0, (hipEvent_t) nullptr); else launch_wave<false>(p, stream, ev0, (hipEvent_t) nullptr);
+    const size_t lds_e = (size_t)p.emit_pairs * ((size_t)p.seq_lds_stride * 4 + (size_t)((((p.ops_slot >> 2) + 1u) | 1u) * 4u));
+    static thread_local size_t allowed_e[16] = {0};
+    allow_lds(wfa_emit_kernel<true, true>, lds_e, allowed_e);
+    const dim3 grid_e((p.n_work + (uint32_t)p.emit_pairs - 1) / (uint32_t)p.emit_pairs);
+    wfa_launch_timed(wfa_emit_kernel<true, true>, grid_e, dim3(TRACE_THREADS), lds_e, stream, (hipEvent_t) nullptr, p.text_scratch ? (hipEvent_t) nullptr : ev1, p);
+    if (p.text_scratch)
+      wfa_launch_timed(wfa_text_compact_kernel, dim3((p.n_work + COMPACT_WAVES * 64 - 1) / (COMPACT_WAVES * 64)), dim3(COMPACT_WAVES * 64), 0, stream, (hipEvent_t) nullptr, ev1, p);
     return true;
   }
   const dim3 grid((p.n_work + TRACE_THREADS - 1) / TRACE_THREADS), block(TRACE_THREADS);
@@ -961,9 +1026,9 @@ bool wfa_launch_trace(const WfaTraceParams& p, hipStream_t stream, hipEvent_t ev
   }
   const size_t lds = (size_t)p.emit_pairs * p.seq_lds_stride * 4;
   static thread_local size_t allowed[16] = {0};
-  allow_lds(wfa_emit_kernel<true>, lds, allowed);
+  allow_lds(wfa_emit_kernel<true, false>, lds, allowed);
   const dim3 grid_e((p.n_work + (uint32_t)p.emit_pairs - 1) / (uint32_t)p.emit_pairs);
-  wfa_launch_timed(wfa_emit_kernel<true>, grid_e, block, lds, stream, (hipEvent_t) nullptr, p.text_scratch ? (hipEvent_t) nullptr : ev1, p);
+  wfa_launch_timed(wfa_emit_kernel<true, false>, grid_e, block, lds, stream, (hipEvent_t) nullptr, p.text_scratch ? (hipEvent_t) nullptr : ev1, p);
   if (p.text_scratch)
     wfa_launch_timed(wfa_text_compact_kernel, dim3((p.n_work + COMPACT_WAVES * 64 - 1) / (COMPACT_WAVES * 64)), dim3(COMPACT_WAVES * 64), 0, stream, (hipEvent_t) nullptr, ev1, p);
   return true;

@@ -910,6 +910,32 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
             for (int g = 8; g >= 2; g >>= 1)
               if ((share + (size_t)(64 / g) * 16 + 16) * g <= (40u << 10) && n_chain >= (uint32_t)g * 1024u) { tp.group = g; break; }
         }
+        // LONG alignments, one wavefront each: the wavefront kernel only walks; the replay is the staged lane-per-alignment kernel's
+        // with as many pairs per wavefront (8, 16, ...) as fit LDS next to three more wavefronts (a replay is one serial chain:
+        // run by a whole wavefront it is 64 lanes executing the same chain).  Op lists in slots of the largest score of the pass.
+        tp.walk_only = 0;
+        const unsigned long long slot = ((unsigned long long)c->h_counters[CT_MAX_SCORE] + 3ull) & ~3ull;
+        const size_t per_pair = (size_t)stride * 4 + (size_t)slot + 8;      // LDS of one alignment of the replay: sequences + op list
+        // (big passes only: a replay step takes a lane of the lane kernel -- its neighbours in other branches -- 1.3 us against the 0.4 us
+        // of a wavefront with a SIMD to itself; with thousands of alignments the wavefronts share SIMDs five at a time and the lanes
+        // win: 16 384 x 10 kbp at 3 %, trace 2.22 -> 2.04 ms.  tuning.trace_mode 4: whatever the size of the pass -- tests)
+        if (tp.wave_kernel && tp.group == 1 && c->tuning.trace_mode != 2 && (n_chain >= 8192u || c->tuning.trace_mode == 4) &&
+            8 * per_pair <= c->lds_per_block_max) {
+          if ((unsigned long long)n_chain * slot <= (1ull << 30)) {
+            if (c->ops.ensure((unsigned long long)n_chain * slot + 256, st)) return -1;
+            tp.walk_only = 1; tp.ops_slot = (uint32_t)slot;
+            c->stats.pairs_trace_split += n_chain;
+            tp.seq_lds_stride = (int)stride;
+            tp.emit_pairs = 8;
+            while (tp.emit_pairs < 64 && (size_t)(tp.emit_pairs + 8) * per_pair * 4 <= c->lds_per_block_max) tp.emit_pairs += 8;
+            const int forced = c->tuning.emit_pairs;
+            if (forced >= 8 && forced <= 64 && (size_t)(forced & ~7) * per_pair <= c->lds_per_block_max) tp.emit_pairs = forced & ~7;
+            // (the walk keeps its op list in LDS when it fits: ops_lds_bytes from above, without the sequences)
+            const size_t smax = (size_t)c->h_counters[CT_MAX_SCORE];
+            tp.ops_lds_bytes = (int)(smax + 16 <= (39u << 10) ? ((smax + 15) & ~(size_t)15) : 0);
+            tp.text_lds_bytes = 0;
+          }
+        }
         // SHORT alignments (no pair of the chain finished above a score of 124): walk and replay in one kernel, op lists in LDS
         tp.lane_fused = 0;
         if (!tp.wave_kernel && tp.seq_lds_stride > 0 && s_hi >= 0 && s_hi <= 124 && c->tuning.trace_mode != 3) {
@@ -931,7 +957,9 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         tp.item_chars = item_chars;
         // lane-per-alignment emit with whole sequences staged: one replay into a scratch + compaction (big passes only: the
         // scratch holds the upper bounds, ~3x the text)
-        if (!tp.wave_kernel && !tp.lane_fused && tp.seq_lds_stride > 0 && n_chain >= 8192u) {
+        // (long alignments replayed by the lane kernel -- walk_only -- always: a second replay of hundreds of operations costs more than
+        // the compaction launch)
+        if (((!tp.wave_kernel && n_chain >= 8192u) || tp.walk_only) && !tp.lane_fused && tp.seq_lds_stride > 0) {
           if (c->text_scratch.ensure(text_sum + 4096, st)) return -1;
           if (zero_counter(c, CT_SCRATCH)) return -1;
           tp.text_scratch = static_cast<char*>(c->text_scratch.p); tp.text_scratch_cap = c->text_scratch.cap; tp.scratch_top = ct + CT_SCRATCH;

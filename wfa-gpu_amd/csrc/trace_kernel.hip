@@ -289,9 +289,8 @@ __device__ __forceinline__ bool walk_ops(const WfaTraceParams& p, const uint32_t
   return !fail;
 }
 
-// Phase 1 kernel: backward walk over the origin bytes, one lane per alignment, no LDS: it is a
-// chain of dependent HBM reads, so it wants every wave slot of the CU.  Leaves the op list of
-// each pair in the scratch arena (ops_off/nops per pair).
+// Phase 1 kernel: backward walk over the origin bytes, one lane per alignment: a chain of dependent HBM reads.  Leaves the op
+// list of each pair in the scratch arena (ops_off/nops per pair).
 constexpr int WALK_WAVES = 4;      // (wavefronts per workgroup: they share the allocation of their op lists, block_alloc)
 __global__ void __launch_bounds__(WALK_WAVES * 64) wfa_walk_kernel(const WfaTraceParams p) {
   // The walk is bound by memory TRANSACTIONS (one dependent 64-byte access per step, half a million lanes in flight: no
@@ -301,28 +300,35 @@ __global__ void __launch_bounds__(WALK_WAVES * 64) wfa_walk_kernel(const WfaTrac
   __shared__ uint2 tab_cache[WALK_WAVES * 64][9];          // [thread][entry & 7] (9: bank spread)
   __shared__ uint32_t wave_total[WALK_WAVES];
   __shared__ unsigned long long block_base;
-  const uint32_t gid = blockIdx.x * (WALK_WAVES * 64) + threadIdx.x;
-  bool active = gid < p.n_work;
-  uint32_t pair = 0;
-  if (active) pair = p.work ? p.work[gid] : gid;
-  if (active && p.status[pair] != WFA_ST_DONE) active = false;
-  int score = 0, plen = 0, tlen = 0;
-  if (active) {
-    score = p.score[pair];
-    plen = (int)p.meta[pair].pattern_len; tlen = (int)p.meta[pair].text_len;
-  }
-  // every operation costs at least min(x, e) >= 1, so `score` bytes suffice
-  const uint32_t need_ops = active ? (((uint32_t)score + 3u) & ~3u) : 0u;
-  const unsigned long long ops_off = block_alloc<WALK_WAVES>(p.ops_top, need_ops, wave_total, &block_base);
-  bool fail = active && (ops_off + need_ops > p.ops_cap);
-  uint8_t* const q_begin = p.ops + ops_off;
-  uint8_t* const q_end = q_begin + need_ops;       // (4-byte aligned: the allocations are multiples of 4)
-  uint32_t nops = 0;
-  if (active && !fail) fail = !walk_ops(p, pair, score, plen, tlen, q_end, need_ops, tab_cache[threadIdx.x], nops);
-  if (active) {
-    // the op list now sits at [q_end - nops, q_end); cigar_off/cigar_len carry it to the emit kernel
-    p.cigar_off[pair] = (unsigned long long)(q_end - nops - p.ops);
-    p.cigar_len[pair] = fail ? 0xFFFFFFFFu : nops;
+  // A grid of two workgroups (eight wavefronts) per CU strides over the list (WfaTraceParams::walk_grid_cap): HBM serves no more
+  // random 64-byte accesses with 32 wavefronts per CU than with 8, and with every wave slot taken the time of the kernel fell
+  // into one of two modes by process (1M x 1 kbp, trace ms per batch at 32 / 16 / 12 / 8 wavefronts per CU: 3.14-3.32 /
+  // 3.17-3.25 / 3.09-3.25 / 3.17 every time -- profiles/r04/trace_slices.txt).
+  for (uint32_t first = blockIdx.x * (WALK_WAVES * 64); first < p.n_work; first += gridDim.x * (WALK_WAVES * 64)) {
+    const uint32_t gid = first + threadIdx.x;
+    bool active = gid < p.n_work;
+    uint32_t pair = 0;
+    if (active) pair = p.work ? p.work[gid] : gid;
+    if (active && p.status[pair] != WFA_ST_DONE) active = false;
+    int score = 0, plen = 0, tlen = 0;
+    if (active) {
+      score = p.score[pair];
+      plen = (int)p.meta[pair].pattern_len; tlen = (int)p.meta[pair].text_len;
+    }
+    // every operation costs at least min(x, e) >= 1, so `score` bytes suffice
+    const uint32_t need_ops = active ? (((uint32_t)score + 3u) & ~3u) : 0u;
+    const unsigned long long ops_off = block_alloc<WALK_WAVES>(p.ops_top, need_ops, wave_total, &block_base);
+    bool fail = active && (ops_off + need_ops > p.ops_cap);
+    uint8_t* const q_begin = p.ops + ops_off;
+    uint8_t* const q_end = q_begin + need_ops;       // (4-byte aligned: the allocations are multiples of 4)
+    uint32_t nops = 0;
+    if (active && !fail) fail = !walk_ops(p, pair, score, plen, tlen, q_end, need_ops, tab_cache[threadIdx.x], nops);
+    if (active) {
+      // the op list now sits at [q_end - nops, q_end); cigar_off/cigar_len carry it to the emit kernel
+      p.cigar_off[pair] = (unsigned long long)(q_end - nops - p.ops);
+      p.cigar_len[pair] = fail ? 0xFFFFFFFFu : nops;
+    }
+    __syncthreads();      // (block_alloc's shared words are written again by the next round)
   }
 }
 
@@ -1019,7 +1025,9 @@ bool wfa_launch_trace(const WfaTraceParams& p, hipStream_t stream, hipEvent_t ev
     else { allow_lds(wfa_trace_lane_kernel<false>, lds, allowed[0]); wfa_launch_timed(wfa_trace_lane_kernel<false>, grid_f, block, lds, stream, ev0, ev1, p); }
     return true;
   }
-  wfa_launch_timed(wfa_walk_kernel, dim3((p.n_work + WALK_WAVES * 64 - 1) / (WALK_WAVES * 64)), dim3(WALK_WAVES * 64), 0, stream, ev0, (hipEvent_t) nullptr, p);
+  uint32_t walk_grid = (p.n_work + WALK_WAVES * 64 - 1) / (WALK_WAVES * 64);
+  if (p.walk_grid_cap > 0 && walk_grid > (uint32_t)p.walk_grid_cap) walk_grid = (uint32_t)p.walk_grid_cap;
+  wfa_launch_timed(wfa_walk_kernel, dim3(walk_grid), dim3(WALK_WAVES * 64), 0, stream, ev0, (hipEvent_t) nullptr, p);
   if (p.seq_lds_stride == 0) {      // (sequences too long to stage 64 pairs, or tuning.trace_mode 1: 8-word LDS windows)
     wfa_launch_timed(wfa_emit_win_kernel, grid, block, 0, stream, (hipEvent_t) nullptr, ev1, p);
     return true;

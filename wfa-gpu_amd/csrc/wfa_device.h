@@ -117,6 +117,7 @@ struct WfaTraceParams {
   int wave_kernel;               // 1: one wavefront per alignment (long alignments), 0: one lane per alignment
   int group;                     // wave kernel: alignments per wavefront (1, 2, 4 or 8: 64/group lanes each, own LDS share)
   int lane_fused;                // lane-per-alignment path: walk + replay in ONE kernel, op lists of ops_lds_bytes per lane in LDS (short alignments)
+  int walk_grid_cap;             // workgroups of wfa_walk_kernel (it strides over the list); 0: one per 256 list entries
   int walk_only;                 // wave kernel: only the walk (op list -> slot w of ops_slot bytes in the global scratch); wfa_emit_kernel replays
   uint32_t ops_slot;
   int seq_words_cap;             // wave kernel: LDS words reserved per sequence

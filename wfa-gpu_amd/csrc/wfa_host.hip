@@ -967,6 +967,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         tp.cigar_off = static_cast<unsigned long long*>(c->cig_off[c->out_set].p);
         tp.cigar_len = static_cast<uint32_t*>(c->cig_len[c->out_set].p);
         // (ev_t0 / ev_t1: start of the first and end of the last backtrace kernel)
+        tp.walk_grid_cap = 2 * c->num_cus;      // (two workgroups = eight wavefronts per CU: trace_kernel.hip, wfa_walk_kernel)
         traced = wfa_launch_trace(tp, st, c->ev_t0, c->ev_t1);
         HIP_TRY(hipGetLastError());
         // ---- pairs that ran out of arena go into the next pass (CIGAR calls only: score-only calls have no arena) ----

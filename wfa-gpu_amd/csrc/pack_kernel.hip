@@ -29,7 +29,8 @@ constexpr int PACK_WAVES = 4;
 template <int L>
 __global__ void __launch_bounds__(PACK_WAVES * 64)
 wfa_pack_kernel(const char* __restrict__ ascii, const WfaSeqPair* __restrict__ meta,
-                uint32_t n_pairs, uint32_t* __restrict__ packed, uint8_t* __restrict__ flags) {
+                uint32_t n_pairs, uint32_t* __restrict__ packed, uint8_t* __restrict__ flags,
+                uint32_t* __restrict__ status, unsigned long long* __restrict__ n_raw) {
   constexpr uint32_t G = 64 / L;
   const int lane = threadIdx.x & 63, j = lane % L, grp = lane / L;
   const uint32_t pair = (blockIdx.x * PACK_WAVES + (threadIdx.x >> 6)) * G + (uint32_t)grp;
@@ -54,23 +55,33 @@ wfa_pack_kernel(const char* __restrict__ ascii, const WfaSeqPair* __restrict__ m
   const unsigned long long grp_mask = (L == 64) ? ~0ull : (((1ull << L) - 1ull) << (grp * L));
   const unsigned long long any_pbad = __ballot(pbad != 0) & grp_mask, any_tbad = __ballot(tbad != 0) & grp_mask;
   if (have && j == 0) { flags[2u * pair] = any_pbad ? 1 : 0; flags[2u * pair + 1u] = any_tbad ? 1 : 0; }
+  // (status != nullptr -- the align call's own packing: flagged pairs never enter the 2-bit tiers, and their number lets the host
+  // skip the byte-compare class when it is empty.  A kernel of its own did this: 4 us + the gap of a launch in a 175 us step of
+  // 100k short reads; clean batches pay no atomic.)
+  if (status) {
+    const bool raw = have && j == 0 && (any_pbad | any_tbad) != 0ull;
+    if (raw) status[pair] = WFA_ST_ALPHABET;
+    const unsigned long long bal = __ballot(raw);
+    if (bal && lane == __builtin_ctzll(bal)) atomicAdd(n_raw, (unsigned long long)__builtin_popcountll(bal));
+  }
 }
 
 }  // namespace
 
 // max_seq_len: the longest sequence of the batch (0: unknown) -- picks the lanes per pair
 void wfa_launch_pack(const char* d_ascii, const WfaSeqPair* d_meta, uint32_t n_pairs,
-                     uint32_t* d_packed, uint8_t* d_flags, hipStream_t stream, uint32_t max_seq_len, hipEvent_t ev0, hipEvent_t ev1) {
+                     uint32_t* d_packed, uint8_t* d_flags, hipStream_t stream, uint32_t max_seq_len, hipEvent_t ev0, hipEvent_t ev1,
+                     uint32_t* d_status, unsigned long long* d_n_raw) {
   if (n_pairs == 0) return;
   const uint32_t words = max_seq_len ? (max_seq_len + 15u) / 16u + 1u : 1u << 20;
   const uint32_t lanes = words <= 8u ? 8u : (words <= 16u ? 16u : (words <= 32u ? 32u : 64u));
   const uint32_t per_block = PACK_WAVES * (64u / lanes);
   const dim3 grid((n_pairs + per_block - 1) / per_block), block(PACK_WAVES * 64);
   switch (lanes) {
-    case 8: wfa_launch_timed(wfa_pack_kernel<8>, grid, block, 0, stream, ev0, ev1, d_ascii, d_meta, n_pairs, d_packed, d_flags); break;
-    case 16: wfa_launch_timed(wfa_pack_kernel<16>, grid, block, 0, stream, ev0, ev1, d_ascii, d_meta, n_pairs, d_packed, d_flags); break;
-    case 32: wfa_launch_timed(wfa_pack_kernel<32>, grid, block, 0, stream, ev0, ev1, d_ascii, d_meta, n_pairs, d_packed, d_flags); break;
-    default: wfa_launch_timed(wfa_pack_kernel<64>, grid, block, 0, stream, ev0, ev1, d_ascii, d_meta, n_pairs, d_packed, d_flags); break;
+    case 8: wfa_launch_timed(wfa_pack_kernel<8>, grid, block, 0, stream, ev0, ev1, d_ascii, d_meta, n_pairs, d_packed, d_flags, d_status, d_n_raw); break;
+    case 16: wfa_launch_timed(wfa_pack_kernel<16>, grid, block, 0, stream, ev0, ev1, d_ascii, d_meta, n_pairs, d_packed, d_flags, d_status, d_n_raw); break;
+    case 32: wfa_launch_timed(wfa_pack_kernel<32>, grid, block, 0, stream, ev0, ev1, d_ascii, d_meta, n_pairs, d_packed, d_flags, d_status, d_n_raw); break;
+    default: wfa_launch_timed(wfa_pack_kernel<64>, grid, block, 0, stream, ev0, ev1, d_ascii, d_meta, n_pairs, d_packed, d_flags, d_status, d_n_raw); break;
   }
 }
 

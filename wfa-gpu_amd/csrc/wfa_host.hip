@@ -144,16 +144,6 @@ __global__ void __launch_bounds__(1024) k_compact_len(uint32_t n, const uint32_t
   block_append(take, gid, out, out_count);
 }
 
-// flagged (non-ACGT) pairs never enter the 2-bit tiers
-__global__ void k_flag_alphabet(const uint8_t* __restrict__ flags, uint32_t n, uint32_t* __restrict__ status,
-                                unsigned long long* __restrict__ n_raw) {
-  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool raw = gid < n && (flags[2 * gid] | flags[2 * gid + 1]);
-  if (raw) status[gid] = WFA_ST_ALPHABET;
-  const unsigned long long bal = __ballot(raw);       // (their number lets the host skip the byte-compare class when it is empty)
-  if (bal && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(bal)) atomicAdd(n_raw, (unsigned long long)__builtin_popcountll(bal));
-}
-
 // bounds for the trace scratch: sum over finished pairs of the op-list and
 // text sizes; also the total of computed cells and the largest score.  Grid-stride, FOUR atomics per block, few blocks: the
 // counters share one cache line and an atomic on it costs ~11 ns whoever issues it (one atomicMax per wavefront + three adds per
@@ -212,14 +202,7 @@ __global__ void k_ratio(const uint32_t* __restrict__ list, uint32_t n, const uin
   out[gid] = (status[pair] == WFA_ST_DONE) ? (int32_t)(((long long)score[pair] * 1024 + len - 1) / len) : INT_MAX;
 }
 
-// per-pair budget = 1.02 * q/1024 * length + slack
-__global__ void k_budget(const WfaSeqPair* __restrict__ meta, uint32_t n, int q, int slack, int margin_pct, int32_t* __restrict__ out) {
-  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= n) return;
-  const unsigned len = max(meta[gid].pattern_len, meta[gid].text_len);
-  out[gid] = (int32_t)min(0x3FFFFFFFll, ((long long)q * len * margin_pct / 100) / 1024 + slack);
-}
-
+// (per-pair budget = 1.02 * q/1024 * length + slack: wfa_pair_budget, wfa_device.h -- computed by the wavefront kernels)
 // pairs that are not DONE at the end of a call (must be none: every list is run to completion).  Grid-stride, four statuses per
 // load: one thread per status took 41 us for 1M pairs -- a million threads for 4 MB.
 __global__ void __launch_bounds__(256) k_count_unfinished(uint32_t n, const uint32_t* __restrict__ status, unsigned long long* __restrict__ count) {
@@ -674,9 +657,8 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   ap.n_raw = ct + CT_NRAW;
   if (!prepacked && !fused_pack) {
     // (ev_pack: the end of the pack kernel, stamped by its own dispatch packet -- wfa_launch_timed, wfa_device.h)
-    wfa_launch_pack(b->d_sequences, ap.meta, n, static_cast<uint32_t*>(c->packed.p), static_cast<uint8_t*>(c->flags.p), st, b->max_seq_len, nullptr, c->ev_pack);
-    LAUNCH_K(k_flag_alphabet, dim3(cdiv(n, 256)), dim3(256), 0, st, static_cast<const uint8_t*>(c->flags.p), n,
-                       static_cast<uint32_t*>(c->status.p), ct + CT_NRAW);
+    wfa_launch_pack(b->d_sequences, ap.meta, n, static_cast<uint32_t*>(c->packed.p), static_cast<uint8_t*>(c->flags.p), st, b->max_seq_len, nullptr, c->ev_pack,
+                    static_cast<uint32_t*>(c->status.p), ct + CT_NRAW);      // (flagged pairs: status ALPHABET, counted)
   }
 
   float align_ms = 0.f, trace_ms = 0.f;
@@ -701,6 +683,8 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   // compaction] -> backtrace + CIGAR text of what finished -> compaction of the pairs that ran out of arena -> ONE
   // synchronisation.  Further chains (wider tiers) follow only for pairs that are still unfinished then.  (Six round
   // trips per batch before: with two lanes per device the lanes fell into lockstep, both waiting on the host at once.)
+  // (`budgets` != nullptr: per-pair budgets by the rule below -- the pointer is only the switch, the kernels compute them)
+  int rule_q = 0, rule_slack = 0, rule_margin = 100;
   auto run_list = [&](uint32_t* pending, uint32_t n_pending, const bool raw, const int32_t* budgets, const int budget_cap,
                       uint32_t* alt0, uint32_t* alt1, const bool allow_band = true, const bool speculate = true) -> int {
   grid_cap = UINT32_MAX;
@@ -742,7 +726,8 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         L = {0, n_links ? CT_LIST2 : CT_LIST, n_links ? CT_LCELLS2 : CT_LCELLS, n_links ? c->ev_b0 : c->ev_a0, n_links ? c->ev_b1 : c->ev_a1,
              false, budget_round, round == 0, n_cur};
         TierPlan tp;
-        ap.budget = budget_round ? budgets : nullptr;
+        ap.budget_on = budget_round ? 1 : 0; ap.budget_slack = rule_slack;
+        { const unsigned long long f = wfa_budget_factor(rule_q, rule_margin); ap.budget_mult_hi = (uint32_t)(f >> 32); ap.budget_mult_lo = (uint32_t)f; }
         // banded first attempt (packed class only); whatever it cannot finish goes to the exact tiers
         // (with tuned budgets the band keeps them: the reach interval of a tight budget makes the banded wavefront shrink
         // towards the end like the exact one; a pair whose banded score exceeds its budget is re-run exactly like any miss)
@@ -1140,7 +1125,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         const int q = c->saved_q[saved_idx].q;
         const int slack = budget_slack;
         if (c->budget.ensure((size_t)4 * n, st)) return -1;
-        LAUNCH_K(k_budget, dim3(cdiv(n, 256)), dim3(256), 0, st, ap.meta, n, q, slack, budget_margin, static_cast<int32_t*>(c->budget.p));
+        rule_q = q; rule_slack = slack; rule_margin = budget_margin;
         budgets = static_cast<const int32_t*>(c->budget.p);
         budget_cap = (int)std::min<long long>(max_error, ((long long)q * max_len * budget_margin / 100) / 1024 + slack);
         c->stats.auto_budget = budget_cap;
@@ -1189,7 +1174,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         if (valid >= n_s / 2) {
           const int q = hr[std::min(valid - 1, (size_t)(budget_q * valid))];      // score per 1024 bases
           const int slack = budget_slack;
-          LAUNCH_K(k_budget, dim3(cdiv(n, 256)), dim3(256), 0, st, ap.meta, n, q, slack, budget_margin, static_cast<int32_t*>(c->budget.p));
+          rule_q = q; rule_slack = slack; rule_margin = budget_margin;
           budgets = static_cast<const int32_t*>(c->budget.p);
           budget_cap = (int)std::min<long long>(max_error, ((long long)q * max_len * budget_margin / 100) / 1024 + slack);
           c->stats.auto_budget = budget_cap;

@@ -283,8 +283,7 @@ wfa_align_kernel(const WfaAlignParams p) {
     // The budget may be per pair (host auto-tuning from a scored sample): smaller budget, narrower
     // window, and -- below -- a wavefront that shrinks again once the score passes half the budget.
     int budget = cold_params()->max_score;
-    if (cold_params()->budget_on)
-      budget = min(budget, wfa_pair_budget(cold_params()->budget_mult_hi, cold_params()->budget_mult_lo, cold_params()->budget_slack, (uint32_t)plen, (uint32_t)tlen));
+    { const int32_t* pb = cold_params()->budget; if (pb) budget = min(budget, pb[pair]); }
     {
       // no optimal alignment costs more than min(P,T) mismatches plus one gap of |T - P| (that alignment
       // always exists); it bounds the backtrace row table

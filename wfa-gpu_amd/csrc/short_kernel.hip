@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(64) wfa_short_kernel(const WfaAlignParams p) {
     const WfaSeqPair mp = p.meta[pair];
     m.plen = (int)mp.pattern_len; m.tlen = (int)mp.text_len;
     m.poff = (uint32_t)(mp.pattern_offset_packed >> 2); m.toff = (uint32_t)(mp.text_offset_packed >> 2);
-    m.budget = p.budget_on ? wfa_pair_budget(p.budget_mult_hi, p.budget_mult_lo, p.budget_slack, mp.pattern_len, mp.text_len) : p.max_score;
+    m.budget = p.budget ? p.budget[pair] : p.max_score;
     return m;
   };
   auto words_of = [](const int len) { return ((len + 15) >> 4) + 1; };

@@ -76,11 +76,7 @@ struct WfaAlignParams {
   int book_mask;                 // row-book entries - 1 (power of two >= max(dm, 64))
   int rs;                        // row stride (elements), even: widest diagonal window + 3
   int max_score;                 // give up (WFA_ST_SCORE) beyond this score
-  // optional per-pair score budget (auto-tuned from a scored sample), capped by max_score: margin_pct/100 * q/1024 * length + slack,
-  // computed by the kernels from the pair's record (a kernel that filled an array of them cost a launch per batch): the factor
-  // margin_pct * q / 102400 as a 32.32 fixed-point number (wfa_budget_factor), two multiplications per pair
-  int budget_on, budget_slack;
-  uint32_t budget_mult_hi, budget_mult_lo;
+  const int32_t* budget;         // optional per-pair score budget (auto-tuned), capped by max_score
   int band_width;                // > 0: adaptive band, diagonals kept per wavefront (banded kernels)
   int band_period;               //      re-centre the band every this many scores
   int seq_words_cap;             // LDS words reserved per packed sequence
@@ -157,18 +153,6 @@ inline void wfa_launch_timed(K kernel, dim3 grid, dim3 block, size_t lds, hipStr
   if (ev0 || ev1) hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, stream, ev0, ev1, 0, args...);
   else hipLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, stream, args...);
 }
-
-inline unsigned long long wfa_budget_factor(const int q, const int margin_pct) {      // host: floor(q * margin_pct / 102400 * 2^32)
-  return (((unsigned long long)(q > 0 ? q : 0) * (unsigned long long)margin_pct) << 32) / 102400ull;
-}
-#ifdef __HIPCC__
-// (never above the host's own margin_pct * q * length / 102400 + slack, which sizes the rings for the longest pair of the batch)
-__device__ __forceinline__ int wfa_pair_budget(const uint32_t mult_hi, const uint32_t mult_lo, const int slack, const uint32_t plen, const uint32_t tlen) {
-  const uint32_t len = plen > tlen ? plen : tlen;
-  const unsigned long long b = (unsigned long long)len * mult_hi + __umulhi(len, mult_lo) + (unsigned long long)(slack > 0 ? slack : 0);
-  return (int)(b < 0x3FFFFFFFull ? b : 0x3FFFFFFFull);
-}
-#endif
 
 // (ev0 / ev1 of every launcher: events that receive the start of the first and the end of the last kernel it launches)
 void wfa_launch_pack(const char* d_ascii, const WfaSeqPair* d_meta, uint32_t n_pairs,

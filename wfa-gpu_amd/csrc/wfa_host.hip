@@ -202,7 +202,14 @@ __global__ void k_ratio(const uint32_t* __restrict__ list, uint32_t n, const uin
   out[gid] = (status[pair] == WFA_ST_DONE) ? (int32_t)(((long long)score[pair] * 1024 + len - 1) / len) : INT_MAX;
 }
 
-// (per-pair budget = 1.02 * q/1024 * length + slack: wfa_pair_budget, wfa_device.h -- computed by the wavefront kernels)
+// per-pair budget = 1.02 * q/1024 * length + slack
+__global__ void k_budget(const WfaSeqPair* __restrict__ meta, uint32_t n, int q, int slack, int margin_pct, int32_t* __restrict__ out) {
+  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n) return;
+  const unsigned len = max(meta[gid].pattern_len, meta[gid].text_len);
+  out[gid] = (int32_t)min(0x3FFFFFFFll, ((long long)q * len * margin_pct / 100) / 1024 + slack);
+}
+
 // pairs that are not DONE at the end of a call (must be none: every list is run to completion).  Grid-stride, four statuses per
 // load: one thread per status took 41 us for 1M pairs -- a million threads for 4 MB.
 __global__ void __launch_bounds__(256) k_count_unfinished(uint32_t n, const uint32_t* __restrict__ status, unsigned long long* __restrict__ count) {
@@ -683,8 +690,6 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   // compaction] -> backtrace + CIGAR text of what finished -> compaction of the pairs that ran out of arena -> ONE
   // synchronisation.  Further chains (wider tiers) follow only for pairs that are still unfinished then.  (Six round
   // trips per batch before: with two lanes per device the lanes fell into lockstep, both waiting on the host at once.)
-  // (`budgets` != nullptr: per-pair budgets by the rule below -- the pointer is only the switch, the kernels compute them)
-  int rule_q = 0, rule_slack = 0, rule_margin = 100;
   auto run_list = [&](uint32_t* pending, uint32_t n_pending, const bool raw, const int32_t* budgets, const int budget_cap,
                       uint32_t* alt0, uint32_t* alt1, const bool allow_band = true, const bool speculate = true) -> int {
   grid_cap = UINT32_MAX;
@@ -726,8 +731,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         L = {0, n_links ? CT_LIST2 : CT_LIST, n_links ? CT_LCELLS2 : CT_LCELLS, n_links ? c->ev_b0 : c->ev_a0, n_links ? c->ev_b1 : c->ev_a1,
              false, budget_round, round == 0, n_cur};
         TierPlan tp;
-        ap.budget_on = budget_round ? 1 : 0; ap.budget_slack = rule_slack;
-        { const unsigned long long f = wfa_budget_factor(rule_q, rule_margin); ap.budget_mult_hi = (uint32_t)(f >> 32); ap.budget_mult_lo = (uint32_t)f; }
+        ap.budget = budget_round ? budgets : nullptr;
         // banded first attempt (packed class only); whatever it cannot finish goes to the exact tiers
         // (with tuned budgets the band keeps them: the reach interval of a tight budget makes the banded wavefront shrink
         // towards the end like the exact one; a pair whose banded score exceeds its budget is re-run exactly like any miss)
@@ -1125,7 +1129,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         const int q = c->saved_q[saved_idx].q;
         const int slack = budget_slack;
         if (c->budget.ensure((size_t)4 * n, st)) return -1;
-        rule_q = q; rule_slack = slack; rule_margin = budget_margin;
+        LAUNCH_K(k_budget, dim3(cdiv(n, 256)), dim3(256), 0, st, ap.meta, n, q, slack, budget_margin, static_cast<int32_t*>(c->budget.p));
         budgets = static_cast<const int32_t*>(c->budget.p);
         budget_cap = (int)std::min<long long>(max_error, ((long long)q * max_len * budget_margin / 100) / 1024 + slack);
         c->stats.auto_budget = budget_cap;
@@ -1174,7 +1178,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         if (valid >= n_s / 2) {
           const int q = hr[std::min(valid - 1, (size_t)(budget_q * valid))];      // score per 1024 bases
           const int slack = budget_slack;
-          rule_q = q; rule_slack = slack; rule_margin = budget_margin;
+          LAUNCH_K(k_budget, dim3(cdiv(n, 256)), dim3(256), 0, st, ap.meta, n, q, slack, budget_margin, static_cast<int32_t*>(c->budget.p));
           budgets = static_cast<const int32_t*>(c->budget.p);
           budget_cap = (int)std::min<long long>(max_error, ((long long)q * max_len * budget_margin / 100) / 1024 + slack);
           c->stats.auto_budget = budget_cap;

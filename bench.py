@@ -151,6 +151,24 @@ def cpu_baseline(buf, meta, compute_cigar, budget_pairs):
     run(meta[:n1], 1)
     d1 = time.perf_counter() - t1
     res["single_core"] = {"value": n1 / d1, "unit": "alignments/s", "sample": f"{n1} pairs, {d1:.2f} s wall"}
+    if oracle_lib.have_refcpu():
+        # the function north_star names: the reference's utils/wfa_cpu.c itself (compute_alignments_cpu_threaded /
+        # compute_distance_cpu_threaded: one WFA2 aligner per OpenMP thread, memory mode low, schedule(static)), compiled in
+        # place by oracle/Makefile and driven by oracle/ref_cpu_shim.c, on the same sample and the same cores
+        try:
+            reps2, t2 = 0, time.perf_counter()
+            while True:
+                oracle_lib.refcpu_batch(sub, pairs_meta, PEN, cigar=compute_cigar, nthreads=cores)
+                reps2 += 1
+                d2 = time.perf_counter() - t2
+                if d2 >= 1.0 or reps2 >= 100:
+                    break
+            res["reference_shim"] = {"value": n * reps2 / d2, "unit": "alignments/s", "cores": cores, "kind": "reference-shim",
+                                     "what": "utils/wfa_cpu.c:%s of the reference, compiled in place (oracle/_ref/libwfacpuref.so)" %
+                                             ("compute_alignments_cpu_threaded" if compute_cigar else "compute_distance_cpu_threaded"),
+                                     "sample": f"{n} pairs x{reps2}, {d2:.2f} s wall"}
+        except Exception as ex:
+            res["reference_shim"] = {"error": str(ex)}
     return res
 
 
@@ -314,6 +332,10 @@ def parity_sample(buf, meta, wl, n_pairs, d_scores, ptrs, st, band):
             want = np.where(sr >= 0, sr, so)
             return {"pairs": k, "valid_and_cost_equals_score": ok, "recall": float((scores == so).mean()),
                     "not_above_the_reference_band_rule": bool((scores <= want).all()),
+                    # (CIGAR mode reports the cost of the CIGAR returned: below the rule's forward score where two gaps of a kind
+                    # that the band made the search open back to back print as one)
+                    "pairs_below_the_rules_forward_score": int((scores < want).sum()),
+                    "equal_to_the_reference_band_rule": int((scores == want).sum()),
                     "reference_band_rule_recall": float(((sr >= 0) & (sr == so)).mean())}
         return {"pairs": k, "bit_exact_vs_oracle": bool(np.array_equal(scores, so)) and (not wl["cigar"] or cg == co)}
     except Exception as ex:  # the checker is optional for the measurement itself
@@ -454,7 +476,7 @@ def extra_config(name, force_band, steps, warmup):
     if not force_band:
         per_pair_us = 2.0 if wl["length"] <= 200 else 95.0 * (wl["length"] / 1000.0) ** 2
         cb = cpu_baseline(buf, meta, wl["cigar"], int(max(16, min(n, 4e6 / per_pair_us))))
-        out["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample")}
+        out["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample", "reference_shim") if k in cb}
     out["leg_s"] = round(time.perf_counter() - t0, 1)
     return out
 

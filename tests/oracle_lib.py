@@ -1,6 +1,7 @@
 """ctypes access to the CHECKERS (test infrastructure only):
    oracle/liboracle.so        from-scratch C restatement of WFA2's gap-affine path
    oracle/_ref/libwfa2ref.so  the reference's own WFA2 sources compiled in place (optional)
+   oracle/_ref/libwfacpuref.so  the reference's utils/wfa_cpu.c + utils/cigar.c (+ WFA2) compiled in place (optional)
 Nothing under wfa-gpu_amd/ imports this module."""
 import ctypes as C
 import os
@@ -12,6 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libwfa2ref.so")
+REFCPU_SO = os.path.join(ORACLE_DIR, "_ref", "libwfacpuref.so")
 
 
 class OracleStats(C.Structure):
@@ -130,6 +132,37 @@ def ref_batch(buf, meta, pen, cigar=True, memory_mode=0, nthreads=1):
     buf = np.ascontiguousarray(buf)
     r.ref_batch(buf.ctypes.data, off.ctypes.data, n, pen[0], pen[1], pen[2], memory_mode, scores.ctypes.data,
                 cbuf.ctypes.data if cigar else None, stride, nthreads)
+    return scores, (_split(cbuf, n, stride) if cigar else None)
+
+
+_refcpu = None
+
+
+def have_refcpu():
+    return os.path.exists(REFCPU_SO)
+
+
+def refcpu_batch(buf, meta, pen, cigar=True, nthreads=1):
+    """The reference's OWN CPU path as it calls it -- utils/wfa_cpu.c: compute_alignments_cpu_threaded /
+    compute_distance_cpu_threaded, one WFA2 aligner per OpenMP thread, memory mode low -- over a batch in the reference
+    layout (oracle/ref_cpu_shim.c).  -> (scores int32[n], cigars or None)"""
+    global _refcpu
+    if _refcpu is None:
+        r = C.CDLL(REFCPU_SO)
+        r.refcpu_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        r.refcpu_batch.restype = C.c_int64
+        _refcpu = r
+    n = len(meta)
+    meta = np.ascontiguousarray(meta)
+    assert meta.dtype.itemsize == 48, "records must be in the reference layout (sequence_pair_t)"
+    scores = np.zeros(n, dtype=np.int32)
+    stride = _cigar_stride(meta) if cigar else 0
+    cbuf = np.zeros(n * stride, dtype=np.uint8) if cigar else None
+    buf = np.ascontiguousarray(buf)
+    done = _refcpu.refcpu_batch(buf.ctypes.data, meta.ctypes.data, n, pen[0], pen[1], pen[2], scores.ctypes.data,
+                                cbuf.ctypes.data if cigar else None, stride, nthreads)
+    if done != n:
+        raise RuntimeError(f"refcpu_batch: {done} of {n} alignments computed")
     return scores, (_split(cbuf, n, stride) if cigar else None)
 
 

@@ -4,9 +4,9 @@ reference's WFA2 (oracle/_ref, or the C restatement when that is not there):
   configs[1]  100k x 150 bp @ 2 %, SCORE-ONLY, max_error 45 -- exactly what `bench.py --workload cfg2` times: the
               several-alignments-per-wavefront tier (short_kernel.hip), every one of the 100 000 scores;
 
-  configs[2]  1M x 1 kbp @ 5 %: scores AND CIGAR strings on a 100k-pair stratified sample that contains EVERY pair that
-              missed its auto-tuned budget (the re-run path) -- once with the arena the library picks, once with an arena
-              cap that forces the batch through several arena-bound passes (the sample covers every pass);
+  configs[2]  1M x 1 kbp @ 5 %: with the arena the library picks ALL 1M scores AND CIGAR strings; with an arena cap that
+              forces the batch through several arena-bound passes a 100k-pair stratified sample that contains EVERY pair
+              that missed its auto-tuned budget (the re-run path; the sample covers every pass);
   configs[3]  16 384 x 10 kbp @ 3 % (the shape that picks the four-wave tier with six rings per CU): every score, CIGAR
               identity on 256 pairs, every CIGAR valid with cost == score; once exact, once with -B auto -t 512;
   configs[4]  1 024 x 30 kbp @ 10 % (hybrid ring tier, one workgroup per CU): every score, CIGAR identity on 32 pairs,
@@ -131,12 +131,16 @@ def test_cfg3_full_size_every_budget_miss_and_every_pass(arena_limit_gib):
     budget_lo = (st.auto_budget - 2) * lens // int(lens.max())
     missed = np.nonzero(scores > budget_lo)[0]
     assert st.pairs_budget_missed <= len(missed) <= 20 * st.pairs_budget_missed
-    sample = np.union1d(np.arange(0, n, 10), missed)
-    assert 100_000 <= len(sample) <= 150_000
-    so, co = _truth(buf, meta[sample], cigar=True)
-    assert np.array_equal(scores[sample], so)
-    bad = [int(i) for j, i in enumerate(sample) if _cigar(text, off, ln, i) != co[j]]
-    assert not bad, bad[:5]
+    # arena picked by the library: ALL 1M scores and CIGAR strings against the reference's WFA2 (16 s of its time on the box's
+    # 16 cores), in slices of 100k pairs; several arena-bound passes: the stratified sample + every budget miss
+    sample = np.arange(n) if arena_limit_gib == 0 else np.union1d(np.arange(0, n, 10), missed)
+    assert len(sample) == n or 100_000 <= len(sample) <= 150_000
+    for lo in range(0, len(sample), 100_000):
+        part = sample[lo:lo + 100_000]
+        so, co = _truth(buf, meta[part], cigar=True)
+        assert np.array_equal(scores[part], so), lo
+        bad = [int(i) for j, i in enumerate(part) if _cigar(text, off, ln, i) != co[j]]
+        assert not bad, bad[:5]
     # size-independent property on everything: the text arena is dense and every text ends where the next begins
     order = np.argsort(off)
     assert np.array_equal(off[order][1:], (off[order] + ln[order] + 1)[:-1])
@@ -201,6 +205,14 @@ def test_cfg4_full_size_with_the_band_forced():
     assert np.array_equal(s0, sr)
     print(f"cfg4, band forced: {st.pairs_banded}/{n} pairs inside the band, recall {(sr == so).mean():.4f} (reference rule: the same pairs)")
     assert (scores >= so).all() and (scores <= sr).all()
+    # With CIGARs the reported score is the cost of the CIGAR that is returned.  It differs from the forward score of the band
+    # rule only where the banded search closed a gap and opened the same kind again right behind it (printed, the two are ONE
+    # gap): each such place saves exactly one gap opening.  Counted and bounded, every other pair must carry the rule's score.
+    fixed = np.nonzero(scores != sr)[0]
+    saved = (sr - scores)[fixed]
+    print(f"cfg4, band forced, with CIGARs: {len(fixed)} of {n} pairs report a cost below the rule's forward score "
+          f"(by {int(saved.min()) if len(fixed) else 0}..{int(saved.max()) if len(fixed) else 0}); all others equal it")
+    assert (saved > 0).all() and (saved % PEN[1] == 0).all() and len(fixed) <= n // 20
     pairs = wfagpu.pairs_from_layout(buf, meta)
     for i in range(n):
         ok, cost = oracle_lib.check_cigar(pairs[i][0], pairs[i][1], _cigar(text, off, ln, i), PEN)

@@ -116,6 +116,25 @@ def test_oracle_matches_compiled_reference_random(pen):
         assert ok and cost == sc
 
 
+@pytest.mark.skipif(not (oracle_lib.have_ref() and oracle_lib.have_refcpu()), reason="oracle/_ref not built (reference tree absent)")
+@pytest.mark.parametrize("pen", [(2, 3, 1), (4, 6, 2), (5, 3, 2)])
+def test_reference_cpu_functions_agree_with_the_wfa2_shim(pen):
+    """utils/wfa_cpu.c itself (compute_alignments_cpu_threaded / compute_distance_cpu_threaded, compiled in place with
+    utils/cigar.c: what north_star names as the CPU baseline and bench.py times as cpu_baseline.reference_shim) returns what
+    the WFA2 shim (ref_shim.c) and the restatement return -- scores and CIGARs, one thread and several."""
+    rng = random.Random(77 + sum(pen))
+    pairs = _rand_pairs(rng, 200, 80) + _rand_pairs(rng, 40, 500, err=0.2) + [(b"A", b"A"), (b"ACGT", b"TGCA"), (b"ACGTACGTAC", b"ACGTACGTACGTACGTACGT")]
+    buf, meta = wfagpu.layout_pairs(pairs)
+    rs, rc = oracle_lib.ref_batch(buf, meta, pen, cigar=True, memory_mode=1)
+    for nt in (1, 4):
+        s, c = oracle_lib.refcpu_batch(buf, meta, pen, cigar=True, nthreads=nt)
+        assert np.array_equal(s, rs) and c == rc
+        s2, _ = oracle_lib.refcpu_batch(buf, meta, pen, cigar=False, nthreads=nt)
+        assert np.array_equal(s2, rs)
+    so, co, _ = oracle_lib.oracle_batch(buf, meta, pen, cigar=True)
+    assert np.array_equal(so, rs) and co == rc
+
+
 def test_host_packer_writes_the_oracle_packers_words():
     """utils/host_pack.c (launch_alignments* pack on the host when it has the cores): the vector path and the portable one
     against the oracle's packer -- every length around the 16- and 32-base steps, the zero word at the end, nothing

@@ -135,7 +135,9 @@ void get_cuda_capability(int dev, int* major, int* minor);
 
 /* ------------------------------------------------------ results storage */
 
-/* lib/alignment_results.h:54-60 */
+/* lib/alignment_results.h:54-60.  An array made by initialize_wfa_results is released through destroy_wfa_results (the
+ * library remembers how many records it made, so that an aligner whose pair count changed afterwards frees and indexes the
+ * array by the right count); arrays built by the caller are the caller's to free. */
 bool initialize_wfa_results(wfa_alignment_result_t** results,
                             const size_t num_alignments,
                             const size_t cigar_length);

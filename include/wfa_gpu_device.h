@@ -204,9 +204,9 @@ typedef struct {
                                  ACGT always goes up as ASCII                                                           */
     int host_pack_threads;    /* threads packing a batch (0: three quarters of a device's share of the host threads, 2..12)         */
     int bring_up;             /* 0: the first device query of the process (get_num_cuda_devices, get_cuda_SM_count -- what the CLI
-                                 and wfagpu_set_default_options call before any alignment) starts bringing the devices up in
-                                 a background thread: streams, lanes, code objects (wfagpu_amd_warmup); -1: never -- set it
-                                 before the first query                                                                  */
+                                 and wfagpu_set_default_options call before any alignment) starts bringing the caller's
+                                 CURRENT device up in a background thread: streams, lanes, code objects (all devices:
+                                 wfagpu_amd_warmup); -1: never -- set it before the first query                           */
 } wfagpu_amd_launch_config_t;
 
 /* NULL: back to the defaults.  Changing `tuning` or `arena_limit_bytes` drops the cached per-device state. */
@@ -245,10 +245,12 @@ void wfagpu_amd_set_num_devices(int n);
  * into a non-zero exit code. */
 long wfagpu_amd_check_failures(void);
 
-/* Starts bringing every visible device up in the background (upload/download streams, three lanes, code objects: what a
- * cold launch_alignments* call otherwise does under its first batches, ~100 ms): returns at once, a call that follows
- * waits only for what is still missing.  Called by the first device query of the process unless
- * wfagpu_amd_launch_config_t::bring_up is -1. */
+/* Starts bringing up, in the background, every device a call would be sharded over (upload/download streams, three lanes,
+ * code objects: what a cold launch_alignments* call otherwise does under its first batches, ~100 ms): returns at once, a
+ * call that follows waits only for what is still missing; the caller's current HIP device is left as it was.  The first
+ * device query of the process (get_num_cuda_devices, get_cuda_SM_count) does the same for ONE device -- the caller's current
+ * one, device 0 unless the process selected another -- unless wfagpu_amd_launch_config_t::bring_up is -1: a process that
+ * will call launch_alignments* over several devices calls this function itself (the CLI does). */
 void wfagpu_amd_warmup(void);
 
 /* launch_alignments* keep their per-device state (context, backtrace arena,

@@ -167,13 +167,17 @@ static void trim(const oracle_aligner_t* al, owf_t* w) {
   w->null = (w->lo > w->hi);
 }
 
-/* EXPERIMENT SWITCH (tests/scratch only, default off = WFA2's semantics): null every I and D value that ran past a sequence
- * end the moment it is computed -- what a kernel that keeps one diagonal per lane and no per-row limits would do
- * (wfa-gpu_amd/csrc/short_kernel.hip does, score-only).  WFA2 keeps such values and only trims them at the ends of a row
- * (wavefront_compute.c:570-603).  scratch/short_cigar_semantics.py looks for pairs whose CIGAR changes. */
-static int g_null_invalid_gaps = 0;
-void oracle_set_null_invalid_gaps(int on) { g_null_invalid_gaps = on; }
-#define GAP_FIX(val, kk) do { if (g_null_invalid_gaps && ((uint32_t)(val) > tlen || (uint32_t)((val) - (kk)) > plen)) (val) = ONULL; } while (0)
+/* EXPERIMENT, COMPILE-TIME ONLY (-DORACLE_EXPERIMENT_NULL_INVALID_GAPS; the checker the tests load is never built with it:
+ * a process-wide run-time switch could leave the ground truth in non-WFA2 mode for whoever calls next): null every I and D
+ * value that ran past a sequence end the moment it is computed -- what a kernel that keeps one diagonal per lane and no
+ * per-row limits does (wfa-gpu_amd/csrc/short_kernel.hip).  WFA2 keeps such values and only trims them at the ends of a row
+ * (wavefront_compute.c:570-603).  scratch/short_cigar_semantics.py builds a second library with the flag and looks for pairs
+ * whose CIGAR changes. */
+#ifdef ORACLE_EXPERIMENT_NULL_INVALID_GAPS
+#define GAP_FIX(val, kk) do { if ((uint32_t)(val) > tlen || (uint32_t)((val) - (kk)) > plen) (val) = ONULL; } while (0)
+#else
+#define GAP_FIX(val, kk) do { } while (0)
+#endif
 
 /* wavefront/wavefront_compute_affine.c:228-259 + :45-87 (kernel) +
  * wavefront_compute.c:41-71 (limits) + :401-437 (which outputs exist) */

@@ -20,6 +20,7 @@ struct hipDeviceProp_t { char name[256]; int multiProcessorCount; int major, min
 const char* hipGetErrorString(hipError_t e);
 hipError_t hipGetDeviceCount(int* n);
 hipError_t hipSetDevice(int d);
+hipError_t hipGetDevice(int* d);
 hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int d);
 hipError_t hipDeviceGetPCIBusId(char* buf, int len, int d);
 hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest);

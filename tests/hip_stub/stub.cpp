@@ -48,7 +48,9 @@ static std::atomic<int> g_devices{1};
 void stub_set_device_count(int n) { g_devices.store(n); }
 const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "stub error"; }
 hipError_t hipGetDeviceCount(int* n) { *n = g_devices.load(); return hipSuccess; }
-hipError_t hipSetDevice(int d) { return d >= 0 && d < g_devices.load() ? hipSuccess : hipErrorInvalidValue; }
+static thread_local int t_device = 0;      // (the current device is per thread, like the runtime's)
+hipError_t hipSetDevice(int d) { if (d < 0 || d >= g_devices.load()) return hipErrorInvalidValue; t_device = d; return hipSuccess; }
+hipError_t hipGetDevice(int* d) { *d = t_device; return hipSuccess; }
 hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { memset(p, 0, sizeof *p); strcpy(p->name, "stub"); p->multiProcessorCount = 256; p->major = 9; p->minor = 5; p->sharedMemPerBlock = 160 << 10; return hipSuccess; }
 hipError_t hipDeviceGetPCIBusId(char*, int, int) { return hipErrorInvalidValue; }
 hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest) { *least = 0; *greatest = -1; return hipSuccess; }

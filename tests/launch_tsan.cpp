@@ -12,7 +12,7 @@
 
 extern "C" size_t wfagen_pair_stride(int length, double error);
 extern "C" size_t wfagen_generate(char* seqbuf, size_t cap, sequence_pair_t* meta, size_t n, int length, double error, uint64_t seed, int nthreads);
-void stub_set_device_count(int n);
+#include <hip/hip_runtime.h>      // (the stub layer of tests/hip_stub: hipSetDevice / hipGetDevice / stub_set_device_count)
 
 #define CHECK(cond) do { if (!(cond)) { fprintf(stderr, "CHECK failed at %s:%d: %s\n", __FILE__, __LINE__, #cond); exit(1); } } while (0)
 
@@ -82,8 +82,17 @@ int main() {
     for (size_t i = 0; i < n; ++i) CHECK((int)res[i].error == want[i] && strcmp(res[i].cigar.buffer, want_cg[i].data()) == 0);
     destroy_wfa_results(res, n);
   }
+  // the explicit warm-up over several devices leaves the caller's current device where it was (the query functions too)
+  stub_set_device_count(4);
+  CHECK(hipSetDevice(2) == hipSuccess);
   wfagpu_amd_warmup();
+  int cur = -1;
+  CHECK(hipGetDevice(&cur) == hipSuccess && cur == 2);
+  get_num_cuda_devices(&nd);
+  CHECK(nd == 4 && get_cuda_SM_count(0) == 256);
+  CHECK(hipGetDevice(&cur) == hipSuccess && cur == 2);
   wfagpu_amd_release_cache();
+  stub_set_device_count(1);
   printf("launch_tsan ok\n");
   return 0;
 }

@@ -256,11 +256,20 @@ DevState g_dev[MAX_DEV];
 std::mutex g_dev_mu[MAX_DEV];   // one per slot: the devices of a call run concurrently
 
 void join_bring(DevState& d) { if (d.bring_thread.joinable()) d.bring_thread.join(); }
+// (a process that ends while a device is still coming up -- or after a call that failed half-way -- must neither tear the
+// runtime down under that thread nor destroy a joinable std::thread: registered by whoever starts the first bring-up thread)
+void join_all_bring_at_exit() {
+  static std::once_flag at_exit;
+  std::call_once(at_exit, [] { atexit([] { for (int i = 0; i < MAX_DEV; ++i) join_bring(g_dev[i]); }); });
+}
 
 void release_dev(DevState& d) {
   join_bring(d);
   if (d.device < 0) return;
   (void)hipSetDevice(d.device);
+  // (the warm-up copies of a bring-up nobody has used yet may still be in flight on the copy streams)
+  if (d.up) (void)hipStreamSynchronize(d.up);
+  if (d.down) (void)hipStreamSynchronize(d.down);
   for (auto& in : d.in) { if (in.d_seq) (void)hipFree(in.d_seq); if (in.d_meta) (void)hipFree(in.d_meta); if (in.d_packed) (void)hipFree(in.d_packed); }
   d.in.clear();
   for (auto& hs : d.stage) { free(hs.p); hs = HostStage{}; }
@@ -431,6 +440,7 @@ void start_bring(DevState& d, const wfagpu_amd_launch_config_t& cfg, int lanes, 
   for (int k = 0; k < lanes; ++k) complete = complete && d.lane[k].ctx;
   if (complete) return;
   { std::lock_guard<std::mutex> l(d.bring_mu); d.bring_active = true; }
+  join_all_bring_at_exit();
   d.bring_thread = std::thread(bring_up_fn, &d, cfg, lanes, prime);
 }
 
@@ -521,6 +531,8 @@ int run_device(const CallArgs& a, Shard& sh) {
   HIP_OK(hipSetDevice(sh.device));
   // streams and lanes that are not there yet come up in the order they are needed, under the packing of the first batch
   start_bring(d, a.cfg, K, false);
+  // (every way out of this function -- the error returns below included -- leaves no bring-up thread behind)
+  struct BringGuard { DevState& d; ~BringGuard() { join_bring(d); } } bring_guard{d};
   const double t_created = now_ms();
 
   // ---- input slots ---------------------------------------------------------------------------------------------------
@@ -1038,29 +1050,40 @@ void launch_alignments_distance(char* sequences_buffer, const size_t sequences_b
               check_correctness, false);
 }
 
-void wfagpu_amd_warmup(void) {
+// Brings devices [first, last] up in the background.  The caller's current HIP device is left as it was found.
+static void warm_devices(int first, int last) {
   wfagpu_amd_launch_config_t cfg;
   { std::lock_guard<std::mutex> l(g_cfg_mu); cfg = g_cfg; }
   if (cfg.bring_up < 0 || cfg.virtual_devices > 0) return;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return;
   if (cfg.num_devices > 0) ndev = std::min(ndev, cfg.num_devices);
-  // (a process that ends while a device is still coming up must not tear the runtime down under that thread)
-  static std::once_flag at_exit;
-  std::call_once(at_exit, [] { atexit([] { for (int i = 0; i < MAX_DEV; ++i) join_bring(g_dev[i]); }); });
-  for (int dev = 0; dev < std::min(ndev, MAX_DEV); ++dev) {
+  int caller_dev = -1;
+  if (hipGetDevice(&caller_dev) != hipSuccess) caller_dev = -1;
+  for (int dev = std::max(first, 0); dev <= std::min(last, std::min(ndev, MAX_DEV) - 1); ++dev) {
     std::lock_guard<std::mutex> guard(g_dev_mu[dev]);
     DevState* d = nullptr;
-    if (acquire_dev(dev, dev, 1, cfg, &d)) return;
+    if (acquire_dev(dev, dev, 1, cfg, &d)) break;
     start_bring(*d, cfg, MAX_LANES - 1, true);
   }
+  if (caller_dev >= 0) (void)hipSetDevice(caller_dev);      // (acquire_dev selects the device it sets up)
 }
 
+// Explicit: every device a call would be sharded over (wfagpu_amd_launch_config_t::num_devices; the CLI calls this).
+void wfagpu_amd_warmup(void) { warm_devices(0, MAX_DEV - 1); }
+
 // The first time the process asks about its devices (the CLI: tools/aligner.c:189-204 of the reference, before it reads its
-// input; the API: wfagpu_set_default_options -> get_cuda_SM_count) the devices start coming up in the background.
+// input; the API: wfagpu_set_default_options -> get_cuda_SM_count) -- the moment the reference creates its CUDA context on
+// ITS device (device 0, lib/alignment_parameters.h:77) -- the caller's CURRENT device starts coming up in the background:
+// one device, not every visible one (a rank of a one-process-per-GPU job that has selected its GPU opens no context, no
+// hardware queue and no VRAM on the other seven), and the caller's current device stays what it was.
 static void first_device_query() {
   static std::once_flag once;
-  std::call_once(once, [] { wfagpu_amd_warmup(); });
+  std::call_once(once, [] {
+    int cur = 0;
+    if (hipGetDevice(&cur) != hipSuccess) cur = 0;
+    warm_devices(cur, cur);
+  });
 }
 
 void get_num_cuda_devices(int* n) {

@@ -169,9 +169,14 @@ bool wfagpu_align(wfagpu_aligner_t* aligner) {
         LOG_ERROR("Invalid aligner.")
         return false;
     }
-    /* (an aligner without sequences or parameters: the reference calls the launcher all the same and returns true,
-     * lib/aligner.c:236-263 -- this build's launcher logs "Invalid buffers." for missing arrays and does nothing for
-     * zero alignments, so the same return value is safe to keep) */
+    /* (an aligner without sequences: the reference calls the launcher all the same and returns true,
+     * lib/aligner.c:236-263 -- this build's launcher does nothing for zero alignments, same return value.  Sequences but no
+     * results array -- wfagpu_initialize_parameters was never called, so the options are not initialised either: the
+     * reference dereferences the missing array; here that is an error the caller gets told about) */
+    if (aligner->results == NULL && aligner->num_sequence_pairs > 0) {
+        LOG_ERROR("No results array: call wfagpu_initialize_parameters before wfagpu_align.")
+        return false;
+    }
     /* sequences added after the parameters were initialised: the results array is still the old count's (the reference
      * indexes it by the new one) -- a fresh array for every pair */
     if (aligner->results != NULL && aligner->num_sequence_pairs > 0) {

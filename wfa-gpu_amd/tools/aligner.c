@@ -67,6 +67,8 @@ int main(int argc, char** argv) {
         LOG_INFO("Using HIP device \"%s\" with capability %d.%d (%d visible)", name, major, minor, ndev)
         free(name);
     }
+    /* (the query above started bringing device 0 up in the background; this call will be sharded over every visible device) */
+    if (ndev > 1) wfagpu_amd_warmup();
 
     int c;
     opterr = 0;      /* (unknown options are skipped silently: see the default case) */

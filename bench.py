@@ -24,6 +24,8 @@ Besides the contract fields the line carries
   cli_wall      bin/wfa.affine.gpu as a fresh process on the same workload from a .seq file: the "Wall time" it prints
   configs       short legs of the other BASELINE GPU configurations (cfg2, cfg4 by policy and with the band forced, cfg5):
                 value, kernel time, issue fraction, parity sample, host-to-host rate, CPU baseline each (N=1, default command)
+  ont_banded    the reference's published experiment in shape: 1024 ONT-shaped 30 kbp pairs, exact against the adaptive band over
+                beta x lambda: ms, speed-up, recall
 """
 import argparse
 import hashlib
@@ -49,6 +51,8 @@ WORKLOADS = {
                  desc="1M synthetic 1 kbp pairs, 5% error, x=2,o=3,e=1, score+CIGAR"),
     "cfg4": dict(pairs=16_384, length=10_000, error=0.03, cigar=True, max_error=3000, band=(25, 512), steps=200,
                  desc="16k HiFi-shaped 10 kbp pairs, 3% error, -B auto (re-centre every 25 scores) -t 512 banded, score+CIGAR"),
+    "cfg4b": dict(pairs=16_384, length=10_000, error=0.03, cigar=True, max_error=3000, band=(25, 512), steps=200, force_band=True,
+                  desc="16k HiFi-shaped 10 kbp pairs, 3% error, -B auto (re-centre every 25 scores) -t 512 on the BANDED kernels (tuning.force_band), score+CIGAR"),
     "cfg4x": dict(pairs=16_384, length=10_000, error=0.03, cigar=True, max_error=3000, band=None, steps=100,
                   desc="16k HiFi-shaped 10 kbp pairs, 3% error, exact (unbanded), score+CIGAR"),
     "cfg5": dict(pairs=1024, length=30_000, error=0.10, cigar=True, max_error=9000, band=None, steps=25,
@@ -212,7 +216,10 @@ def host_to_host(buf, meta, wl, max_error, n_devices=1, reps=8, registered=False
                    ("" if wl["cigar"] else "_distance", " with CIGAR strings" if wl["cigar"] else ""),
            "pageable": {"cold_ms": round(ms[0], 2), "warm_ms": round(med_ms, 2), "best_ms": round(steady[0][0], 2),
                         "cold": round(n / ms[0] * 1e3, 1), "warm": round(n / med_ms * 1e3, 1),
-                        "best": round(n / steady[0][0] * 1e3, 1), "calls_ms": [round(m, 2) for m in ms]},
+                        "best": round(n / steady[0][0] * 1e3, 1), "calls_ms": [round(m, 2) for m in ms],
+                        # no call after the cold one may take a multiple of the median (an arena that is freed and re-allocated
+                        # between calls stalls behind the driver's wipe of released memory: profiles/r04/cold_long.txt)
+                        "max_over_median": round(max(ms[1:]) / sorted(ms[1:])[len(ms[1:]) // 2], 3)},
            "stages_ms": {k: (round(v, 2) if isinstance(v, float) else v) for k, v in med_stats.items()},
            "cold_stages_ms": {k: (round(v, 2) if isinstance(v, float) else v) for k, v in calls[0][1].items()},
            "input_bytes": int(buf.nbytes)}
@@ -445,10 +452,62 @@ def cli_wall(n_pairs=1_000_000, length=1000, error=0.05, max_error=300, runs=2):
             "alignments_per_s": [w[1] for w in walls], "best_wall_ms": round(best[0] * 1e3, 1), "process_s": proc, "generate_s": round(gen_s, 2)}
 
 
-def extra_config(name, force_band, steps, warmup):
+def ont_banded_leg(n=1024, length=30_000, reps=2):
+    """The reference's only published experiment, in shape (README.md:125-137 of the reference, img/approximate-time.png /
+    approximate-recall.png; BASELINE.md section 1: exact ~4400 s against beta 512 ~990-1900 s and beta 1024 ~1640-5070 s, recall
+    96.8-99.9 %, on a Nanopore set): ONT-shaped 30 kbp pairs, the exact search against the adaptive band over the same grid,
+    beta in {352, 512, 1024} x lambda in {10, 25, 50, 100, 750}: step ms (resident batch, score + CIGAR), speed-up over the exact
+    step, recall (share of pairs with the optimal score) and the pairs that finished inside the band.  Two data sets: the i.i.d.
+    model of BASELINE configs[4] (10 % single-base edits) and a long-read shaped one (6 % events of which 60 % are indels of
+    2.5 bases on average, 2 % long ones of 30-150 bases, 30 % clustered: ~10 % of the bases differ)."""
+    import torch
+    import wfagpu
+    nt = min(16, usable_cores())
+    sets = (("iid_10pct", lambda: wfagpu.generate_pairs(n, length, 0.10, seed=1000, nthreads=nt), 9000),
+            ("long_read_shaped", lambda: wfagpu.generate_pairs_model(n, length, seed=1001, error=0.06, indel_frac=0.6, indel_mean=2.5, long_frac=0.02,
+                                                                     long_min=30, long_max=150, cluster=0.3, nthreads=nt), 12000))
+    out = {"what": f"{n} x {length // 1000} kbp pairs, penalties x=2,o=3,e=1, score + CIGAR, resident batch; ms = best of {reps} steps after a warm-up",
+           "grid": "beta x lambda = the reference's README.md:125-137"}
+    for name, gen, me in sets:
+        buf, meta = gen()
+        al = wfagpu.DeviceAligner(0)
+        batch = al.upload(buf, meta)
+
+        def run(band, beta):
+            best = None
+            for _ in range(reps + 1):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                d_scores, _ = al.align(batch, PEN, max_error=me, compute_cigar=True, band=band, band_width=beta, fetch=False)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) * 1e3
+                st = al.stats()
+                if best is None or dt < best[0]:
+                    best = (dt, float(st.align_ms), int(st.pairs_banded), int(st.main_launch_tier))
+            return best, d_scores.cpu().numpy()
+
+        ex, s_exact = run(-1, 0)
+        rec = {"max_error": me, "mean_score": round(float(s_exact.mean()), 1), "exact_ms": round(ex[0], 2), "exact_kernel_ms": round(ex[1], 2), "exact_tier": ex[3],
+               "rows": []}
+        for beta in (352, 512, 1024):
+            for lam in (10, 25, 50, 100, 750):
+                r, sc = run(lam, beta)
+                rec["rows"].append({"beta": beta, "lambda": lam, "ms": round(r[0], 2), "kernel_ms": round(r[1], 2), "tier": r[3],
+                                    "speedup": round(ex[0] / r[0], 2), "kernel_speedup": round(ex[1] / r[1], 2),
+                                    "recall": round(float((sc == s_exact).mean()), 4), "inside_band": r[2],
+                                    "mean_excess": round(float(((sc - s_exact) / np.maximum(s_exact, 1)).mean()), 5)})
+        out[name] = rec
+        al.close()
+        del batch
+        torch.cuda.empty_cache()
+    return out
+
+
+def extra_config(name, steps, warmup):
     """A short leg of another BASELINE configuration on this GPU, everything the headline carries in small: resident value,
     kernel time + issue fraction, parity sample, host-to-host rate, CPU baseline."""
     wl = WORKLOADS[name]
+    force_band = bool(wl.get("force_band"))
     tuning = {"force_band": 1} if force_band else {}
     t0 = time.perf_counter()
     n = wl["pairs"]
@@ -459,12 +518,13 @@ def extra_config(name, force_band, steps, warmup):
     try:
         h2h = host_to_host(buf, meta, wl, wl["max_error"], tuning=tuning, reps=3)
         h2h_out = {"host_to_host_value": h2h["pageable"]["warm"], "host_to_host_ms_per_call": h2h["pageable"]["warm_ms"],
-                   "host_to_host_cold_ms": h2h["pageable"]["cold_ms"], "host_to_host_calls_ms": h2h["pageable"]["calls_ms"]}
+                   "host_to_host_cold_ms": h2h["pageable"]["cold_ms"], "host_to_host_calls_ms": h2h["pageable"]["calls_ms"],
+                   "host_to_host_max_over_median": h2h["pageable"]["max_over_median"]}
     except Exception as ex:
         h2h_out = {"host_to_host_value": None, "host_to_host_error": str(ex)}
-    rec, buf, meta = resident_leg(name, n, wl["max_error"], steps, warmup, 0, 1000, tuning, True, use_pmc=not force_band, data=(buf, meta))
+    rec, buf, meta = resident_leg(name, n, wl["max_error"], steps, warmup, 0, 1000, tuning, True, use_pmc=True, data=(buf, meta))
     rf = rec["roofline"]
-    out = {"workload": wl["desc"] + (" [band forced]" if force_band else ""), "pairs": n, "steps": steps, "warmup": warmup,
+    out = {"workload": wl["desc"], "pairs": n, "steps": steps, "warmup": warmup,
            "value": round(n * steps / rec["elapsed"], 1), "unit": "alignments/s", "ms_per_step": round(rec["ms_per_step"], 3),
            "gcups": round(rec["dptt"] * steps / rec["elapsed"] / 1e9, 2),
            "kernel_ms": rf["kernel_ms"], "tier": rf["tier"], "roofline_bound": rf["bound"], "roofline_frac": rf["frac"],
@@ -494,6 +554,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-to-host", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the short legs of the other BASELINE configurations and the CLI leg")
+    ap.add_argument("--ont-banded-only", action="store_true", help="only the ONT-shaped exact-against-banded grid (the reference's published experiment in shape)")
     ap.add_argument("--no-inherit-budgets", action="store_true", help="sample the score budgets again in every step")
     ap.add_argument("--force-band", action="store_true", help="banded workloads: always run the banded kernels (tuning.force_band)")
     ap.add_argument("--tuning", action="append", default=[], metavar="KEY=INT",
@@ -527,6 +588,9 @@ def main():
 
     if args.mode == "library":
         return library_mode(args, wl, n_pairs, max_error, steps)
+    if args.ont_banded_only:
+        print(json.dumps({"ont_banded": ont_banded_leg()}))
+        return
 
     dist = None
     torch.cuda.set_device(local_rank)
@@ -540,6 +604,9 @@ def main():
     tuning.update({kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.tuning})
     # (the committed counters belong to the default command: not to other sizes, and not to runs with the A/B switches set)
     default_cmd = not args.pairs and not args.max_error and not tuning
+    if wl.get("force_band"):
+        tuning["force_band"] = 1      # (part of the workload: cfg4b IS configs[3] on the banded kernels)
+        args.force_band = True
     data = make_pairs(args.workload, n_pairs, shardlib.shard_seed(1000, rank))
     pre = {}
     if rank == 0 and world == 1:
@@ -564,6 +631,7 @@ def main():
                 pre["host_to_host_value"] = h2h["pageable"]["warm"]
                 pre["host_to_host_ms_per_call"] = h2h["pageable"]["warm_ms"]
                 pre["host_to_host_cold_ms"] = h2h["pageable"]["cold_ms"]
+                pre["host_to_host_max_over_median"] = h2h["pageable"]["max_over_median"]
                 if h2h["stages_ms"].get("host_packed_batches"):
                     # the call above packed its sequences on the host (a quarter of the bytes over PCIe); the same call
                     # with the ASCII going up and the pack kernel running, for comparison
@@ -617,14 +685,23 @@ def main():
             del buf, meta, data
             # the other BASELINE GPU configurations, short legs (~60 s together)
             out["configs"] = {}
-            for key, name, forced, k, w in (("cfg2", "cfg2", False, 400, 5), ("cfg2_with_cigar", "cfg2c", False, 200, 5), ("cfg4", "cfg4", False, 8, 3), ("cfg4_band_forced", "cfg4", True, 8, 3),
-                                            ("cfg5", "cfg5", False, 4, 2)):
+            for key, name, k, w in (("cfg2", "cfg2", 400, 5), ("cfg2_with_cigar", "cfg2c", 200, 5), ("cfg4", "cfg4", 8, 3), ("cfg4_band_forced", "cfg4b", 8, 3),
+                                    ("cfg5", "cfg5", 4, 2)):
                 try:
-                    out["configs"][key] = extra_config(name, forced, k, w)
+                    out["configs"][key] = extra_config(name, k, w)
                 except Exception as ex:
                     out["configs"][key] = {"error": str(ex)}
             for key, leg in out["configs"].items():      # (flat copies: the driver's record keeps top-level scalars)
                 out[f"{key}_value"] = leg.get("value")
+            try:
+                out["ont_banded"] = ont_banded_leg()
+                rows = out["ont_banded"]["long_read_shaped"]["rows"]
+                r1024 = [r for r in rows if r["beta"] == 1024 and r["lambda"] == 100]
+                if r1024:      # (flat: the reference's suggested operating point for a large band, lambda = 100)
+                    out["ont_banded_beta1024_lambda100_speedup"] = r1024[0]["speedup"]
+                    out["ont_banded_beta1024_lambda100_recall"] = r1024[0]["recall"]
+            except Exception as ex:
+                out["ont_banded"] = {"error": str(ex)}
     if dist is not None:
         # N > 1: the ranks above never share anything but the barrier.  The reference's user calls launch_alignments()
         # ONCE and the library shards the call over the N devices from one process: host RAM bandwidth, the PCIe root and

@@ -45,6 +45,10 @@ typedef struct {
     int no_short_cigar;    /* A/B and test hook: CIGAR calls never take tier 5 (several alignments per wavefront)               */
     int no_fused_pack;     /* A/B: always run the pack kernel (default: reads of 512 bases and more are packed by the wavefront
                               kernels while they stage them)                                                                    */
+    int no_kernel_walk;    /* A/B and test hook: the one-wave wavefront kernels never walk their alignments back themselves
+                              (wfa_walk_kernel does, in the backtrace pass: the round-4 path)                                    */
+    int band_tier;         /* A/B hook: wavefronts per alignment of the banded kernels -- 1: one, 2: four, 3: sixteen (0: by the
+                              wavefronts a CU ends up holding, plan_tier)                                                        */
     int emit_pairs;        /* lane-per-alignment CIGAR replay with the sequences staged in LDS: alignments per wavefront
                               (8..64; 0: automatic -- as many as keep the most lanes resident per CU)                          */
 } wfagpu_amd_tuning_t;
@@ -110,6 +114,7 @@ typedef struct {
     int sample_launches;
     unsigned int sample_passes;
     int waves_per_simd_tier0;          /* instantiation the first wavefront launch used (one-wave exact kernels: 8, 7, 6 or 4) */
+    unsigned int pairs_walked_in_kernel; /* pairs of chains whose wavefront kernels walked their alignments back themselves (no wfa_walk_kernel) */
     unsigned int pairs_trace_split;    /* long alignments whose backtrace was walked by the wave-per-alignment kernel and replayed by
                                           the lane-per-alignment kernel (passes of 8192 and more; tuning.trace_mode 4: any)        */
 } wfagpu_amd_stats_t;

@@ -23,12 +23,12 @@ def run(al, batch, me, band, beta, cigar=True, reps=2):
 
 if which in ("all", "cfg4"):
     buf, meta = wfagpu.generate_pairs(16384, 10000, 0.03, seed=1000, nthreads=16)
-    for mt in (0, 1):
-        al = wfagpu.DeviceAligner(0, force_band=1, min_tier=mt)
+    for mt in (1, 2, 3):
+        al = wfagpu.DeviceAligner(0, force_band=1, band_tier=mt)
         batch = al.upload(buf, meta)
         for cigar in (True, False):
             r, s = run(al, batch, 3000, 25, 512, cigar=cigar)
-            print(f"cfg4 band forced min_tier={mt} cigar={cigar}: step {r[0]:.2f} ms main {r[1]:.2f} align {r[2]:.2f} trace {r[3]:.2f} tiers {r[4]} banded {r[5]} bpc {r[6]} cells {r[7]/1e9:.2f} G", flush=True)
+            print(f"cfg4 band forced band_tier={mt} cigar={cigar}: step {r[0]:.2f} ms main {r[1]:.2f} align {r[2]:.2f} trace {r[3]:.2f} tiers {r[4]} banded {r[5]} bpc {r[6]} cells {r[7]/1e9:.2f} G", flush=True)
         al.close()
     al = wfagpu.DeviceAligner(0)
     batch = al.upload(buf, meta)
@@ -45,11 +45,14 @@ if which in ("all", "ont"):
     ex_ms = r[0]
     print(f"ont exact: step {r[0]:.2f} ms main {r[1]:.2f} align {r[2]:.2f} trace {r[3]:.2f} tiers {r[4]} cells {r[7]/1e9:.2f} G mean score {s_exact.mean():.0f}", flush=True)
     al.close()
-    al = wfagpu.DeviceAligner(0, force_band=1)
-    batch = al.upload(buf, meta)
-    for beta in (352, 512, 1024):
-        for lam in (10, 25, 50, 100, 750):
-            r, s = run(al, batch, 9000, lam, beta, reps=1)
-            print(f"ont beta {beta} lambda {lam}: step {r[0]:.2f} ms main {r[1]:.2f} align {r[2]:.2f} trace {r[3]:.2f} tiers {r[4]} banded {r[5]} bpc {r[6]} cells {r[7]/1e9:.2f} G "
-                  f"speedup {ex_ms / r[0]:.2f}x recall {(s == s_exact).mean() * 100:.2f} % excess {((s - s_exact) / np.maximum(s_exact, 1)).mean() * 100:.2f} %", flush=True)
-    al.close()
+    tiers = [int(t) for t in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0]
+    for bt in tiers:
+        al = wfagpu.DeviceAligner(0, force_band=1, band_tier=bt)
+        batch = al.upload(buf, meta)
+        print("band_tier", bt)
+        for beta in (352, 512, 1024):
+            for lam in ((10, 25, 50, 100, 750) if bt == 0 else (25, 750)):
+                r, s = run(al, batch, 9000, lam, beta, reps=1)
+                print(f"ont beta {beta} lambda {lam}: step {r[0]:.2f} ms main {r[1]:.2f} align {r[2]:.2f} trace {r[3]:.2f} tiers {r[4]} banded {r[5]} bpc {r[6]} cells {r[7]/1e9:.2f} G "
+                      f"speedup {ex_ms / r[0]:.2f}x recall {(s == s_exact).mean() * 100:.2f} % excess {((s - s_exact) / np.maximum(s_exact, 1)).mean() * 100:.2f} %", flush=True)
+        al.close()

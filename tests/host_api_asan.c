@@ -157,6 +157,61 @@ static void readers(void) {
     }
     memset(&s, 0, sizeof s);
     CHECK(read_seq_file(&s, path_buf[0], 1000000) && s.num_pairs == 11000);      /* -n past the end of the file */
+    /* the file is parsed in strips by several threads (sequence_reader.c): the same records and the same bytes from 1, 2, 3, 7
+     * and 32 strips, with -n cutting inside a strip, at a strip's first pair and beyond the file; lines with CR LF, blank lines
+     * and a doubled pattern line (the last one counts) across the cuts */
+    {
+        size_t len2 = 0;
+        char* mixed = malloc(cap + (1u << 20));
+        for (int i = 0; i < 9000; ++i) {
+            const size_t pl = rnd() % 300, tl = rnd() % 300;
+            if (i % 97 == 0) { mixed[len2++] = '>'; mixed[len2++] = 'T'; mixed[len2++] = 'T'; mixed[len2++] = '\n'; }      /* overwritten by the next '>' line */
+            mixed[len2++] = '>'; for (size_t j = 0; j < pl; ++j) mixed[len2++] = "ACGTN"[rnd() % 5 == 4 && rnd() % 50 == 0 ? 4 : rnd() & 3];
+            if (i % 3 == 0) mixed[len2++] = '\r';
+            mixed[len2++] = '\n';
+            if (i % 41 == 0) mixed[len2++] = '\n';
+            mixed[len2++] = '<'; for (size_t j = 0; j < tl; ++j) mixed[len2++] = "ACGT"[rnd() & 3];
+            if (i % 3 == 0) mixed[len2++] = '\r';
+            mixed[len2++] = '\n';
+        }
+        const char* mp = write_file(1, "mixed.seq", mixed, len2);
+        static const size_t limits[] = {0, 1, 2999, 3000, 8999, 9000, 20000};
+        for (size_t li = 0; li < sizeof limits / sizeof limits[0]; ++li) {
+            sequence_set_t ref;
+            memset(&ref, 0, sizeof ref);
+            sequence_reader_force_threads = 1;
+            CHECK(read_seq_file(&ref, mp, limits[li]));
+            CHECK(ref.num_pairs == (limits[li] && limits[li] < 9000 ? limits[li] : 9000u));
+            check_set(&ref);
+            static const int strips[] = {2, 3, 7, 32};
+            for (size_t si = 0; si < sizeof strips / sizeof strips[0]; ++si) {
+                sequence_set_t got;
+                memset(&got, 0, sizeof got);
+                sequence_reader_force_threads = strips[si];
+                CHECK(read_seq_file(&got, mp, limits[li]));
+                CHECK(got.num_pairs == ref.num_pairs && got.sequences_buffer_used == ref.sequences_buffer_used);
+                CHECK(memcmp(got.sequences_metadata, ref.sequences_metadata, ref.num_pairs * sizeof(sequence_pair_t)) == 0);
+                CHECK(memcmp(got.sequences_buffer, ref.sequences_buffer, ref.sequences_buffer_used) == 0);
+                free_sequence_set(&got);
+            }
+            free_sequence_set(&ref);
+        }
+        /* a malformed line deep inside the file is found whichever strip it falls into */
+        mixed[len2 / 2] = '\n'; mixed[len2 / 2 + 1] = 'A';
+        mp = write_file(1, "mixed_bad.seq", mixed, len2);
+        for (int t = 1; t <= 7; t += 3) {
+            sequence_set_t got;
+            memset(&got, 0, sizeof got);
+            sequence_reader_force_threads = t;
+            CHECK(!read_seq_file(&got, mp, 0));
+            free_sequence_set(&got);
+            memset(&got, 0, sizeof got);
+            CHECK(read_seq_file(&got, mp, 100) && got.num_pairs == 100);      /* (-n stops before it, like the reference's reader) */
+            free_sequence_set(&got);
+        }
+        sequence_reader_force_threads = 0;
+        free(mixed);
+    }
     free_sequence_set(&s);
     free(big);
     static const char crlf[] = ">ACGT\r\n<ACGA\r\n>AC\r\n<\r\n";

@@ -63,6 +63,7 @@
 //   align/loop_lean_hbm.inc   lean score loop of the tiers whose ring lives in HBM
 //   align/loop_careful.inc    the careful score step (WFA2 to the letter)
 //   align/band_window.inc, align/loop_banded.inc   the adaptive band: the reference's window rule, the banded search
+//   align/walk_epilogue.inc   the one-wave tiers walk a finished alignment back themselves (tiles through the freed ring LDS)
 #include <type_traits>
 
 #include "wfa_device.h"
@@ -220,9 +221,12 @@ wfa_align_kernel(const WfaAlignParams p) {
   const int bkm = p.book_mask;                                // row book: 64 (or more) entries indexed by score & bkm
   int* red = reinterpret_cast<int*>(Tw + p.seq_words_cap);    // [3][8] per-score reduction slots (NW > 1)
   uint32_t* bslot = reinterpret_cast<uint32_t*>(red + 24);    // [2] broadcast slots
-  RowBook<NW> book;
+  // (the banded search keeps the book in registers in every tier: all waves of a workgroup derive the same windows, each keeps
+  // its own copy -- no LDS round trip, no barrier for the book: loop_banded.inc)
+  constexpr int BOOK_NW = BANDED ? 1 : NW;
+  RowBook<BOOK_NW> book;
   book.reset();
-  if constexpr (NW == 1) { book.A = book.I = book.D = nullptr; }
+  if constexpr (BOOK_NW == 1) { book.A = book.I = book.D = nullptr; }
   else { book.A = reinterpret_cast<int*>(bslot + 2); book.I = book.A + (bkm + 1); book.D = book.I + (bkm + 1); }
 
   uint32_t chunk_cur = 0, chunk_left = 0;   // arena units owned by this block
@@ -376,11 +380,9 @@ wfa_align_kernel(const WfaAlignParams p) {
           for (int i = tid; i < rs; i += NT) hm[i] = (OffT)max(min(plen + (i - kidx0), tlen), 0);
         }
       }
-      if constexpr (NW == 1) book.reset();
-      else {
-        for (int i = tid; i <= bkm; i += NT) { book.A[i] = book.I[i] = book.D[i] = ROW_NONE_A; }
-        if (tid < 24) red[tid] = (tid & 7) == 6 ? 0 : (((tid & 7) & 1) ? INT_MIN : INT_MAX);
-      }
+      if constexpr (BOOK_NW == 1) book.reset();
+      else { for (int i = tid; i <= bkm; i += NT) { book.A[i] = book.I[i] = book.D[i] = ROW_NONE_A; } }
+      if constexpr (NW > 1) { if (tid < 24) red[tid] = (tid & 7) == 6 ? 0 : (((tid & 7) & 1) ? INT_MIN : INT_MAX); }
       block_sync<NW>();
 
       // A fresh chunk of the backtrace arena for this workgroup, at least `units` (16-byte units) long: one returning
@@ -506,7 +508,14 @@ wfa_align_kernel(const WfaAlignParams p) {
       if constexpr (BT) {
         if (status == WFA_ST_DONE) {
           tab_flush(s);
-          if (tid == 0) cold_params()->bt_final_row[pair] = tab_base;
+          bool walked = false;
+          if constexpr (NW == 1 && !GLOBAL_RING) {
+            if (cold_params()->walk_in_kernel) {
+              #include "align/walk_epilogue.inc"
+            }
+          }
+          // (WFA_ROW_NONE: walked here -- wfa_walk_kernel skips the pair, the replay finds the op list through cigar_off)
+          if (tid == 0 && status == WFA_ST_DONE) cold_params()->bt_final_row[pair] = walked ? WFA_ROW_NONE : tab_base;
         }
       }
     }
@@ -619,7 +628,7 @@ size_t wfa_align_lds_bytes(const WfaAlignParams& p, int tier) {
   const size_t seq = (size_t)2 * p.seq_words_cap * 4;
   // reduction slots [24] + broadcast [2] + (NW > 1) row book [3][book]
   const size_t bk = (size_t)p.book_mask + 1;
-  const size_t meta = (size_t)(24 + 2 + (tier == 0 ? 0 : 3 * bk)) * 4;     // (tiers 1, 2, 3, 4: row book in LDS)
+  const size_t meta = (size_t)(24 + 2 + ((tier == 0 || p.band_width > 0) ? 0 : 3 * bk)) * 4;     // (tiers 1, 2, 3, 4 of the exact search: row book in LDS)
   return ((ring + seq + meta) + 15) & ~(size_t)15;
 }
 

@@ -27,8 +27,6 @@
 
 namespace {
 
-enum : uint8_t { OP_X = 1, OP_I = 2, OP_D = 3, OP_EXT_AFTER = 0x10 };
-
 // How the replay reads a packed sequence: words i and i+1 at a time, at positions that only move forward.
 //   SeqDirect  the whole sequence is addressable (LDS copy, or global memory)
 //   SeqWindow  8 words per lane in LDS, refilled from global memory when the position leaves them: 64 bytes of LDS per
@@ -310,6 +308,7 @@ __global__ void __launch_bounds__(WALK_WAVES * 64) wfa_walk_kernel(const WfaTrac
     uint32_t pair = 0;
     if (active) pair = p.work ? p.work[gid] : gid;
     if (active && p.status[pair] != WFA_ST_DONE) active = false;
+    if (active && p.bt_final_row[pair] == WFA_ROW_NONE) active = false;      // (walked by its wavefront kernel: the op list is in the arena)
     int score = 0, plen = 0, tlen = 0;
     if (active) {
       score = p.score[pair];
@@ -354,7 +353,7 @@ __global__ void __launch_bounds__(TRACE_THREADS) wfa_emit_win_kernel(const WfaTr
     pv.g = p.packed + ((p.raw ? mp.pattern_offset : mp.pattern_offset_packed) >> 2);
     tv.g = p.packed + ((p.raw ? mp.text_offset : mp.text_offset_packed) >> 2);
     pv.nwords = ((plen + (1 << sh) - 1) >> sh) + 1; tv.nwords = ((tlen + (1 << sh) - 1) >> sh) + 1;
-    q = p.ops + p.cigar_off[pair];
+    { const unsigned long long off = p.cigar_off[pair]; q = ((off & WFA_OPS_IN_ARENA) ? p.arena : p.ops) + (off & ~WFA_OPS_IN_ARENA); }
     nops = p.cigar_len[pair];
     fail = nops == 0xFFFFFFFFu;
   }
@@ -518,7 +517,8 @@ __global__ void __launch_bounds__(TRACE_THREADS) wfa_emit_kernel(const WfaTraceP
     plen = (int)mp.pattern_len; tlen = (int)mp.text_len;
     Pw = p.packed + ((p.raw ? mp.pattern_offset : mp.pattern_offset_packed) >> 2);
     Tw = p.packed + ((p.raw ? mp.text_offset : mp.text_offset_packed) >> 2);
-    q = p.ops + p.cigar_off[pair];
+    const unsigned long long off = p.cigar_off[pair];
+    q = ((off & WFA_OPS_IN_ARENA) ? p.arena : p.ops) + (off & ~WFA_OPS_IN_ARENA);
     nops = p.cigar_len[pair];
     fail = nops == 0xFFFFFFFFu;
   }
@@ -1027,16 +1027,17 @@ bool wfa_launch_trace(const WfaTraceParams& p, hipStream_t stream, hipEvent_t ev
   }
   uint32_t walk_grid = (p.n_work + WALK_WAVES * 64 - 1) / (WALK_WAVES * 64);
   if (p.walk_grid_cap > 0 && walk_grid > (uint32_t)p.walk_grid_cap) walk_grid = (uint32_t)p.walk_grid_cap;
-  wfa_launch_timed(wfa_walk_kernel, dim3(walk_grid), dim3(WALK_WAVES * 64), 0, stream, ev0, (hipEvent_t) nullptr, p);
+  hipEvent_t ev_first = ev0;      // (start of whichever kernel comes first)
+  if (!p.skip_walk) { wfa_launch_timed(wfa_walk_kernel, dim3(walk_grid), dim3(WALK_WAVES * 64), 0, stream, ev0, (hipEvent_t) nullptr, p); ev_first = nullptr; }
   if (p.seq_lds_stride == 0) {      // (sequences too long to stage 64 pairs, or tuning.trace_mode 1: 8-word LDS windows)
-    wfa_launch_timed(wfa_emit_win_kernel, grid, block, 0, stream, (hipEvent_t) nullptr, ev1, p);
+    wfa_launch_timed(wfa_emit_win_kernel, grid, block, 0, stream, ev_first, ev1, p);
     return true;
   }
   const size_t lds = (size_t)p.emit_pairs * p.seq_lds_stride * 4;
   static thread_local size_t allowed[16] = {0};
   allow_lds(wfa_emit_kernel<true, false>, lds, allowed);
   const dim3 grid_e((p.n_work + (uint32_t)p.emit_pairs - 1) / (uint32_t)p.emit_pairs);
-  wfa_launch_timed(wfa_emit_kernel<true, false>, grid_e, block, lds, stream, (hipEvent_t) nullptr, p.text_scratch ? (hipEvent_t) nullptr : ev1, p);
+  wfa_launch_timed(wfa_emit_kernel<true, false>, grid_e, block, lds, stream, ev_first, p.text_scratch ? (hipEvent_t) nullptr : ev1, p);
   if (p.text_scratch)
     wfa_launch_timed(wfa_text_compact_kernel, dim3((p.n_work + COMPACT_WAVES * 64 - 1) / (COMPACT_WAVES * 64)), dim3(COMPACT_WAVES * 64), 0, stream, (hipEvent_t) nullptr, ev1, p);
   return true;

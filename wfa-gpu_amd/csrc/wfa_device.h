@@ -46,6 +46,13 @@ enum : uint32_t {
 //   bit  0    I came from I (gap extension) rather than from M (gap open)
 enum : uint32_t { BT_M_NONE = 0, BT_M_X = 12, BT_M_D = 8, BT_M_I = 4, BT_M_MASK = 12, BT_D_EXT = 2, BT_I_EXT = 1 };
 
+// Operations of a reversed op list (what the backward walk leaves for the replay): the kind, and whether a run of matches
+// follows the operation (re-derived by the replay as a longest common prefix).
+enum : uint8_t { OP_X = 1, OP_I = 2, OP_D = 3, OP_EXT_AFTER = 0x10 };
+// cigar_off of an alignment between walk and replay: byte offset of its op list -- in the op scratch, or (this bit set) in the
+// backtrace ARENA, where the one-wave wavefront kernels leave it when they walk their own alignments (WfaAlignParams::walk_in_kernel)
+#define WFA_OPS_IN_ARENA (1ull << 63)
+
 #define WFA_ROW_NONE 0xFFFFFFFFu
 // The lean cells of the 16-bit LDS tiers (0, 1, 2, 4) never switch a lane off: the lanes of a row's last 64-diagonal
 // chunk that lie beyond its upper limit store NULL offsets into that many cells behind the row (every ring row carries
@@ -90,7 +97,14 @@ struct WfaAlignParams {
   unsigned long long arena_units;        // capacity in 16-byte units
   unsigned long long* arena_top;         // bump pointer (units)
   uint32_t chunk_units;          // refill granularity
-  uint32_t* bt_final_row;        // [pair] out: unit offset of the pair's row table
+  uint32_t* bt_final_row;        // [pair] out: unit offset of the pair's row table (WFA_ROW_NONE once the kernel has walked the alignment itself)
+  // The one-wave LDS tiers walk a finished alignment back at once (round 5): its origin rows and row table are still in this
+  // XCD's L2 / the memory-side cache, the ring's LDS is free for the tiles, and the op list goes into the workgroup's own arena
+  // chunk -- no wfa_walk_kernel re-reading 4.6 GB from HBM 25 ms later (the reference walks at the end of its kernel too:
+  // lib/kernels/sequence_alignment_kernel.cu:659-683).  1: do it (the host has checked that ring LDS holds tile + op list).
+  int walk_in_kernel;
+  unsigned long long* cigar_off; // [pair] out (walk_in_kernel): WFA_OPS_IN_ARENA | byte offset of the op list in the arena
+  uint32_t* cigar_len;           // [pair] out (walk_in_kernel): number of operations
   // global-memory ring (only the GLOBAL_RING instantiation)
   void* gring;                   // per-block slices of gring_stride bytes
   int ring16;                    //   16-bit offsets in it (sequences <= 32766 bases), else 32-bit
@@ -118,6 +132,7 @@ struct WfaTraceParams {
   int group;                     // wave kernel: alignments per wavefront (1, 2, 4 or 8: 64/group lanes each, own LDS share)
   int lane_fused;                // lane-per-alignment path: walk + replay in ONE kernel, op lists of ops_lds_bytes per lane in LDS (short alignments)
   int walk_grid_cap;             // workgroups of wfa_walk_kernel (it strides over the list); 0: one per 256 list entries
+  int skip_walk;                 // lane path: every finished pair of the list was walked by its wavefront kernel: no wfa_walk_kernel
   int walk_only;                 // wave kernel: only the walk (op list -> slot w of ops_slot bytes in the global scratch); wfa_emit_kernel replays
   uint32_t ops_slot;
   int seq_words_cap;             // wave kernel: LDS words reserved per sequence

@@ -431,23 +431,39 @@ int window_width(long long S, int o, int e, unsigned max_seq_len) {
 // Smallest tier whose LDS footprint fits a score budget S.
 // few_pairs: the list is expected to hold fewer pairs than the device has workgroup slots (the re-run of a long-read batch's
 // budget misses): what counts is the latency of ONE alignment, so wide wavefronts take sixteen waves instead of four.
-bool plan_tier(const wfagpu_amd_ctx* c, WfaAlignParams& p, int max_score, unsigned max_seq_len, bool bt, bool raw, TierPlan* out, bool few_pairs = false) {
+bool plan_tier(const wfagpu_amd_ctx* c, WfaAlignParams& p, int max_score, unsigned max_seq_len, bool bt, bool raw, TierPlan* out, bool few_pairs = false,
+               uint32_t n_pairs = 0) {
   p.max_score = max_score;
   if (p.band_width > 0) {
     // Adaptive band: a ring row holds the band_width diagonals of its score, stored relative to the row's own lower limit,
     // between two guard zones of 4 dm + 2 NULL cells (see the kernel: the band moves by at most two diagonals per score),
     // plus the padding chunk of the lean cells.
     p.rs = ((p.band_width + 2 * (4 * p.dm + 2) + 2 + 1) & ~1) + WFA_RING_ROW_PAD;
-    // One wavefront per alignment up to 512 diagonals, four up to 1024, sixteen beyond (the per-score bookkeeping is
-    // repeated by every wave of a workgroup).
-    constexpr int t0_max = 512;
-    int t = (p.band_width <= t0_max && p.dm <= 64) ? 0 : (p.band_width <= 1024 ? 1 : 2);
-    if (c->tuning.min_tier >= 1 && c->tuning.min_tier <= 2) t = std::max(t, c->tuning.min_tier);      // (test hook)
-    const size_t lds = wfa_align_lds_bytes(p, t);
-    if (lds > c->lds_per_block_max || max_seq_len > 32766u || max_score > 30000) return false;
-    const int nb = wfa_align_max_blocks_per_cu(t, bt, false, true, lds);
-    if (nb < 1) return false;
-    *out = {t, p.band_width, max_score, lds, nb};
+    // (the banded kernels keep their row book in one register per wave, lane = score & 63: ring depths to 64)
+    if (max_seq_len > 32766u || max_score > 30000 || p.dm > 64) return false;
+    // Waves per alignment (1, 4 or 16) by what the DEVICE ends up holding, not by the band width alone (round 5).  A banded row
+    // is band_width / 64 chunks whatever the score, every chunk a chain of dependent LDS round trips, so the kernel lives on
+    // the waves a SIMD can switch between: 16k x 10 kbp pairs at a band of 512 on one wave each are 10 rings = 10 waves per CU
+    // (LDS-bound, 2.5 per SIMD: 355 G cells/s against 607 G for the exact four-wave tier on the same pairs); 1024 x 30 kbp
+    // pairs one wave each are ONE wave per SIMD.  The smallest tier that keeps 16 waves per CU resident (four per SIMD) -- with
+    // the workgroups LDS allows and the pairs the launch has --, else the one that keeps the most.
+    const int min_t = (c->tuning.min_tier >= 1 && c->tuning.min_tier <= 2) ? c->tuning.min_tier : 0;      // (test hook)
+    const uint32_t pairs_per_cu = n_pairs ? std::max<uint32_t>(1u, (n_pairs + (uint32_t)c->num_cus - 1u) / (uint32_t)c->num_cus) : 1u << 20;
+    int best_t = -1, best_waves = -1, best_nb = 0; size_t best_lds = 0;
+    const int forced_t = (c->tuning.band_tier >= 1 && c->tuning.band_tier <= 3) ? c->tuning.band_tier - 1 : -1;      // (A/B hook)
+    for (int t = forced_t >= 0 ? forced_t : min_t; t < (forced_t >= 0 ? forced_t + 1 : 3); ++t) {
+      const int nw = t == 0 ? 1 : (t == 1 ? 4 : 16);
+      if (forced_t < 0 && t > min_t && p.band_width < 48 * nw) break;            // (a wave without a chunk of its own only waits at the barrier)
+      const size_t lds = wfa_align_lds_bytes(p, t);
+      if (lds > c->lds_per_block_max) continue;
+      const int nb = wfa_align_max_blocks_per_cu(t, bt, false, true, lds);
+      if (nb < 1) continue;
+      const int waves = (int)std::min<uint32_t>(32u, std::min<uint32_t>((uint32_t)nb, pairs_per_cu) * (uint32_t)nw);
+      if (waves > best_waves) { best_t = t; best_waves = waves; best_nb = nb; best_lds = lds; }
+      if (waves >= 16) break;
+    }
+    if (best_t < 0) return false;
+    *out = {best_t, p.band_width, max_score, best_lds, best_nb};
     return true;
   }
   const int width = window_width(max_score, p.oe - p.e, p.e, max_seq_len);
@@ -722,14 +738,14 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       unfinished_at_sync = -1;      // (work is being queued: the last count is history)
       uint32_t* const chain_list = cur;
       const uint32_t n_chain = n_cur;
-      struct Link { int tier; int ct_list; int ct_cells; hipEvent_t e0, e1; bool banded; bool budgeted; bool first_round; uint32_t n_in; } link[2];
+      struct Link { int tier; int ct_list; int ct_cells; hipEvent_t e0, e1; bool banded; bool budgeted; bool first_round; uint32_t n_in; bool walked; } link[2];
       int n_links = 0;
       long long s_hi = 0;                       // no pair of this chain finishes with a larger score
       const unsigned long long* cur_len_dev = nullptr;
       for (;;) {
         Link& L = link[n_links];
         L = {0, n_links ? CT_LIST2 : CT_LIST, n_links ? CT_LCELLS2 : CT_LCELLS, n_links ? c->ev_b0 : c->ev_a0, n_links ? c->ev_b1 : c->ev_a1,
-             false, budget_round, round == 0, n_cur};
+             false, budget_round, round == 0, n_cur, false};
         TierPlan tp;
         ap.budget = budget_round ? budgets : nullptr;
         // banded first attempt (packed class only); whatever it cannot finish goes to the exact tiers
@@ -737,7 +753,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         // towards the end like the exact one; a pair whose banded score exceeds its budget is re-run exactly like any miss)
         ap.band_width = (want_band && allow_band && !raw && round == 0) ? band_width : 0;
         ap.band_period = band;
-        if (ap.band_width > 0 && !plan_tier(c, ap, std::min(max_score, 30000), max_len, cigar_now, raw, &tp)) ap.band_width = 0;
+        if (ap.band_width > 0 && !plan_tier(c, ap, std::min(max_score, 30000), max_len, cigar_now, raw, &tp, false, n_cur)) ap.band_width = 0;
         L.banded = ap.band_width > 0;
         // (the speculative re-run of budget misses: a percent or two of the chain's pairs)
         const bool few_pairs = n_links == 1 && link[0].budgeted && (n_chain / 50u) <= 2u * (unsigned)c->num_cus;
@@ -753,6 +769,20 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
           const int g = (int)std::min<uint32_t>(n_cur, (uint32_t)(c->num_cus * tp.blocks_per_cu));
           if (c->gring.ensure(stride * g, st)) return -1;
           ap.gring = c->gring.p; ap.gring_stride = stride;
+        }
+        // The one-wave LDS tiers walk a finished alignment back themselves (align/walk_epilogue.inc) when what follows is the
+        // lane-per-alignment replay -- sequences of 64 pairs stageable in LDS, no pair of the chain short enough for the
+        // one-kernel backtrace of short alignments (which walks by itself) -- and the ring's LDS holds a tile and the op list.
+        {
+          const unsigned per_seq_w = raw ? (max_len + 3) / 4 + 1 : (max_len + 15) / 16 + 1;
+          const bool lane_replay = (size_t)64 * ((2 * per_seq_w) | 1u) * 4 <= (48u << 10);
+          const size_t ring_bytes = (size_t)(ap.dm + 2 * ap.de + ((tp.tier == 0 && ap.band_width <= 0) ? 1 : 0)) * (size_t)ap.rs * 2;
+          const int s_cap = std::min(ap.max_score, 30000);
+          L.walked = cigar_now && tp.tier == 0 && !c->tuning.no_kernel_walk && lane_replay && s_cap > 124 &&
+                     ring_bytes >= (size_t)64 * 16 + (((size_t)s_cap + 3) & ~(size_t)3) + 16;
+          ap.walk_in_kernel = L.walked ? 1 : 0;
+          ap.cigar_off = static_cast<unsigned long long*>(c->cig_off[c->out_set].p);
+          ap.cigar_len = static_cast<uint32_t*>(c->cig_len[c->out_set].p);
         }
         ap.dbg_times = nullptr; ap.dbg_cap = 0;
         if (c->tuning.timed_barriers && round == 0 && cigar_now && !raw && !L.banded && (tp.tier == 1 || tp.tier == 4)) {
@@ -957,6 +987,10 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         tp.cigar_len = static_cast<uint32_t*>(c->cig_len[c->out_set].p);
         // (ev_t0 / ev_t1: start of the first and end of the last backtrace kernel)
         tp.walk_grid_cap = 2 * c->num_cus;      // (two workgroups = eight wavefronts per CU: trace_kernel.hip, wfa_walk_kernel)
+        // (every link of the chain walked its own alignments: no wfa_walk_kernel; a mixed chain runs it, and it skips the walked pairs)
+        tp.skip_walk = 1;
+        for (int l = 0; l < n_links; ++l) if (!link[l].walked) tp.skip_walk = 0;
+        if (tp.skip_walk) c->stats.pairs_walked_in_kernel += n_chain;
         traced = wfa_launch_trace(tp, st, c->ev_t0, c->ev_t1);
         HIP_TRY(hipGetLastError());
         // ---- pairs that ran out of arena go into the next pass (CIGAR calls only: score-only calls have no arena) ----

@@ -17,7 +17,9 @@ typedef struct {
     size_t num_pairs;
 } sequence_set_t;
 
-/* max_pairs == 0 reads everything.  Return false on I/O or format errors. */
+/* max_pairs == 0 reads everything.  Return false on I/O or format errors.  `set` must be empty (zeroed).  .seq files are
+ * mapped and parsed by all the cores the process may use (sequence_reader.c). */
+extern int sequence_reader_force_threads;      /* test hook: that many strips whatever the file's size (0: automatic) */
 bool read_seq_file(sequence_set_t* set, const char* path, size_t max_pairs);
 bool read_fasta_pair_files(sequence_set_t* set, const char* query_path, const char* target_path, size_t max_pairs);
 void free_sequence_set(sequence_set_t* set);

@@ -437,19 +437,26 @@ def cli_wall(n_pairs=1_000_000, length=1000, error=0.05, max_error=300, runs=2):
         subprocess.run([gen, "-n", str(n_pairs), "-l", str(length), "-e", str(error), "-s", "9", "-t", str(min(16, usable_cores())), "-o", seq],
                        check=True, timeout=600, capture_output=True)
         gen_s = time.perf_counter() - t0
-        walls, proc = [], []
+        walls, proc, stages, reads = [], [], [], []
         for _ in range(runs):
             t0 = time.perf_counter()
-            r = subprocess.run([cli, "-i", seq, "-x", "-e", str(max_error)], capture_output=True, text=True, timeout=600)
+            # (--stage-times: the library's own stage clocks of the call on stderr, so that a slow run says where it was slow)
+            r = subprocess.run([cli, "-i", seq, "-x", "-e", str(max_error), "--stage-times"], capture_output=True, text=True, timeout=600)
             proc.append(round(time.perf_counter() - t0, 3))
             m = re.search(r"Wall time: ([0-9.]+)s \(([0-9.]+) alignments per second\)", r.stdout)
             if r.returncode != 0 or not m:
                 return {"error": f"exit code {r.returncode}: {(r.stderr or r.stdout)[-300:]}"}
             walls.append((float(m.group(1)), float(m.group(2))))
+            st = re.search(r"\[wfagpu timing\] device 0 [^\n]*", r.stderr)
+            bu = re.search(r"\[wfagpu timing\]   bring-up: [^\n]*", r.stderr)
+            rd = re.search(r"File read: ([0-9.]+)s", r.stderr)
+            stages.append(((st.group(0)[len("[wfagpu timing] "):] if st else "") + (" | " + bu.group(0)[len("[wfagpu timing]   "):] if bu else "")) or None)
+            reads.append(float(rd.group(1)) if rd else None)
     best = min(walls)
     return {"what": "bin/wfa.affine.gpu -i <1M x 1 kbp @ 5 % .seq> -x -e 300, fresh process per run: the 'Wall time' line it prints",
             "unit": "alignments/s", "pairs": n_pairs, "value": round(max(w[1] for w in walls), 1), "wall_s": [w[0] for w in walls],
-            "alignments_per_s": [w[1] for w in walls], "best_wall_ms": round(best[0] * 1e3, 1), "process_s": proc, "generate_s": round(gen_s, 2)}
+            "alignments_per_s": [w[1] for w in walls], "best_wall_ms": round(best[0] * 1e3, 1), "process_s": proc, "file_read_s": reads,
+            "stage_clocks": stages, "generate_s": round(gen_s, 2)}
 
 
 def ont_banded_leg(n=1024, length=30_000, reps=2):
@@ -561,12 +568,15 @@ def main():
                     help="wfagpu_amd_tuning_t field for A/B runs (waves_per_simd=7, max_blocks_per_cu=24, ...)")
     ap.add_argument("--virtual-devices", type=int, default=0,
                     help="--mode library: shard the call over this many device slots mapped onto the visible GPUs")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="--gpus 1: still run as a torch.distributed job of one rank (self-spawned torchrun child, RCCL process group, "
+                         "barrier + max-over-ranks all-reduce + all-gather executed) -- exercises the N > 1 harness on one GPU")
     ap.add_argument("--cpu-harness", action="store_true",
                     help="CPU-only check of the rank/timing harness (gloo; the step is the ORACLE, nothing is measured)")
     args = ap.parse_args()
 
     in_torchrun = "WORLD_SIZE" in os.environ and "RANK" in os.environ
-    if args.mode == "ranks" and args.gpus > 1 and not in_torchrun:
+    if args.mode == "ranks" and (args.gpus > 1 or args.force_dist) and not in_torchrun:
         self_spawn(args)
 
     wl = dict(WORKLOADS[args.workload])
@@ -595,7 +605,7 @@ def main():
     dist = None
     torch.cuda.set_device(local_rank)
     host_grp = None
-    if world > 1:
+    if world > 1 or (args.force_dist and in_torchrun):
         dist = shardlib.init_distributed("nccl", device=torch.device("cuda", local_rank))   # "nccl" is RCCL on ROCm
         host_grp = shardlib.host_group(dist)
 
@@ -664,7 +674,8 @@ def main():
                        "band": {"period": band[0], "width": band[1], "forced": bool(args.force_band),
                                 "policy": "the band is used only where the sampled score budgets leave the exact wavefronts wider "
                                           "than 2.5 bands (tiers.pairs_banded counts the pairs it finished)"} if band else None,
-                       "sharding": f"batch-sharded x{world}, no collective", "mode": "ranks"},
+                       "sharding": f"batch-sharded x{world}, no collective", "mode": "ranks",
+                       "process_group": ("rccl (backend nccl), world size %d: barrier + max all-reduce + all-gather of the clocks" % world) if dist is not None else None},
             "gcups": round(gcups, 2),
             # every rank's own clock over the same K steps (the aggregate above uses the slowest: max over ranks)
             "per_rank": [{"rank": r, "ms_per_step": round(e / steps * 1e3, 3), "value": round(n_pairs * steps / e, 1)}
@@ -791,7 +802,7 @@ def cpu_harness(args, rank, world, n_pairs, steps):
     import oracle_lib
     import shardlib
     import wfagpu
-    dist = shardlib.init_distributed("gloo") if world > 1 else None
+    dist = shardlib.init_distributed("gloo") if (world > 1 or (args.force_dist and "WORLD_SIZE" in os.environ)) else None
     n = min(n_pairs, 64)
     buf, meta = wfagpu.generate_pairs(n, 120, 0.05, seed=shardlib.shard_seed(1000, rank))
     state = {}

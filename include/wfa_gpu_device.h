@@ -45,10 +45,12 @@ typedef struct {
     int no_short_cigar;    /* A/B and test hook: CIGAR calls never take tier 5 (several alignments per wavefront)               */
     int no_fused_pack;     /* A/B: always run the pack kernel (default: reads of 512 bases and more are packed by the wavefront
                               kernels while they stage them)                                                                    */
-    int no_kernel_walk;    /* A/B and test hook: the one-wave wavefront kernels never walk their alignments back themselves
-                              (wfa_walk_kernel does, in the backtrace pass: the round-4 path)                                    */
-    int band_tier;         /* A/B hook: wavefronts per alignment of the banded kernels -- 1: one, 2: four, 3: sixteen (0: by the
-                              wavefronts a CU ends up holding, plan_tier)                                                        */
+    int kernel_walk;       /* 1: the one-wave wavefront kernels walk a finished alignment back themselves (align/walk_epilogue.inc:
+                              tiles through the freed ring LDS, op list into the arena) and wfa_walk_kernel does not run.  Off by
+                              default: measured on BASELINE configs[2] the backtrace pass drops from 3.05 to 1.45 ms but the serial
+                              walk costs the wavefront kernel 2.45 ms of instruction issue (25.4 -> 27.9 ms): EXPERIMENTS.md       */
+    int band_tier;         /* A/B hook: wavefronts per alignment of the banded kernels -- 1: one, 2: two, 3: four, 4: sixteen (0: by
+                              the wavefronts a CU ends up holding, plan_tier)                                                    */
     int emit_pairs;        /* lane-per-alignment CIGAR replay with the sequences staged in LDS: alignments per wavefront
                               (8..64; 0: automatic -- as many as keep the most lanes resident per CU)                          */
 } wfagpu_amd_tuning_t;
@@ -61,8 +63,8 @@ typedef struct {
     size_t arena_limit_bytes; /* cap for the automatic arena size (0: none); a batch that needs
                               more runs in several passes                                   */
     size_t arena_limit_max_bytes; /* > arena_limit_bytes: the cap doubles, up to this value, after every call that
-                              needed several passes -- a one-shot call touches little fresh device memory (first touch
-                              costs ~33 ms per GiB), a long-lived process ends up with the arena its batches need */
+                              needed several passes (launch_alignments* no longer use it: a call that regrows its arena
+                              stalls behind the driver's wipe of the memory it has just released) */
     wfagpu_amd_tuning_t tuning;
 } wfagpu_amd_config_t;
 
@@ -197,7 +199,8 @@ typedef struct {
     int lanes_per_device;     /* contexts per device working on alternate batches (0: 2 for big calls -- 3 when the
                                  sequences go up packed, see host_pack --, else 1)                                        */
     int batches_per_device;   /* a single huge batch is cut into this many so that the stages overlap (0: 16)            */
-    size_t arena_limit_bytes; /* fixed backtrace-arena cap per lane (0: 4 GiB, growing with use)                         */
+    size_t arena_limit_bytes; /* fixed backtrace-arena cap per lane (0: the lane's share of the device memory -- half of what
+                                 was free, over all lanes --: an arena is sized once, by its first batch's expected need)      */
     size_t input_pool_bytes;  /* device memory for resident input per device (0: a quarter of the free memory, <= 24 GiB) */
     int numa_pin;             /* 0: pin a device's host threads to its NUMA node when several devices are used,
                                  1: always (test hook for one-GPU boxes), -1: never                                      */

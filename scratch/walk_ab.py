@@ -8,8 +8,8 @@ buf, meta = wfagpu.generate_pairs(n, 1000, 0.05, seed=1000, nthreads=16)
 idx = np.arange(0, n, max(1, n // 4000))
 so, co = oracle_lib.ref_batch(buf, meta[idx], (2, 3, 1), cigar=True, memory_mode=0, nthreads=16) if oracle_lib.have_ref() else oracle_lib.oracle_batch(buf, meta[idx], (2, 3, 1), cigar=True, nthreads=16)[:2]
 for rnd in range(2):
-    for nk in (1, 0):
-        al = wfagpu.DeviceAligner(0, no_kernel_walk=nk)
+    for kw in (0, 1):
+        al = wfagpu.DeviceAligner(0, kernel_walk=kw)
         batch = al.upload(buf, meta)
         al.align(batch, (2, 3, 1), max_error=300, compute_cigar=True, fetch=False)
         al.hint_same_stream(True)
@@ -23,5 +23,5 @@ for rnd in range(2):
         sc = out[0].cpu().numpy()
         cg = wfagpu.fetch_cigars(out[1][0], out[1][1], out[1][2], n, st.text_bytes)
         ok = bool(np.array_equal(sc[idx], so)) and all(cg[i] == co[j] for j, i in enumerate(idx))
-        print(f"no_kernel_walk={nk}: step {np.median(ts):.2f} ms main {np.median(ms):.2f} align {st.align_ms:.2f} trace {np.median(tr):.2f} walked {st.pairs_walked_in_kernel} tiers {list(st.pairs_tier)} parity {ok}", flush=True)
+        print(f"kernel_walk={kw}: step {np.median(ts):.2f} ms main {np.median(ms):.2f} align {st.align_ms:.2f} trace {np.median(tr):.2f} walked {st.pairs_walked_in_kernel} tiers {list(st.pairs_tier)} parity {ok}", flush=True)
         al.close(); del batch; torch.cuda.empty_cache()

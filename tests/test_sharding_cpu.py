@@ -89,6 +89,10 @@ def test_bench_gpus_flag_starts_its_own_ranks():
     assert [r["rank"] for r in out["per_rank"]] == [0, 1] and all(r["ms_per_step"] <= out["ms_per_step"] * 1.001 for r in out["per_rank"])
     one = _bench_json(["--cpu-harness", "--steps", "2", "--warmup", "1"])
     assert one["n_gpus"] == 1
+    # --force-dist: ONE rank, but as a torch.distributed job all the same (self-spawned child, process group, barriers, all-reduce
+    # and all-gather of the clocks): what the GPU suite runs with RCCL on the one device it has
+    forced = _bench_json(["--gpus", "1", "--force-dist", "--cpu-harness", "--steps", "2", "--warmup", "1"])
+    assert forced["n_gpus"] == 1 and forced["library_call"] == {"ranks_parked": 0} and len(forced["per_rank"]) == 1
 
 
 def test_bench_refuses_a_rank_count_that_differs_from_gpus():

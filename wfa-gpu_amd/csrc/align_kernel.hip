@@ -586,10 +586,13 @@ void launch_tier(const WfaAlignParams& p, int tier, size_t lds, int grid, hipStr
       break;
   }
 }
+// (tier 6: TWO waves per alignment, banded kernels only -- a band of 512 diagonals on many pairs: twice the wavefronts per CU of the
+// one-wave tier at the same LDS, four chunks per wave and score to spread the per-score part over)
 template <bool BT>
 void launch_tier_banded(const WfaAlignParams& p, int tier, size_t lds, int grid, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
   switch (tier) {
     case 0: launch_inst<1, BT, int16_t, false, false, true>(p, lds, grid, stream, ev0, ev1); break;
+    case 6: launch_inst<2, BT, int16_t, false, false, true>(p, lds, grid, stream, ev0, ev1); break;
     case 1: launch_inst<4, BT, int16_t, false, false, true>(p, lds, grid, stream, ev0, ev1); break;
     default: launch_inst<16, BT, int16_t, false, false, true>(p, lds, grid, stream, ev0, ev1); break;
   }
@@ -614,6 +617,7 @@ template <bool BT>
 int occ_tier_banded(int tier, size_t lds) {
   switch (tier) {
     case 0: return occ_inst<1, BT, int16_t, false, false, true>(lds);
+    case 6: return occ_inst<2, BT, int16_t, false, false, true>(lds);
     case 1: return occ_inst<4, BT, int16_t, false, false, true>(lds);
     default: return occ_inst<16, BT, int16_t, false, false, true>(lds);
   }

@@ -450,10 +450,13 @@ bool plan_tier(const wfagpu_amd_ctx* c, WfaAlignParams& p, int max_score, unsign
     const int min_t = (c->tuning.min_tier >= 1 && c->tuning.min_tier <= 2) ? c->tuning.min_tier : 0;      // (test hook)
     const uint32_t pairs_per_cu = n_pairs ? std::max<uint32_t>(1u, (n_pairs + (uint32_t)c->num_cus - 1u) / (uint32_t)c->num_cus) : 1u << 20;
     int best_t = -1, best_waves = -1, best_nb = 0; size_t best_lds = 0;
-    const int forced_t = (c->tuning.band_tier >= 1 && c->tuning.band_tier <= 3) ? c->tuning.band_tier - 1 : -1;      // (A/B hook)
-    for (int t = forced_t >= 0 ? forced_t : min_t; t < (forced_t >= 0 ? forced_t + 1 : 3); ++t) {
-      const int nw = t == 0 ? 1 : (t == 1 ? 4 : 16);
-      if (forced_t < 0 && t > min_t && p.band_width < 48 * nw) break;            // (a wave without a chunk of its own only waits at the barrier)
+    // (candidates by wavefronts per alignment: 1, 2, 4, 16 = tiers 0, 6, 1, 2; tuning.band_tier 1..4 forces one of them: A/B hook)
+    static const int cand_tier[4] = {0, 6, 1, 2}, cand_nw[4] = {1, 2, 4, 16};
+    const int forced_i = (c->tuning.band_tier >= 1 && c->tuning.band_tier <= 4) ? c->tuning.band_tier - 1 : -1;
+    const int first_i = forced_i >= 0 ? forced_i : (min_t == 0 ? 0 : (min_t == 1 ? 2 : 3));
+    for (int i = first_i; i < (forced_i >= 0 ? forced_i + 1 : 4); ++i) {
+      const int t = cand_tier[i], nw = cand_nw[i];
+      if (forced_i < 0 && i > first_i && p.band_width < 48 * nw) break;            // (a wave without a chunk of its own only waits at the barrier)
       const size_t lds = wfa_align_lds_bytes(p, t);
       if (lds > c->lds_per_block_max) continue;
       const int nb = wfa_align_max_blocks_per_cu(t, bt, false, true, lds);
@@ -753,8 +756,13 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         // towards the end like the exact one; a pair whose banded score exceeds its budget is re-run exactly like any miss)
         ap.band_width = (want_band && allow_band && !raw && round == 0) ? band_width : 0;
         ap.band_period = band;
-        if (ap.band_width > 0 && !plan_tier(c, ap, std::min(max_score, 30000), max_len, cigar_now, raw, &tp, false, n_cur)) ap.band_width = 0;
+        // (a banded launch runs under the caller's max_error, not under the tuned per-pair budgets: a budget narrows nothing
+        // there -- every score has band_width diagonals whatever it is, the reference's windows are not clipped by a budget's
+        // reach -- and a pair whose banded score passed its budget went through a second, exact alignment for nothing:
+        // BASELINE configs[3] with the band forced, 198 of 16 384 pairs re-run on sixteen waves each, 2.5 of a 20 ms step)
+        if (ap.band_width > 0 && !plan_tier(c, ap, std::min(max_error, 30000), max_len, cigar_now, raw, &tp, false, n_cur)) ap.band_width = 0;
         L.banded = ap.band_width > 0;
+        if (L.banded) { ap.budget = nullptr; L.budgeted = false; }
         // (the speculative re-run of budget misses: a percent or two of the chain's pairs)
         const bool few_pairs = n_links == 1 && link[0].budgeted && (n_chain / 50u) <= 2u * (unsigned)c->num_cus;
         if (ap.band_width == 0 && !plan_tier(c, ap, max_score, max_len, cigar_now, raw, &tp, few_pairs)) {
@@ -778,7 +786,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
           const bool lane_replay = (size_t)64 * ((2 * per_seq_w) | 1u) * 4 <= (48u << 10);
           const size_t ring_bytes = (size_t)(ap.dm + 2 * ap.de + ((tp.tier == 0 && ap.band_width <= 0) ? 1 : 0)) * (size_t)ap.rs * 2;
           const int s_cap = std::min(ap.max_score, 30000);
-          L.walked = cigar_now && tp.tier == 0 && !c->tuning.no_kernel_walk && lane_replay && s_cap > 124 &&
+          L.walked = cigar_now && tp.tier == 0 && c->tuning.kernel_walk && lane_replay && s_cap > 124 &&
                      ring_bytes >= (size_t)64 * 16 + (((size_t)s_cap + 3) & ~(size_t)3) + 16;
           ap.walk_in_kernel = L.walked ? 1 : 0;
           ap.cigar_off = static_cast<unsigned long long*>(c->cig_off[c->out_set].p);
@@ -839,14 +847,14 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         uint32_t* nxt = spare[flip]; flip ^= 1;
         LAUNCH_K(k_compact, dim3(cdiv(n_cur, compact_block(n_cur))), dim3(compact_block(n_cur)), 0, st, (const uint32_t*)cur, n_cur, cur_len_dev,
                            static_cast<const uint32_t*>(c->status.p), MASK(WFA_ST_BAND) | MASK(WFA_ST_SCORE), nxt, ct + L.ct_list, ap.work_counter);
-        s_hi = std::max<long long>(s_hi, L.banded ? std::min(max_score, 30000) : max_score);
+        s_hi = std::max<long long>(s_hi, L.banded ? std::min(max_error, 30000) : max_score);
         ++n_links; ++round;
         // what the failures of this round run with next
         cur = nxt; cur_len_dev = ct + L.ct_list;      // (n_cur stays as the upper bound until the chain's synchronisation)
-        if (budget_round) {
-          budget_round = false; max_score = max_error;      // auto-budget misses (banded or not): the caller's budget, exact tiers
-        } else if (L.banded) {
-          // banded misses: exact tiers from the start
+        if (L.banded) {
+          // banded misses: exact tiers from the start (under the tuned budgets first, where there are any)
+        } else if (budget_round) {
+          budget_round = false; max_score = max_error;      // auto-budget misses: the caller's budget, exact tiers
         } else {
           // widen: 4x the score budget (and with it the diagonal window); beyond what 16-bit offsets
           // allow the last resort is the unbounded 32-bit tier
@@ -1020,7 +1028,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         const uint32_t n_out = (uint32_t)c->h_counters[L.ct_list];
         // (an unfiltered list: the pairs of the byte-compare class were skipped, not finished)
         const uint32_t skipped = (unfiltered && L.first_round) ? (uint32_t)std::min<unsigned long long>(c->h_counters[CT_NRAW], n_in - n_out) : 0u;
-        c->stats.pairs_tier[L.tier] += n_in - n_out - skipped;
+        c->stats.pairs_tier[L.tier == 6 ? 1 : L.tier] += n_in - n_out - skipped;      // (tier 6, two waves, banded only: counted with the four-wave tier)
         if (L.banded) c->stats.pairs_banded += n_in - n_out;
         if (L.first_round) c->stats.pairs_retried += n_out;
         if (L.budgeted) c->stats.pairs_budget_missed += n_out;
@@ -1107,7 +1115,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       // (tuned budgets pay where they narrow a wide window -- or, score-only, where they bring it down to what the
       // several-alignments-per-wavefront tier holds)
       const bool short_ok = wfa_short_supported(pen.x, oe, pen.e) && !c->tuning.min_tier && !(compute_cigar && c->tuning.no_short_cigar);
-      const bool would_tune = n >= 8192 && !c->tuning.no_auto_budget && (w_me > 128 || (w_me > 15 && short_ok));
+      const bool would_tune = n >= 8192 && !c->tuning.no_auto_budget && !(want_band && c->tuning.force_band) && (w_me > 128 || (w_me > 15 && short_ok));
       bool inherited = false;
       if (would_tune && c->same_stream)
         for (int i = 0; i < c->n_saved_q; ++i) {
@@ -1149,7 +1157,9 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       // (with a band requested the sample still runs, exactly: the budgets serve the banded kernels too -- see the band policy below)
       const int w_me2 = window_width(max_error, pen.o, pen.e, max_len);
       const bool short_ok2 = wfa_short_supported(pen.x, oe, pen.e) && !c->tuning.min_tier && !(compute_cigar && c->tuning.no_short_cigar);
-      const bool try_budget = !raw && n_pending >= 8192 && !c->tuning.no_auto_budget && (w_me2 > 128 || (w_me2 > 15 && short_ok2));
+      // (the budgets decide whether the band is worth using and serve the exact kernels; with the band forced neither applies)
+      const bool try_budget = !raw && n_pending >= 8192 && !c->tuning.no_auto_budget && !(want_band && c->tuning.force_band) &&
+                              (w_me2 > 128 || (w_me2 > 15 && short_ok2));
       int saved_idx = -1;
       if (try_budget && c->same_stream) {
         for (int i = 0; i < c->n_saved_q; ++i) {

@@ -342,17 +342,21 @@ int make_lane(DevState& d, int k, const wfagpu_amd_launch_config_t& cfg) {
   wfagpu_amd_config_t c{};
   c.device = d.device;
   c.tuning = cfg.tuning;
-  // The backtrace arena is kept between calls.  Its cap starts at 4 GiB -- fresh device memory costs ~33 ms per GiB at
-  // first touch, and a batch that needs more simply runs in several passes -- and grows after every call that needed
-  // several passes (a long-lived process ends up with one pass per call).  All lanes of all slots of a device
-  // together never claim more than half of the memory that was free when the slot was created.
+  // The backtrace arena is kept between calls, and it is sized ONCE: by what the lane's first batch is expected to need, up to
+  // the lane's share of the device -- all lanes of all slots of a device together never claim more than half of the memory that
+  // was free when the slot was created; a batch that needs more runs in several passes.  (Rounds 2-4 started every arena at a
+  // cap of 4 GiB that doubled after every call that had needed several passes, on the belief that fresh device memory costs
+  // ~33 ms per GiB at first touch.  It does not -- 0.2 ms per GiB, profiles/r04/touch_probe.txt -- and the doubling was worse
+  // than useless: the call that regrows frees its arena and allocates a bigger one, and a large hipMalloc right behind a large
+  // hipFree waits for the driver to wipe what was released: a warm call of 2.48 s among calls of 77 ms, BENCH_r04 configs.cfg5.
+  // hipMalloc itself is 0.3 ms whatever the size, profiles/r02/malloc_probe.txt.)
   const size_t share = d.free_at_creation / 2 / (size_t)std::max(1, sharers * std::max(lanes, MAX_LANES - 1));
   if (cfg.arena_limit_bytes) {
     c.arena_limit_bytes = cfg.arena_limit_bytes;      // fixed cap
     c.arena_limit_max_bytes = 0;
   } else {
-    c.arena_limit_bytes = std::min<size_t>((size_t)4 << 30, std::max<size_t>(share, (size_t)64 << 20));
-    c.arena_limit_max_bytes = std::max<size_t>(c.arena_limit_bytes, std::min<size_t>((size_t)32 << 30, share));
+    c.arena_limit_bytes = std::min<size_t>((size_t)48 << 30, std::max<size_t>(share, (size_t)64 << 20));
+    c.arena_limit_max_bytes = 0;
   }
   wfagpu_amd_ctx_t* ctx = nullptr;
   if (wfagpu_amd_create(&ctx, &c)) return -1;

@@ -35,6 +35,7 @@ static void usage(const char* prog) {
            "[System]\n"
            "\t-t, --threads-per-block <int>     Accepted for compatibility (band width in banded mode)\n"
            "\t-w, --workers <int>               Accepted for compatibility\n"
+           "\t    --stage-times                 Print the stage clocks of the alignment call on stderr\n"
            "[Examples]\n"
            "\t%s -i sequences.seq -b <batch_size> -o scores.out\n"
            "\t%s -i sequences.seq -b <batch_size> -B auto -o scores-banded.out\n"
@@ -52,10 +53,10 @@ int main(int argc, char** argv) {
         {"compute-cigar", no_argument, 0, 'x'}, {"max-distance", required_argument, 0, 'e'},
         {"batch-size", required_argument, 0, 'b'}, {"band", required_argument, 0, 'B'},
         {"check", no_argument, 0, 'c'}, {"threads-per-block", required_argument, 0, 't'},
-        {"workers", required_argument, 0, 'w'}, {"help", no_argument, 0, 'h'}, {0, 0, 0, 0}};
+        {"workers", required_argument, 0, 'w'}, {"help", no_argument, 0, 'h'}, {"stage-times", no_argument, 0, 1000}, {0, 0, 0, 0}};
     const char *seq_path = NULL, *q_path = NULL, *t_path = NULL, *out_path = NULL, *pen_str = NULL;
     long n_read = 0, max_distance = -1, batch_size = -1, band_arg = -2, tpb = -1, workers = -1;
-    bool print_out = false, verbose = false, cigar = false, check = false;
+    bool print_out = false, verbose = false, cigar = false, check = false, stage_times = false;
 
     int ndev = 0;
     get_num_cuda_devices(&ndev);
@@ -89,6 +90,7 @@ int main(int argc, char** argv) {
             case 'c': check = true; break;
             case 't': tpb = atol(optarg); break;
             case 'w': workers = atol(optarg); break;
+            case 1000: stage_times = true; break;      /* (not in the reference: the library's stage clocks of the call on stderr) */
             case 'h': usage(argv[0]); exit(0);
             default: break;      /* an option the tool does not know is skipped, like the reference's parser does (utils/arg_handler.c:97-140) */
         }
@@ -151,6 +153,12 @@ int main(int argc, char** argv) {
     opt.band = band; opt.batch_size = (size_t)batch_size; opt.num_alignments = num_alignments;
     opt.penalties = penalties; opt.compute_cigar = cigar;
 
+    if (stage_times) {
+        wfagpu_amd_launch_config_t lc;
+        memset(&lc, 0, sizeof lc);
+        lc.timing = 2;
+        wfagpu_amd_configure_launch(&lc);
+    }
     t0 = wf_now_seconds();
     if (cigar) launch_alignments(set.sequences_buffer, set.sequences_buffer_size, set.sequences_metadata, results, opt, check);
     else launch_alignments_distance(set.sequences_buffer, set.sequences_buffer_size, set.sequences_metadata, results, opt, check);

@@ -49,6 +49,7 @@ typedef struct {
                               tiles through the freed ring LDS, op list into the arena) and wfa_walk_kernel does not run.  Off by
                               default: measured on BASELINE configs[2] the backtrace pass drops from 3.05 to 1.45 ms but the serial
                               walk costs the wavefront kernel 2.45 ms of instruction issue (25.4 -> 27.9 ms): EXPERIMENTS.md       */
+    int exact_two_waves;   /* A/B hook: the exact search takes two waves per alignment where it would take four                 */
     int band_tier;         /* A/B hook: wavefronts per alignment of the banded kernels -- 1: one, 2: two, 3: four, 4: sixteen (0: by
                               the wavefronts a CU ends up holding, plan_tier)                                                    */
     int emit_pairs;        /* lane-per-alignment CIGAR replay with the sequences staged in LDS: alignments per wavefront

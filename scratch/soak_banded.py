@@ -32,6 +32,8 @@ for it in range(iters):
     batch = al.upload(buf, meta)
     beta = rng.choice([64, 128, 256, 512, 1024]); lam = rng.choice([1, 10, 25, 50, 750])
     me = int(L * 0.3 * max(pen))
+    # (round 5: one / two / four / sixteen wavefronts per alignment, or the library's own choice)
+    al.set_tuning(force_band=1, band_tier=rng.choice([0, 0, 1, 2, 3, 4]))
     s1, c1 = al.align(batch, pen, max_error=me, compute_cigar=True, band=lam, band_width=beta)
     s2, c2 = al.align(batch, pen, max_error=me, compute_cigar=True, band=lam, band_width=beta)
     s3, _ = al.align(batch, pen, max_error=me, compute_cigar=False, band=lam, band_width=beta)

@@ -576,6 +576,10 @@ void launch_tier(const WfaAlignParams& p, int tier, size_t lds, int grid, hipStr
       if constexpr (BT && !RAW) { if (p.dbg_times) { launch_inst<4, true, int16_t, false, false, false, false, 8, true>(p, lds, grid, stream, ev0, ev1); break; } }
       launch_inst<4, BT, int16_t, false, RAW, false>(p, lds, grid, stream, ev0, ev1); break;
     case 2: launch_inst<16, BT, int16_t, false, RAW, false>(p, lds, grid, stream, ev0, ev1); break;
+    case 6:      // two waves per alignment (exact: A/B hook tuning.exact_two_waves; the byte-compare class keeps four)
+      if constexpr (!RAW) launch_inst<2, BT, int16_t, false, false, false>(p, lds, grid, stream, ev0, ev1);
+      else launch_inst<4, BT, int16_t, false, RAW, false>(p, lds, grid, stream, ev0, ev1);
+      break;
     case 4:
       if constexpr (BT && !RAW) { if (p.dbg_times) { launch_inst<16, true, int16_t, false, false, false, true, 8, true>(p, lds, grid, stream, ev0, ev1); break; } }
       if constexpr (!RAW) launch_inst<16, BT, int16_t, false, false, false, true>(p, lds, grid, stream, ev0, ev1);
@@ -609,6 +613,7 @@ int occ_tier(int tier, size_t lds, int wpe) {
       return occ_inst<1, BT, int16_t, false, RAW, false>(lds);
     case 1: return occ_inst<4, BT, int16_t, false, RAW, false>(lds);
     case 2: return occ_inst<16, BT, int16_t, false, RAW, false>(lds);
+    case 6: if constexpr (!RAW) return occ_inst<2, BT, int16_t, false, false, false>(lds); else return occ_inst<4, BT, int16_t, false, RAW, false>(lds);
     case 4: if constexpr (!RAW) return occ_inst<16, BT, int16_t, false, false, false, true>(lds); else return 0;
     default: return occ_inst<16, BT, int32_t, true, RAW, false>(lds);
   }

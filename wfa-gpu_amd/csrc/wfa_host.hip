@@ -521,6 +521,12 @@ bool plan_tier(const wfagpu_amd_ctx* c, WfaAlignParams& p, int max_score, unsign
     // (profiles/r02/mid_lengths.txt).  tuning.t0_min_blocks: A/B.
     const int t0_min_blocks = c->tuning.t0_min_blocks > 0 ? c->tuning.t0_min_blocks : 10;
     if (t == 0 && !min_tier && nb < t0_min_blocks && width >= 384) continue;
+    if (t == 1 && !raw && c->tuning.exact_two_waves) {
+      // A/B hook: TWO waves per alignment where four would run (same ring, same LDS; half the per-score bookkeeping per chunk, half the waves)
+      const size_t lds2 = wfa_align_lds_bytes(p, 6);
+      const int nb2 = wfa_align_max_blocks_per_cu(6, bt, raw, false, lds2);
+      if (nb2 >= 1) { *out = {6, width, max_score, lds2, nb2, wpe}; return true; }
+    }
     *out = {t, width, max_score, lds, nb, wpe};
     return true;
   }
@@ -1247,11 +1253,13 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         }
       }
       // Band policy: the band is a permission to approximate, not an obligation.  Where the tuned budgets leave the exact
-      // wavefronts no wider than 2.5 bands the exact search costs about what the band does and every result is optimal: the
+      // wavefronts narrower than 1.75 bands the exact search costs no more than the band does and every result is optimal: the
       // band is not used for the bucket (tuning.force_band keeps it).  Otherwise, and in batches too small to tune, the
-      // banded kernels run -- with the budgets, where there are any.
+      // banded kernels run.  (The threshold was 2.5 bands through round 4; since round 5 the banded kernels run a cell as fast
+      // as the exact ones and need no budget re-runs: BASELINE configs[3] -- windows of 1.94 bands -- 16.0 ms exact against
+      // 14.0 ms banded per step.  The exact diamond has ~0.45 W cells per score, the band ~0.92 beta: even at W = 1.75 beta.)
       const bool use_band = want_band && (!budgets || c->tuning.force_band ||
-                                          2 * window_width(budget_cap, pen.o, pen.e, max_len) > 5 * band_width);
+                                          4 * window_width(budget_cap, pen.o, pen.e, max_len) > 7 * band_width);
       const unsigned missed_before = c->stats.pairs_budget_missed;
       const bool speculate = !(saved_idx >= 0 && c->saved_q[saved_idx].last_missed == 0);
       if (n_pending && run_list(pending, n_pending, raw, budgets, budget_cap, static_cast<uint32_t*>(c->list_d.p), bucket_list, use_band, speculate)) return -1;

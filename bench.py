@@ -767,6 +767,8 @@ def library_mode(args, wl, n_pairs, max_error, steps):
     lib.get_num_cuda_devices(C.byref(nd))
     if nd.value < args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but only {nd.value} devices are visible")
+    if args.gpus > 1:
+        lib.wfagpu_amd_warmup()      # (the device query above brings up the current device only: every device of the call, in the background)
     steps = args.steps or max(5, steps // 5)
     for _ in range(max(1, args.warmup)):
         fn(buf.ctypes.data, buf.nbytes, meta.ctypes.data, res, opt, False)

@@ -12,8 +12,8 @@ al = wfagpu.DeviceAligner(0)
 bad = 0; worse = 0; total = 0; ref_checked = 0
 for it in range(iters):
     pen = (rng.randint(1, 8), rng.randint(0, 10), rng.choice([1, 1, 1, 2, 3, 5]))
-    L = rng.choice([300, 1200, 4000])
-    n = rng.choice([32, 128])
+    L = rng.choice([300, 1200, 4000] + ([12000] if len(sys.argv) > 3 and sys.argv[3] == "long" else []))
+    n = rng.choice([32, 128]) if L < 12000 else 16
     err = rng.choice([0.01, 0.05, 0.15])
     pairs = []
     for _ in range(n):

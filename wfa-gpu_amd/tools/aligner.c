@@ -143,7 +143,10 @@ int main(int argc, char** argv) {
     }
 
     wfa_alignment_result_t* results = NULL;
-    if (!initialize_wfa_results(&results, num_alignments, (size_t)max_distance * 5)) {
+    /* (the reference starts every CIGAR buffer at max_distance * 5 bytes: 1.5 GB of calloc for a million 1 kbp pairs, 0.4 s of the
+     * tool's run time.  An RLE CIGAR of score s has at most s operations, each at most ~5 characters with its match run; the typical
+     * one is a quarter of that bound, and a buffer that is too small grows when the results are scattered) */
+    if (!initialize_wfa_results(&results, num_alignments, cigar ? (size_t)max_distance * 5 / 4 + 16 : 1)) {
         LOG_ERROR("Can not initialise CIGAR buffer.")
         exit(-1);
     }

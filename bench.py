@@ -673,7 +673,7 @@ def main():
                                   else "tuned on a sample in every step",
                        "band": {"period": band[0], "width": band[1], "forced": bool(args.force_band),
                                 "policy": "the band is used only where the sampled score budgets leave the exact wavefronts wider "
-                                          "than 2.5 bands (tiers.pairs_banded counts the pairs it finished)"} if band else None,
+                                          "than 1.75 bands (tiers.pairs_banded counts the pairs it finished)"} if band else None,
                        "sharding": f"batch-sharded x{world}, no collective", "mode": "ranks",
                        "process_group": ("rccl (backend nccl), world size %d: barrier + max all-reduce + all-gather of the clocks" % world) if dist is not None else None},
             "gcups": round(gcups, 2),

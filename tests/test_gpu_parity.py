@@ -661,7 +661,7 @@ def test_penalty_sets_at_scale(aligner, pen, max_error):
 
 def test_band_is_only_used_where_it_pays():
     """-B on a big batch: the sample that tunes the score budgets runs exactly; when the budgets leave the exact wavefronts
-    no wider than 2.5 bands the exact kernels are at least as fast as the band and are used instead (optimal results, no
+    narrower than 1.75 bands the exact kernels are at least as fast as the band and are used instead (optimal results, no
     pair counted as banded); wfagpu_amd_tuning_t::force_band keeps the band.  Both ways: valid alignments, cost == score >= optimum."""
     buf, meta = wfagpu.generate_pairs(9000, 1500, 0.04, seed=401)
     so, co, _ = oracle_lib.oracle_batch(buf, meta, (2, 3, 1), cigar=True, nthreads=16)

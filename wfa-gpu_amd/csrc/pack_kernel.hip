@@ -58,9 +58,11 @@ wfa_pack_kernel(const char* __restrict__ ascii, const WfaSeqPair* __restrict__ m
   // (status != nullptr -- the align call's own packing: flagged pairs never enter the 2-bit tiers, and their number lets the host
   // skip the byte-compare class when it is empty.  A kernel of its own did this: 4 us + the gap of a launch in a 175 us step of
   // 100k short reads; clean batches pay no atomic.)
+  // (every pair's status is written here -- PENDING for the clean ones: the align call needs no memset of the status array in front
+  // of this kernel, one launch fewer per step)
   if (status) {
     const bool raw = have && j == 0 && (any_pbad | any_tbad) != 0ull;
-    if (raw) status[pair] = WFA_ST_ALPHABET;
+    if (have && j == 0) status[pair] = raw ? WFA_ST_ALPHABET : WFA_ST_PENDING;
     const unsigned long long bal = __ballot(raw);
     if (bal && lane == __builtin_ctzll(bal)) atomicAdd(n_raw, (unsigned long long)__builtin_popcountll(bal));
   }

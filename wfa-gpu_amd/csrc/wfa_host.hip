@@ -148,12 +148,28 @@ __global__ void __launch_bounds__(1024) k_compact_len(uint32_t n, const uint32_t
 // text sizes; also the total of computed cells and the largest score.  Grid-stride, FOUR atomics per block, few blocks: the
 // counters share one cache line and an atomic on it costs ~11 ns whoever issues it (one atomicMax per wavefront + three adds per
 // block of a 391-block grid: 22 of the 250 microseconds of a BASELINE configs[1] step).
+// (n_all > 0: the same launch also counts the pairs of the WHOLE batch that are not DONE -- what k_count_unfinished does -- into
+// ct[CT_UNFIN]: the statuses are final once the chain's wavefront launches are through, the backtrace does not touch them; one
+// launch and its gap fewer per chain: ~8 us of a 175 us step of 100k short reads)
 __global__ void __launch_bounds__(256) k_trace_bounds(const uint32_t* __restrict__ work, uint32_t n, const uint32_t* __restrict__ status,
                                const int32_t* __restrict__ score, const uint32_t* __restrict__ cells, int min_op_cost, int item_chars,
-                               unsigned long long* __restrict__ ct) {
+                               unsigned long long* __restrict__ ct, uint32_t n_all) {
   __shared__ unsigned long long part[4][4];
   unsigned long long ops = 0, txt = 0, cl = 0;
   uint32_t smax = 0;
+  if (n_all) {
+    uint32_t bad = 0;
+    for (uint32_t i = (blockIdx.x * 256u + threadIdx.x) * 4u; i < n_all; i += gridDim.x * 1024u) {
+      if (i + 3u < n_all) {
+        const uint4 v = *reinterpret_cast<const uint4*>(status + i);      // (the status array is 16-byte aligned, i a multiple of 4)
+        bad += (v.x != WFA_ST_DONE) + (v.y != WFA_ST_DONE) + (v.z != WFA_ST_DONE) + (v.w != WFA_ST_DONE);
+      } else {
+        for (uint32_t j = i; j < n_all; ++j) bad += status[j] != WFA_ST_DONE;
+      }
+    }
+    for (int d = 32; d > 0; d >>= 1) bad += __shfl_down(bad, d);
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(&ct[CT_UNFIN], (unsigned long long)bad);
+  }
   for (uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x; gid < n; gid += gridDim.x * blockDim.x) {
     const uint32_t pair = work ? work[gid] : gid;
     if (status[pair] == WFA_ST_DONE) {
@@ -184,6 +200,65 @@ __global__ void __launch_bounds__(256) k_trace_bounds(const uint32_t* __restrict
     if (txt) atomicAdd(&ct[CT_SUM_TEXT], txt);
     if (cl) atomicAdd(&ct[CT_CELLS], cl);
   }
+}
+
+// The tail of a chain with ONE wavefront launch, in one kernel: compaction of the launch's failures (k_compact), bounds of what
+// finished (k_trace_bounds) and the count of unfinished pairs of the whole batch (k_count_unfinished).  Three launches of ~4 us
+// each (+ the gaps between them) were a tenth of a 175 us step of 100k short reads.  One thread per list entry.
+__global__ void __launch_bounds__(256) k_chain_tail(const uint32_t* __restrict__ work, uint32_t n, const uint32_t* __restrict__ status,
+                             uint32_t mask, uint32_t* __restrict__ out, unsigned long long* __restrict__ out_count, unsigned int* __restrict__ work_ctr,
+                             const int32_t* __restrict__ score, const uint32_t* __restrict__ cells, int min_op_cost, int item_chars,
+                             unsigned long long* __restrict__ ct, uint32_t n_all) {
+  // (few blocks, grid-stride: all the counters of a call share one cache line and an atomic on it costs ~11 ns whoever issues it --
+  // one block per 64 list entries, four atomics each, made this kernel 70 us for 100k pairs)
+  __shared__ unsigned long long part[4][4];
+  if (work_ctr && blockIdx.x == 0 && threadIdx.x < 8) work_ctr[threadIdx.x * 16] = 0u;
+  unsigned long long ops = 0, txt = 0, cl = 0;
+  uint32_t smax = 0;
+  for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {      // (uniform per block: block_append has barriers)
+    const uint32_t gid = base + threadIdx.x;
+    bool take = false; uint32_t pair = 0, st = WFA_ST_PENDING;
+    if (gid < n) { pair = work ? work[gid] : gid; st = status[pair]; take = (mask >> st) & 1u; }
+    block_append(take, pair, out, out_count);
+    if (gid < n && st == WFA_ST_DONE) {
+      const uint32_t sc = (uint32_t)score[pair];
+      smax = max(smax, sc);
+      ops += (sc + 3u) & ~3u;
+      txt += (unsigned long long)item_chars * (2ull * (sc / (uint32_t)min_op_cost) + 1ull) + 1ull;
+      if (cells) cl += cells[pair];
+    }
+    __syncthreads();      // (block_append's shared words are written again by the next round)
+  }
+  for (int d = 32; d > 0; d >>= 1) {
+    ops += __shfl_down((unsigned long long)ops, d);
+    txt += __shfl_down((unsigned long long)txt, d);
+    cl += __shfl_down((unsigned long long)cl, d);
+    smax = max(smax, (uint32_t)__shfl_down((int)smax, d));
+  }
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { part[0][wv] = ops; part[1][wv] = txt; part[2][wv] = cl; part[3][wv] = smax; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    ops = part[0][0] + part[0][1] + part[0][2] + part[0][3];
+    txt = part[1][0] + part[1][1] + part[1][2] + part[1][3];
+    cl = part[2][0] + part[2][1] + part[2][2] + part[2][3];
+    const unsigned long long sm = max(max(part[3][0], part[3][1]), max(part[3][2], part[3][3]));
+    if (sm) atomicMax(&ct[CT_MAX_SCORE], sm);
+    if (ops) atomicAdd(&ct[CT_SUM_OPS], ops);
+    if (txt) atomicAdd(&ct[CT_SUM_TEXT], txt);
+    if (cl) atomicAdd(&ct[CT_CELLS], cl);
+  }
+  uint32_t bad = 0;
+  for (uint32_t i = (blockIdx.x * 256u + threadIdx.x) * 4u; i < n_all; i += gridDim.x * 1024u) {
+    if (i + 3u < n_all) {
+      const uint4 v = *reinterpret_cast<const uint4*>(status + i);
+      bad += (v.x != WFA_ST_DONE) + (v.y != WFA_ST_DONE) + (v.z != WFA_ST_DONE) + (v.w != WFA_ST_DONE);
+    } else {
+      for (uint32_t j = i; j < n_all; ++j) bad += status[j] != WFA_ST_DONE;
+    }
+  }
+  for (int d = 32; d > 0; d >>= 1) bad += __shfl_down(bad, d);
+  if ((threadIdx.x & 63) == 0 && bad) atomicAdd(&ct[CT_UNFIN], (unsigned long long)bad);
 }
 
 // every stride-th entry of a pair list -> sample list
@@ -681,14 +756,16 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
     ap.arena_units = c->arena.cap / 16 - 8;      // (128 bytes of slack: the walk reads row-table entries a line at a time)
   }
 
-  HIP_TRY(hipMemsetAsync(c->status.p, 0, (size_t)4 * n, st));
-  HIP_TRY(hipMemsetAsync(c->counters.p, 0, CT_BYTES + 8 * 64, st));
-  c->ct_used = 0;
-  HIP_TRY(hipEventRecord(c->ev_start, st));
   // Long enough reads are packed by the wavefront kernels themselves while they stage them (WfaAlignParams::ascii): no pack
   // kernel in front of the first wavefront launch (0.63 ms per 1M x 1 kbp pairs).  Short reads keep the pack kernel: their tier
   // (several alignments per wavefront, short_kernel.hip) prefetches packed words.
   const bool fused_pack = !prepacked && b->max_seq_len >= 512u && !c->tuning.no_fused_pack;
+  // (every status starts as PENDING = 0: written by the pack kernel where it runs -- it visits every pair anyway --, by a memset
+  // -- a launch of its own, ~5 us -- where it does not)
+  if (prepacked || fused_pack) HIP_TRY(hipMemsetAsync(c->status.p, 0, (size_t)4 * n, st));
+  HIP_TRY(hipMemsetAsync(c->counters.p, 0, CT_BYTES + 8 * 64, st));
+  c->ct_used = 0;
+  HIP_TRY(hipEventRecord(c->ev_start, st));
   ap.ascii = fused_pack ? b->d_sequences : nullptr;
   ap.n_raw = ct + CT_NRAW;
   if (!prepacked && !fused_pack) {
@@ -753,6 +830,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       const uint32_t n_chain = n_cur;
       struct Link { int tier; int ct_list; int ct_cells; hipEvent_t e0, e1; bool banded; bool budgeted; bool first_round; uint32_t n_in; bool walked; } link[2];
       int n_links = 0;
+      bool fused_tail = false; uint32_t* tail_out = nullptr; unsigned long long* tail_count = nullptr;
       long long s_hi = 0;                       // no pair of this chain finishes with a larger score
       const unsigned long long* cur_len_dev = nullptr;
       for (;;) {
@@ -855,8 +933,13 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
           }
         }
         uint32_t* nxt = spare[flip]; flip ^= 1;
-        LAUNCH_K(k_compact, dim3(cdiv(n_cur, compact_block(n_cur))), dim3(compact_block(n_cur)), 0, st, (const uint32_t*)cur, n_cur, cur_len_dev,
-                           static_cast<const uint32_t*>(c->status.p), MASK(WFA_ST_BAND) | MASK(WFA_ST_SCORE), nxt, ct + L.ct_list, ap.work_counter);
+        // (the chain's ONLY launch -- nothing is enqueued behind it that needs its failure list on the device: the list is made by the
+        // chain's tail kernel together with the bounds and the count of unfinished pairs)
+        fused_tail = n_links == 0 && !(L.budgeted && speculate) && cur_len_dev == nullptr;
+        tail_out = nxt; tail_count = ct + L.ct_list;
+        if (!fused_tail)
+          LAUNCH_K(k_compact, dim3(cdiv(n_cur, compact_block(n_cur))), dim3(compact_block(n_cur)), 0, st, (const uint32_t*)cur, n_cur, cur_len_dev,
+                             static_cast<const uint32_t*>(c->status.p), MASK(WFA_ST_BAND) | MASK(WFA_ST_SCORE), nxt, ct + L.ct_list, ap.work_counter);
         s_hi = std::max<long long>(s_hi, L.banded ? std::min(max_error, 30000) : max_score);
         ++n_links; ++round;
         // what the failures of this round run with next
@@ -885,9 +968,15 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       if (zero_counter(c, CT_OPS)) return -1;
       if (zero_counter(c, CT_MAX_SCORE)) return -1;
       bool traced = false;      // (did the backtrace launch anything: are ev_t0 / ev_t1 this chain's)
-      LAUNCH_K(k_trace_bounds, dim3(std::min<uint32_t>(cdiv(n_chain, 2048), 256u)), dim3(256), 0, st, (const uint32_t*)chain_list, n_chain,
-                         static_cast<const uint32_t*>(c->status.p), (const int32_t*)d_scores,
-                         static_cast<const uint32_t*>(c->cells.p), std::min(pen.x, pen.e), item_chars, ct);
+      if (zero_counter(c, CT_UNFIN)) return -1;
+      if (fused_tail)
+        LAUNCH_K(k_chain_tail, dim3(std::min<uint32_t>(std::max(cdiv(n_chain, 2048), cdiv(n, 8192)), 256u)), dim3(256), 0, st, (const uint32_t*)chain_list, n_chain,
+                           static_cast<const uint32_t*>(c->status.p), MASK(WFA_ST_BAND) | MASK(WFA_ST_SCORE), tail_out, tail_count, ap.work_counter,
+                           (const int32_t*)d_scores, static_cast<const uint32_t*>(c->cells.p), std::min(pen.x, pen.e), item_chars, ct, n);
+      else
+        LAUNCH_K(k_trace_bounds, dim3(std::min<uint32_t>(std::max(cdiv(n_chain, 2048), cdiv(n, 8192)), 256u)), dim3(256), 0, st, (const uint32_t*)chain_list, n_chain,
+                           static_cast<const uint32_t*>(c->status.p), (const int32_t*)d_scores,
+                           static_cast<const uint32_t*>(c->cells.p), std::min(pen.x, pen.e), item_chars, ct, n);
       if (cigar_now) {
         WfaTraceParams tp{};
         tp.raw = raw ? 1 : 0;
@@ -1019,8 +1108,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       // ---- the chain's one synchronisation --------------------------------------------------------------------------
       // (with it comes the number of pairs of the whole batch that are not finished yet: when this turns out to have been the
       // call's last chain, that IS the end-of-call check -- no launch and no round trip of its own)
-      if (zero_counter(c, CT_UNFIN)) return -1;
-      LAUNCH_K(k_count_unfinished, dim3(std::min<uint32_t>(cdiv(n, 1024), 1024u)), dim3(256), 0, st, n, static_cast<const uint32_t*>(c->status.p), ct + CT_UNFIN);
+      // (k_trace_bounds above counted them)
       HIP_TRY(hipEventRecord(c->ev_end, st));
       if (read_counters(c)) return -1;
       unfinished_at_sync = (long long)c->h_counters[CT_UNFIN];

@@ -44,6 +44,13 @@ static_assert(sizeof(sequence_pair_t) == sizeof(WfaSeqPair), "ABI mirror");
     HIP_TRY(hipGetLastError());                                        \
   } while (0)
 
+// the same with the END of the kernel stamped into `ev1` by its own dispatch packet (wfa_launch_timed: no barrier packet of a hipEventRecord)
+#define LAUNCH_K_END(kern, grid, block, lds, stream, ev1, ...)                                       \
+  do {                                                                                                 \
+    wfa_launch_timed(kern, grid, block, lds, stream, (hipEvent_t) nullptr, ev1, __VA_ARGS__);          \
+    HIP_TRY(hipGetLastError());                                                                        \
+  } while (0)
+
 namespace {
 
 // hipFree waits for the whole device to go idle: inside a call -- other lanes' kernels running -- a buffer that has to grow
@@ -765,12 +772,16 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   if (prepacked || fused_pack) HIP_TRY(hipMemsetAsync(c->status.p, 0, (size_t)4 * n, st));
   HIP_TRY(hipMemsetAsync(c->counters.p, 0, CT_BYTES + 8 * 64, st));
   c->ct_used = 0;
-  HIP_TRY(hipEventRecord(c->ev_start, st));
+  // (ev_start -- the start of the call on the device -- is the start stamp of the FIRST kernel of the call, carried by its own dispatch
+  // packet: the pack kernel, or the first wavefront launch.  A hipEventRecord is a barrier packet of its own: ~5 us in front of the
+  // first kernel of every call)
+  bool have_start = false;
   ap.ascii = fused_pack ? b->d_sequences : nullptr;
   ap.n_raw = ct + CT_NRAW;
   if (!prepacked && !fused_pack) {
     // (ev_pack: the end of the pack kernel, stamped by its own dispatch packet -- wfa_launch_timed, wfa_device.h)
-    wfa_launch_pack(b->d_sequences, ap.meta, n, static_cast<uint32_t*>(c->packed.p), static_cast<uint8_t*>(c->flags.p), st, b->max_seq_len, nullptr, c->ev_pack,
+    have_start = true;
+    wfa_launch_pack(b->d_sequences, ap.meta, n, static_cast<uint32_t*>(c->packed.p), static_cast<uint8_t*>(c->flags.p), st, b->max_seq_len, c->ev_start, c->ev_pack,
                     static_cast<uint32_t*>(c->status.p), ct + CT_NRAW);      // (flagged pairs: status ALPHABET, counted)
   }
 
@@ -837,6 +848,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         Link& L = link[n_links];
         L = {0, n_links ? CT_LIST2 : CT_LIST, n_links ? CT_LCELLS2 : CT_LCELLS, n_links ? c->ev_b0 : c->ev_a0, n_links ? c->ev_b1 : c->ev_a1,
              false, budget_round, round == 0, n_cur, false};
+        if (!have_start) { L.e0 = c->ev_start; have_start = true; }      // (the call's first kernel: its start stamp is the call's)
         TierPlan tp;
         ap.budget = budget_round ? budgets : nullptr;
         // banded first attempt (packed class only); whatever it cannot finish goes to the exact tiers
@@ -969,14 +981,17 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       if (zero_counter(c, CT_MAX_SCORE)) return -1;
       bool traced = false;      // (did the backtrace launch anything: are ev_t0 / ev_t1 this chain's)
       if (zero_counter(c, CT_UNFIN)) return -1;
+      // (ev_end -- the end of the chain on the device -- is the end stamp of the chain's LAST kernel: this one in score-only calls,
+      // the compaction of the NOMEM pairs behind the backtrace otherwise)
+      const hipEvent_t ev_tail = cigar_now ? (hipEvent_t) nullptr : c->ev_end;
       if (fused_tail)
-        LAUNCH_K(k_chain_tail, dim3(std::min<uint32_t>(std::max(cdiv(n_chain, 2048), cdiv(n, 8192)), 256u)), dim3(256), 0, st, (const uint32_t*)chain_list, n_chain,
-                           static_cast<const uint32_t*>(c->status.p), MASK(WFA_ST_BAND) | MASK(WFA_ST_SCORE), tail_out, tail_count, ap.work_counter,
-                           (const int32_t*)d_scores, static_cast<const uint32_t*>(c->cells.p), std::min(pen.x, pen.e), item_chars, ct, n);
+        LAUNCH_K_END(k_chain_tail, dim3(std::min<uint32_t>(std::max(cdiv(n_chain, 2048), cdiv(n, 8192)), 256u)), dim3(256), 0, st, ev_tail, (const uint32_t*)chain_list, n_chain,
+                               static_cast<const uint32_t*>(c->status.p), MASK(WFA_ST_BAND) | MASK(WFA_ST_SCORE), tail_out, tail_count, ap.work_counter,
+                               (const int32_t*)d_scores, static_cast<const uint32_t*>(c->cells.p), std::min(pen.x, pen.e), item_chars, ct, n);
       else
-        LAUNCH_K(k_trace_bounds, dim3(std::min<uint32_t>(std::max(cdiv(n_chain, 2048), cdiv(n, 8192)), 256u)), dim3(256), 0, st, (const uint32_t*)chain_list, n_chain,
-                           static_cast<const uint32_t*>(c->status.p), (const int32_t*)d_scores,
-                           static_cast<const uint32_t*>(c->cells.p), std::min(pen.x, pen.e), item_chars, ct, n);
+        LAUNCH_K_END(k_trace_bounds, dim3(std::min<uint32_t>(std::max(cdiv(n_chain, 2048), cdiv(n, 8192)), 256u)), dim3(256), 0, st, ev_tail, (const uint32_t*)chain_list, n_chain,
+                               static_cast<const uint32_t*>(c->status.p), (const int32_t*)d_scores,
+                               static_cast<const uint32_t*>(c->cells.p), std::min(pen.x, pen.e), item_chars, ct, n);
       if (cigar_now) {
         WfaTraceParams tp{};
         tp.raw = raw ? 1 : 0;
@@ -1102,14 +1117,13 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         traced = wfa_launch_trace(tp, st, c->ev_t0, c->ev_t1);
         HIP_TRY(hipGetLastError());
         // ---- pairs that ran out of arena go into the next pass (CIGAR calls only: score-only calls have no arena) ----
-        LAUNCH_K(k_compact, dim3(cdiv(n_chain, compact_block(n_chain))), dim3(compact_block(n_chain)), 0, st, (const uint32_t*)chain_list, n_chain, (const unsigned long long*)nullptr,
-                           static_cast<const uint32_t*>(c->status.p), MASK(WFA_ST_NOMEM), nxt_pending, ct + CT_NOMEM);
+        LAUNCH_K_END(k_compact, dim3(cdiv(n_chain, compact_block(n_chain))), dim3(compact_block(n_chain)), 0, st, c->ev_end, (const uint32_t*)chain_list, n_chain, (const unsigned long long*)nullptr,
+                               static_cast<const uint32_t*>(c->status.p), MASK(WFA_ST_NOMEM), nxt_pending, ct + CT_NOMEM, (unsigned int*)nullptr);
       }
       // ---- the chain's one synchronisation --------------------------------------------------------------------------
       // (with it comes the number of pairs of the whole batch that are not finished yet: when this turns out to have been the
       // call's last chain, that IS the end-of-call check -- no launch and no round trip of its own)
       // (k_trace_bounds above counted them)
-      HIP_TRY(hipEventRecord(c->ev_end, st));
       if (read_counters(c)) return -1;
       unfinished_at_sync = (long long)c->h_counters[CT_UNFIN];
       uint32_t n_in = n_chain;

@@ -43,8 +43,8 @@ typedef struct {
                               records when each of its waves reaches and leaves the per-score barrier (s_memtime);
                               wfagpu_amd_debug_times() hands the records out                                              */
     int no_short_cigar;    /* A/B and test hook: CIGAR calls never take tier 5 (several alignments per wavefront)               */
-    int no_fused_pack;     /* A/B: always run the pack kernel (default: reads of 512 bases and more are packed by the wavefront
-                              kernels while they stage them)                                                                    */
+    int no_fused_pack;     /* A/B: always run the pack kernel (default: reads of 512 bases and more -- and shorter ones where tier 5, several
+                              alignments per wavefront, takes the penalties -- are packed by the wavefront kernels while they stage them) */
     int kernel_walk;       /* 1: the one-wave wavefront kernels walk a finished alignment back themselves (align/walk_epilogue.inc:
                               tiles through the freed ring LDS, op list into the arena) and wfa_walk_kernel does not run.  Off by
                               default: measured on BASELINE configs[2] the backtrace pass drops from 3.05 to 1.45 ms but the serial
@@ -52,6 +52,10 @@ typedef struct {
     int exact_two_waves;   /* A/B hook: the exact search takes two waves per alignment where it would take four                 */
     int band_tier;         /* A/B hook: wavefronts per alignment of the banded kernels -- 1: one, 2: two, 3: four, 4: sixteen (0: by
                               the wavefronts a CU ends up holding, plan_tier)                                                    */
+    int no_host_parts;     /* A/B and test hook: a score-only call whose only wavefront launch is tier 5 over the whole batch lets that
+                              launch store its partial sums (cells, unfinished / failed / flagged pairs per wavefront) straight into
+                              pinned host memory -- one kernel and a stream synchronisation per call --; 1: they stay on the device and
+                              come over with the counter block (a copy behind the kernel)                                           */
     int emit_pairs;        /* lane-per-alignment CIGAR replay with the sequences staged in LDS: alignments per wavefront
                               (8..64; 0: automatic -- as many as keep the most lanes resident per CU)                          */
 } wfagpu_amd_tuning_t;

@@ -176,3 +176,55 @@ def test_one_million_pairs_sharded_over_eight_device_slots():
     so, co = _truth(buf, meta[idx], PEN)
     assert np.array_equal(s8[idx], so)
     assert [c8[i].decode() for i in idx] == co
+
+
+@pytest.mark.parametrize("cigar", [False, True])
+def test_short_reads_packed_by_their_own_tier(cigar):
+    """Reads of 150 bases are packed by tier 5 itself while it stages them (short_kernel.hip, ASCII instantiations) and -- score-only,
+    once the budgets are inherited -- the call is ONE kernel: the launch appends its failures, counts what it leaves unfinished and
+    stores its partial sums straight into pinned host memory.  Same scores (and CIGARs) as the checker and as the older paths
+    (tuning.no_host_parts: partial sums copied from the device; tuning.no_fused_pack: the pack kernel in front), with pairs that leave
+    the tier on every way out: bytes outside ACGT (byte-compare class), a long gap (diagonal window too wide), many errors (budget),
+    an empty pattern."""
+    rng = random.Random(77)
+    buf_a, meta_a = wfagpu.generate_pairs(24000, 150, 0.02, seed=51)
+    pairs = wfagpu.pairs_from_layout(buf_a, meta_a)
+    buf_b, meta_b = wfagpu.generate_pairs(60, 150, 0.25, seed=52)
+    pairs += wfagpu.pairs_from_layout(buf_b, meta_b)
+    for _ in range(50):
+        p, t = pairs[rng.randrange(24000)]
+        p = bytearray(p)
+        p[rng.randrange(len(p))] = rng.choice(b"NnRYk")
+        pairs.append((bytes(p), t))
+    for _ in range(40):
+        p, t = pairs[rng.randrange(24000)]
+        cut = rng.randrange(10, 60)
+        pairs.append((p, t[:cut] + t[cut + 45:]))
+    pairs.append((b"", b"ACGTACGTAC"))
+    pairs.append((b"ACGTTGCA", b""))
+    rng.shuffle(pairs)
+    buf, meta = wfagpu.layout_pairs(pairs)
+    so, co = _truth(buf, meta, PEN, cigar=cigar)
+    me = int(so.max()) + 4
+    # (one context: the first call draws the budget sample -- which pairs it holds is not deterministic --, the later ones inherit its
+    # budgets: the one-kernel shape, then the older paths under the same budgets)
+    stats = {}
+    al = wfagpu.DeviceAligner(0)
+    try:
+        al.hint_same_stream(True)
+        batch = al.upload(buf, meta)
+        for name, tuning in (("sampling", {}), ("default", {}), ("parts_on_device", {"no_host_parts": 1}), ("pack_kernel", {"no_fused_pack": 1}),
+                             ("default_again", {})):
+            al.set_tuning(**tuning)
+            s, c = al.align(batch, PEN, max_error=me, compute_cigar=cigar)
+            assert np.array_equal(s, so), (name, np.nonzero(np.asarray(s) != so)[0][:8])
+            if cigar:
+                assert c == co, name
+            st = al.stats()
+            assert st.pairs_raw == 50, (name, st.pairs_raw)
+            stats[name] = (st.cells, st.pairs_tier[5], st.pairs_retried, st.pairs_budget_missed, st.align_launches)
+    finally:
+        al.close()
+    assert stats["default"][1] > 23000      # (tier 5 took the batch)
+    # (the same work accounting whichever way the sums reach the host)
+    assert stats["default"] == stats["parts_on_device"] == stats["pack_kernel"] == stats["default_again"], stats

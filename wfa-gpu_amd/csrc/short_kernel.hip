@@ -22,6 +22,7 @@
 #include <utility>
 
 #include "wfa_device.h"
+#include "pack_device.h"
 
 namespace {
 
@@ -53,7 +54,12 @@ template <int L> __device__ __forceinline__ int from_above(int v, int j) {
 // stays valid in WFA2), so scores, tie-breaks along the optimal path and hence the CIGAR are the same: argued in DESIGN.md
 // section 4.2b, searched with scratch/short_cigar_semantics.py (oracle with that one change: 0 of 240 000 indel-heavy short
 // pairs differ), and held by the parity tests, which compare every CIGAR of this tier with WFA2's.
-template <int L, int X, int OE, bool BT>
+// ASCII: the batch has not been packed (WfaAlignParams::ascii): the sixteen bytes of a word are what is requested ahead, and the word
+// is made when it is staged -- to LDS and to the packed buffer, where the backtrace kernels look for it.  (A pack kernel in front of a
+// launch of 100k configs[1] pairs was 18 us + the gap between two launches of a 168 us step; here it is ~80 vector instructions per
+// iteration in a kernel whose vector pipe is half idle.)  A pair with a byte outside ACGT leaves with status ALPHABET like in the
+// wavefront kernels that pack while staging (align_kernel.hip).
+template <int L, int X, int OE, bool BT, bool ASCII>
 __global__ void __launch_bounds__(64) wfa_short_kernel(const WfaAlignParams p) {
   static_assert(X >= 1 && X <= 8 && OE >= 1 && OE <= 8, "history of eight scores");
   constexpr int D = X > OE ? X : OE;
@@ -74,6 +80,7 @@ __global__ void __launch_bounds__(64) wfa_short_kernel(const WfaAlignParams p) {
   if (p.n_work_dev) n_work = min(n_work, (uint32_t)*p.n_work_dev);
   const unsigned long long grp_mask = (L == 64) ? ~0ull : (((1ull << L) - 1ull) << (grp * L));
   unsigned long long blk_cells = 0;
+  uint32_t not_done = 0, n_fail = 0, n_flag = 0;            // (group leaders: pairs of this wavefront's share that did not leave DONE / went to fail_list / were flagged ALPHABET)
   unsigned long long arena_top0 = 0;                        // (the bump pointer as the launch found it: nobody moves it while the launch runs)
   if constexpr (BT) arena_top0 = *p.arena_top;
 
@@ -84,9 +91,11 @@ __global__ void __launch_bounds__(64) wfa_short_kernel(const WfaAlignParams p) {
   // Now the work item of iteration i+3, the record of i+2 and the sequences of i+1 are requested at the top of iteration i and
   // looked at one iteration later; the sequences wait in registers (NPF words per lane and sequence; longer ones fetch the
   // rest when they are staged) and go into the other LDS set when iteration i is done.
-  constexpr int NPF = 2;
-  struct Meta { uint32_t pair, st, poff, toff; int plen, tlen, budget; };
-  struct SeqRegs { uint32_t a[NPF], b[NPF]; };
+  constexpr int NPF = ASCII ? 1 : 2;
+  struct Meta { uint32_t pair, st, poff, toff; int plen, tlen, budget; uint32_t pasc, tasc; };      // (pasc / tasc: ASCII, dword index of the sequence in the batch)
+  struct SeqRegs { uint32_t a[ASCII ? 4 : NPF], b[ASCII ? 4 : NPF]; };
+  const uint32_t* const asc = reinterpret_cast<const uint32_t*>(p.ascii);
+  uint32_t* const packed_out = const_cast<uint32_t*>(p.packed);
   const uint32_t stride = gridDim.x * G;
   auto fetch_pair = [&](const uint32_t b) -> uint32_t {     // (groups beyond the list look at its last item and stay inactive)
     const uint32_t w = min(b + (uint32_t)grp, n_work - 1u);
@@ -99,7 +108,14 @@ __global__ void __launch_bounds__(64) wfa_short_kernel(const WfaAlignParams p) {
     const WfaSeqPair mp = p.meta[pair];
     m.plen = (int)mp.pattern_len; m.tlen = (int)mp.text_len;
     m.poff = (uint32_t)(mp.pattern_offset_packed >> 2); m.toff = (uint32_t)(mp.text_offset_packed >> 2);
-    m.budget = p.budget ? p.budget[pair] : p.max_score;
+    m.pasc = ASCII ? (uint32_t)(mp.pattern_offset >> 2) : 0u; m.tasc = ASCII ? (uint32_t)(mp.text_offset >> 2) : 0u;
+    if (p.budget) m.budget = p.budget[pair];
+    else if (p.budget_q > 0) {
+      // (k_budget's rule, wfa_host.hip)
+      const unsigned long long ql = (unsigned long long)p.budget_q * (unsigned)max(m.plen, m.tlen);
+      const long long v = (long long)((p.budget_margin == 100 ? ql : ql * (unsigned)p.budget_margin / 100ull) >> 10) + p.budget_slack;
+      m.budget = (int)min(0x3FFFFFFFll, v);
+    } else m.budget = p.max_score;
     return m;
   };
   auto words_of = [](const int len) { return ((len + 15) >> 4) + 1; };
@@ -109,17 +125,53 @@ __global__ void __launch_bounds__(64) wfa_short_kernel(const WfaAlignParams p) {
   auto fetch_seq = [&](const Meta& m, const bool ok) -> SeqRegs {
     SeqRegs r;
     const int pw = ok ? words_of(m.plen) : 0, tw = ok ? words_of(m.tlen) : 0;
+    if constexpr (ASCII) {
+      // the sixteen bytes of word j of either sequence (indices clamped to the sequence's last dword: pack_device.h; an empty
+      // sequence may sit at the very end of the buffer: its fully masked loads go to the record array)
+      const uint32_t* const ps = m.plen ? asc + m.pasc : reinterpret_cast<const uint32_t*>(p.meta);
+      const uint32_t* const ts = m.tlen ? asc + m.tasc : reinterpret_cast<const uint32_t*>(p.meta);
+      wfa_pack::PackWord a{0u, 0u, 0u, 0u}, b{0u, 0u, 0u, 0u};
+      if (j < pw) a = wfa_pack::load_word(ps, (uint32_t)m.plen, (uint32_t)j);
+      if (j < tw) b = wfa_pack::load_word(ts, (uint32_t)m.tlen, (uint32_t)j);
+      r.a[0] = a.a0; r.a[1] = a.a1; r.a[2] = a.a2; r.a[3] = a.a3;
+      r.b[0] = b.a0; r.b[1] = b.a1; r.b[2] = b.a2; r.b[3] = b.a3;
+    } else {
 #pragma unroll
     for (int u = 0; u < NPF; ++u) {
       const int i = j + u * L;
       r.a[u] = i < pw ? p.packed[(size_t)m.poff + i] : 0u;
       r.b[u] = i < tw ? p.packed[(size_t)m.toff + i] : 0u;
     }
+    }
     return r;
   };
-  auto stage_seq = [&](uint32_t* const Pb, const Meta& m, const SeqRegs& r, const bool ok) {
+  // (ASCII: marks a group whose pair has a byte outside ACGT -- status ALPHABET, counted, out of this kernel's hands)
+  auto stage_seq = [&](uint32_t* const Pb, Meta& m, const SeqRegs& r, const bool ok) {
     uint32_t* const Tb = Pb + cap;
     const int pw = ok ? words_of(m.plen) : 0, tw = ok ? words_of(m.tlen) : 0;
+    if constexpr (ASCII) {
+      uint32_t bad = 0;
+      const uint32_t* const ps = m.plen ? asc + m.pasc : reinterpret_cast<const uint32_t*>(p.meta);
+      const uint32_t* const ts = m.tlen ? asc + m.tasc : reinterpret_cast<const uint32_t*>(p.meta);
+      if (j < pw) { const uint32_t w = wfa_pack::pack_word(wfa_pack::PackWord{r.a[0], r.a[1], r.a[2], r.a[3]}, (uint32_t)m.plen, (uint32_t)j, bad); Pb[j] = w; packed_out[(size_t)m.poff + j] = w; }
+      if (j < tw) { const uint32_t w = wfa_pack::pack_word(wfa_pack::PackWord{r.b[0], r.b[1], r.b[2], r.b[3]}, (uint32_t)m.tlen, (uint32_t)j, bad); Tb[j] = w; packed_out[(size_t)m.toff + j] = w; }
+#pragma nounroll
+      for (int i = j + L; i < pw; i += L) { const uint32_t w = wfa_pack::pack_word(wfa_pack::load_word(ps, (uint32_t)m.plen, (uint32_t)i), (uint32_t)m.plen, (uint32_t)i, bad); Pb[i] = w; packed_out[(size_t)m.poff + i] = w; }
+#pragma nounroll
+      for (int i = j + L; i < tw; i += L) { const uint32_t w = wfa_pack::pack_word(wfa_pack::load_word(ts, (uint32_t)m.tlen, (uint32_t)i), (uint32_t)m.tlen, (uint32_t)i, bad); Tb[i] = w; packed_out[(size_t)m.toff + i] = w; }
+      if ((__builtin_amdgcn_ballot_w64(bad != 0u) & grp_mask) != 0ull) {
+        // WFA2 compares raw bytes: this pair belongs to the byte-compare class, which runs after the packed one
+        if (j == 0) {
+          atomicAdd(p.n_raw, 1ull);
+          p.score[m.pair] = -1;
+          p.status[m.pair] = WFA_ST_ALPHABET;
+          if (p.cells) p.cells[m.pair] = 0;
+          ++n_flag;
+        }
+        m.st = WFA_ST_ALPHABET;
+      }
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < NPF; ++u) {
       const int i = j + u * L;
@@ -316,42 +368,54 @@ __global__ void __launch_bounds__(64) wfa_short_kernel(const WfaAlignParams p) {
       const uint32_t cells = (status == WFA_ST_DONE) ? (uint32_t)(max(score, 0) + 1) * (uint32_t)L : 0u;
       if (p.cells) p.cells[pair] = cells;
       blk_cells += cells;
+      if (p.fail_list && (status == WFA_ST_BAND || status == WFA_ST_SCORE)) { p.fail_list[atomicAdd(p.fail_count, 1ull)] = pair; ++n_fail; }      // (rare)
     }
+    if (j == 0 && w < n_work && !(active && status == WFA_ST_DONE)) ++not_done;      // (skipped pairs -- another class's -- included)
     // ---- everything moves up one stage
     m0 = m1; m1 = m2; pair2 = pair3;
     { uint32_t* const t = Pw; Pw = Pn; Pn = t; }
     __builtin_amdgcn_wave_barrier();
   }
   // cells of this wavefront (the group leaders counted theirs)
-  for (int d = 32; d > 0; d >>= 1) blk_cells += __shfl_down(blk_cells, d);
-  if (lane == 0 && blk_cells && p.launch_cells) atomicAdd(p.launch_cells, blk_cells);
+  for (int d = 32; d > 0; d >>= 1) {
+    blk_cells += __shfl_down(blk_cells, d); not_done += __shfl_down(not_done, d); n_fail += __shfl_down(n_fail, d); n_flag += __shfl_down(n_flag, d);
+  }
+  if (lane == 0) {
+    if (p.wave_parts) {
+      ulonglong4* const out = reinterpret_cast<ulonglong4*>(p.wave_parts) + blockIdx.x;
+      *out = make_ulonglong4(blk_cells, not_done, n_fail, n_flag);
+    }
+    else if (blk_cells && p.launch_cells) atomicAdd(p.launch_cells, blk_cells);
+  }
 }
 
-template <int L, int X, int OE, bool BT>
+template <int L, int X, int OE, bool BT, bool ASCII>
 void launch_short(const WfaAlignParams& p, int grid, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
   const size_t lds = wfa_short_lds_bytes(p, L, BT);
-  wfa_launch_timed(wfa_short_kernel<L, X, OE, BT>, dim3(grid), dim3(64), lds, stream, ev0, ev1, p);
+  wfa_launch_timed(wfa_short_kernel<L, X, OE, BT, ASCII>, dim3(grid), dim3(64), lds, stream, ev0, ev1, p);
 }
 
 // wavefronts of this instantiation a CU holds (registers and LDS)
-template <int L, int X, int OE, bool BT>
+template <int L, int X, int OE, bool BT, bool ASCII>
 int occ_short(size_t lds) {
   int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(wfa_short_kernel<L, X, OE, BT>), 64, lds) != hipSuccess) { nb = 0; (void)hipGetLastError(); }
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(wfa_short_kernel<L, X, OE, BT, ASCII>), 64, lds) != hipSuccess) { nb = 0; (void)hipGetLastError(); }
   return nb;
 }
 
-// [x - 1][oe - 1], one table per group width and mode
+// [x - 1][oe - 1], one table per group width, mode and input (packed words / ASCII)
 struct ShortEntry { void (*launch)(const WfaAlignParams&, int, hipStream_t, hipEvent_t, hipEvent_t); int (*occ)(size_t); };
-template <int L, bool BT, int I> constexpr ShortEntry short_entry() { return {&launch_short<L, I / 8 + 1, I % 8 + 1, BT>, &occ_short<L, I / 8 + 1, I % 8 + 1, BT>}; }
-template <int L, bool BT, int... Is> constexpr std::array<ShortEntry, 64> short_table(std::integer_sequence<int, Is...>) { return {short_entry<L, BT, Is>()...}; }
-const std::array<ShortEntry, 64> g_short16 = short_table<16, false>(std::make_integer_sequence<int, 64>{});
-const std::array<ShortEntry, 64> g_short32 = short_table<32, false>(std::make_integer_sequence<int, 64>{});
-const std::array<ShortEntry, 64> g_short16_bt = short_table<16, true>(std::make_integer_sequence<int, 64>{});
-const std::array<ShortEntry, 64> g_short32_bt = short_table<32, true>(std::make_integer_sequence<int, 64>{});
+template <int L, bool BT, bool ASCII, int I> constexpr ShortEntry short_entry() { return {&launch_short<L, I / 8 + 1, I % 8 + 1, BT, ASCII>, &occ_short<L, I / 8 + 1, I % 8 + 1, BT, ASCII>}; }
+template <int L, bool BT, bool ASCII, int... Is> constexpr std::array<ShortEntry, 64> short_table(std::integer_sequence<int, Is...>) { return {short_entry<L, BT, ASCII, Is>()...}; }
+// [ASCII][BT][L == 32]
+const std::array<ShortEntry, 64> g_short[2][2][2] = {
+    {{short_table<16, false, false>(std::make_integer_sequence<int, 64>{}), short_table<32, false, false>(std::make_integer_sequence<int, 64>{})},
+     {short_table<16, true, false>(std::make_integer_sequence<int, 64>{}), short_table<32, true, false>(std::make_integer_sequence<int, 64>{})}},
+    {{short_table<16, false, true>(std::make_integer_sequence<int, 64>{}), short_table<32, false, true>(std::make_integer_sequence<int, 64>{})},
+     {short_table<16, true, true>(std::make_integer_sequence<int, 64>{}), short_table<32, true, true>(std::make_integer_sequence<int, 64>{})}}};
 const ShortEntry& short_pick(const WfaAlignParams& p, int lanes, bool with_bt) {
   const int idx = (p.x - 1) * 8 + (p.oe - 1);
-  return with_bt ? (lanes == 16 ? g_short16_bt : g_short32_bt)[idx] : (lanes == 16 ? g_short16 : g_short32)[idx];
+  return g_short[p.ascii ? 1 : 0][with_bt ? 1 : 0][lanes == 16 ? 0 : 1][idx];
 }
 
 }  // namespace

@@ -84,6 +84,8 @@ struct WfaAlignParams {
   int rs;                        // row stride (elements), even: widest diagonal window + 3
   int max_score;                 // give up (WFA_ST_SCORE) beyond this score
   const int32_t* budget;         // optional per-pair score budget (auto-tuned), capped by max_score
+  int budget_q, budget_slack, budget_margin;   // tier 5 only, budget == NULL, budget_q > 0: the per-pair budget by k_budget's rule (wfa_host.hip), computed in the
+                                 // kernel: (q * longer length * margin / 100) / 1024 + slack -- no launch to fill the array in front of the call's only wavefront launch
   int band_width;                // > 0: adaptive band, diagonals kept per wavefront (banded kernels)
   int band_period;               //      re-centre the band every this many scores
   int seq_words_cap;             // LDS words reserved per packed sequence
@@ -92,6 +94,13 @@ struct WfaAlignParams {
   uint32_t* status;              // [pair] out
   uint32_t* cells;               // [pair] out, optional: number of wavefront cells computed
   unsigned long long* launch_cells;  // optional: += cells computed by this launch (one atomic per workgroup)
+  // tier 5 only.  wave_parts: four u64 per wavefront of the launch {cells, pairs of its share of the list that did not leave DONE, pairs
+  // it appended to fail_list, pairs it flagged ALPHABET}, plain stores -- to device memory, or straight to pinned host memory --
+  // (instead of the atomic on launch_cells: thousands of wavefronts ending together on one counter line).  fail_list / fail_count: the
+  // kernel appends the pairs it leaves with status BAND or SCORE itself (the chain's only launch, score-only: no kernel behind it)
+  unsigned long long* wave_parts;
+  uint32_t* fail_list;
+  unsigned long long* fail_count;
   // backtrace (CIGAR mode)
   uint8_t* arena;                // base of the arena
   unsigned long long arena_units;        // capacity in 16-byte units

@@ -102,6 +102,12 @@ enum { CT_ARENA = 0, CT_OPS = 1, CT_TEXT = 2, CT_LCELLS = 3, CT_LIST = 4, CT_SUM
        CT_LCELLS2 = 11, CT_LIST2 = 12, CT_NOMEM = 13, CT_UNFIN = 14, CT_N = 15 };
 constexpr size_t CT_BYTES = 128;      // the u64 slots, padded to a cache line boundary (CT_N * 8 = 120)
 static_assert(CT_N * sizeof(unsigned long long) <= CT_BYTES && CT_N <= 32, "counter block");
+// Behind the u64 slots and the eight claim counters: tier 5's partial sums, four u64 per wavefront of a launch (WfaAlignParams::wave_parts;
+// a launch has at most 32 wavefronts per CU).  On the device when a kernel behind the launch adds them up; in the pinned host copy
+// of this block (the kernel stores them there itself) when nothing runs behind the launch.
+constexpr size_t CT_PARTS_OFF = CT_BYTES + 8 * 64;
+constexpr size_t CT_PARTS_PER_CU = 32;
+constexpr size_t CT_PART_BYTES = 32;
 
 constexpr uint32_t MASK(uint32_t st) { return 1u << st; }
 
@@ -123,6 +129,16 @@ __device__ __forceinline__ void block_append(bool take, uint32_t value, uint32_t
   if (take) out[block_base + wave_n[wave] + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = value;
 }
 
+// Tier 5 leaves the cells of a launch as one partial sum per wavefront (plain stores): the kernel behind the launch adds them up.
+// (One atomic per wavefront on the call's counter line -- ~11 ns each whoever issues it, 3571 wavefronts ending together -- was 15 of the
+// 107 us of a launch of 100k configs[1] pairs.)
+__device__ __forceinline__ void add_wave_parts(const unsigned long long* __restrict__ parts, uint32_t n_parts, unsigned long long* __restrict__ out) {
+  unsigned long long s = 0;
+  for (uint32_t i = threadIdx.x; i < n_parts; i += blockDim.x) s += parts[4 * i];      // ({cells, ...} per wavefront: WfaAlignParams::wave_parts)
+  for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d);
+  if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
+}
+
 // pairs of `work` whose status is in `mask` -> out list (appended at *out_count).  n_dev (optional): the real length of
 // `work` where only the device knows it yet; n is then an upper bound.
 // work_ctr (optional): the eight claim counters of the wavefront launch that has just finished, zeroed here for the next
@@ -130,9 +146,11 @@ __device__ __forceinline__ void block_append(bool take, uint32_t value, uint32_t
 __global__ void __launch_bounds__(1024) k_compact(const uint32_t* __restrict__ work, uint32_t n, const unsigned long long* __restrict__ n_dev,
                           const uint32_t* __restrict__ status,
                           uint32_t mask, uint32_t* __restrict__ out, unsigned long long* __restrict__ out_count,
-                          unsigned int* __restrict__ work_ctr = nullptr) {
+                          unsigned int* __restrict__ work_ctr = nullptr,
+                          const unsigned long long* __restrict__ parts = nullptr, uint32_t n_parts = 0, unsigned long long* __restrict__ parts_out = nullptr) {
   const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
   if (work_ctr && blockIdx.x == 0 && threadIdx.x < 8) work_ctr[threadIdx.x * 16] = 0u;
+  if (parts && blockIdx.x == 0) add_wave_parts(parts, n_parts, parts_out);
   if (n_dev) n = min(n, (uint32_t)*n_dev);
   bool take = false; uint32_t pair = 0;
   if (gid < n) { pair = work ? work[gid] : gid; take = (mask >> status[pair]) & 1u; }
@@ -215,11 +233,13 @@ __global__ void __launch_bounds__(256) k_trace_bounds(const uint32_t* __restrict
 __global__ void __launch_bounds__(256) k_chain_tail(const uint32_t* __restrict__ work, uint32_t n, const uint32_t* __restrict__ status,
                              uint32_t mask, uint32_t* __restrict__ out, unsigned long long* __restrict__ out_count, unsigned int* __restrict__ work_ctr,
                              const int32_t* __restrict__ score, const uint32_t* __restrict__ cells, int min_op_cost, int item_chars,
-                             unsigned long long* __restrict__ ct, uint32_t n_all) {
+                             unsigned long long* __restrict__ ct, uint32_t n_all,
+                             const unsigned long long* __restrict__ parts, uint32_t n_parts, unsigned long long* __restrict__ parts_out) {
   // (few blocks, grid-stride: all the counters of a call share one cache line and an atomic on it costs ~11 ns whoever issues it --
   // one block per 64 list entries, four atomics each, made this kernel 70 us for 100k pairs)
   __shared__ unsigned long long part[4][4];
   if (work_ctr && blockIdx.x == 0 && threadIdx.x < 8) work_ctr[threadIdx.x * 16] = 0u;
+  if (parts && blockIdx.x == gridDim.x - 1) add_wave_parts(parts, n_parts, parts_out);
   unsigned long long ops = 0, txt = 0, cl = 0;
   uint32_t smax = 0;
   for (uint32_t base = blockIdx.x * 256u; base < n; base += gridDim.x * 256u) {      // (uniform per block: block_append has barriers)
@@ -346,6 +366,8 @@ struct wfagpu_amd_ctx {
   size_t lds_per_block_max = 0;
   size_t arena_cfg = 0, text_cfg = 0, arena_limit = 0, arena_limit_max = 0;
   wfagpu_amd_tuning_t tuning{};
+  bool counters_zeroed = false;    // (the last call returned with its counters zeroed again behind its last read: the next one need not start with a memset)
+  bool short_ascii_ok = true;      // (this call's ASCII buffer is below 16 GiB: tier 5 indexes it by 32-bit dwords)
   DevBuf packed, flags, status, cells, bt_final, list_a, list_b, list_c, list_d, list_e, work_ctr, sample, ratio, budget, counters, arena, ops, text_scratch, gring;
   // The results of a CIGAR call -- dense text, offsets, lengths -- alternate between two sets of buffers: the pointers a call
   // hands out stay valid through the NEXT call, so a pipelined caller copies the results of batch j to the host while the
@@ -402,14 +424,14 @@ int wfagpu_amd_create(wfagpu_amd_ctx_t** out, const wfagpu_amd_config_t* cfg) {
     c->arena_limit = cfg ? cfg->arena_limit_bytes : 0;
     c->arena_limit_max = cfg ? cfg->arena_limit_max_bytes : 0;
     if (cfg) c->tuning = cfg->tuning;
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_counters), CT_N * sizeof(unsigned long long), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_counters), CT_PARTS_OFF + CT_PART_BYTES * CT_PARTS_PER_CU * (size_t)c->num_cus, hipHostMallocDefault));
     HIP_TRY(hipEventCreate(&c->ev_start)); HIP_TRY(hipEventCreate(&c->ev_pack));
     HIP_TRY(hipEventCreate(&c->ev_a0)); HIP_TRY(hipEventCreate(&c->ev_a1));
     HIP_TRY(hipEventCreate(&c->ev_b0)); HIP_TRY(hipEventCreate(&c->ev_b1));
     HIP_TRY(hipEventCreate(&c->ev_t0)); HIP_TRY(hipEventCreate(&c->ev_t1));
     HIP_TRY(hipEventCreate(&c->ev_end));
     // (the eight claim counters of the wavefront kernels, 64 bytes apart, sit behind the u64 slots: one memset zeroes both)
-    if (c->counters.ensure(CT_BYTES + 8 * 64, c->stream)) return -1;
+    if (c->counters.ensure(CT_PARTS_OFF + CT_PART_BYTES * CT_PARTS_PER_CU * (size_t)c->num_cus, c->stream)) return -1;
     return 0;
   };
   if (init()) { wfagpu_amd_destroy(c); return -1; }
@@ -555,7 +577,7 @@ bool plan_tier(const wfagpu_amd_ctx* c, WfaAlignParams& p, int max_score, unsign
   // Short wavefronts, score only (tier 5, short_kernel.hip): when the diagonal window of the budget fits 16 or 32 lanes, four or two
   // alignments share a wavefront and the rings live in registers (BASELINE configs[1]: 150 bp reads, budgets of ~14 once
   // they are tuned).  Pairs whose own window is wider (large |tlen - plen|) come back as BAND failures and go on as always.
-  if (!raw && !p.ascii && c->tuning.min_tier == 0 && !(bt && c->tuning.no_short_cigar) && wfa_short_supported(p.x, p.oe, p.e) && width + 1 <= 32 && max_score <= 30000) {
+  if (!raw && !(p.ascii && !c->short_ascii_ok) && c->tuning.min_tier == 0 && !(bt && c->tuning.no_short_cigar) && wfa_short_supported(p.x, p.oe, p.e) && width + 1 <= 32 && max_score <= 30000) {
     const int lanes = width + 1 <= 16 ? 16 : 32;
     p.rs = 0;
     const size_t lds = wfa_short_lds_bytes(p, lanes, bt);
@@ -628,8 +650,10 @@ bool plan_tier(const wfagpu_amd_ctx* c, WfaAlignParams& p, int max_score, unsign
   return true;
 }
 
-int read_counters(wfagpu_amd_ctx* c) {
-  HIP_TRY(hipMemcpyAsync(c->h_counters, c->counters.p, CT_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+// (n_parts > 0: with the partial sums of a tier-5 launch of n_parts wavefronts -- one copy)
+int read_counters(wfagpu_amd_ctx* c, uint32_t n_parts = 0) {
+  const size_t bytes = n_parts ? CT_PARTS_OFF + CT_PART_BYTES * n_parts : CT_N * sizeof(unsigned long long);
+  HIP_TRY(hipMemcpyAsync(c->h_counters, c->counters.p, bytes, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -764,13 +788,31 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   }
 
   // Long enough reads are packed by the wavefront kernels themselves while they stage them (WfaAlignParams::ascii): no pack
-  // kernel in front of the first wavefront launch (0.63 ms per 1M x 1 kbp pairs).  Short reads keep the pack kernel: their tier
-  // (several alignments per wavefront, short_kernel.hip) prefetches packed words.
-  const bool fused_pack = !prepacked && b->max_seq_len >= 512u && !c->tuning.no_fused_pack;
-  // (every status starts as PENDING = 0: written by the pack kernel where it runs -- it visits every pair anyway --, by a memset
-  // -- a launch of its own, ~5 us -- where it does not)
-  if (prepacked || fused_pack) HIP_TRY(hipMemsetAsync(c->status.p, 0, (size_t)4 * n, st));
-  HIP_TRY(hipMemsetAsync(c->counters.p, 0, CT_BYTES + 8 * 64, st));
+  // kernel in front of the first wavefront launch (0.63 ms per 1M x 1 kbp pairs).  Short reads too where tier 5 (several
+  // alignments per wavefront, short_kernel.hip: the sixteen bytes of a word requested ahead instead of the word) takes the penalties:
+  // 18 us + the gap between two launches of a 168 us step of 100k configs[1] pairs.  (ASCII dword indices are 32-bit there.)
+  c->short_ascii_ok = b->sequences_bytes < ((size_t)1 << 34);
+  const bool short_fuses = wfa_short_supported(pen.x, oe, pen.e) && !c->tuning.min_tier && !(compute_cigar && c->tuning.no_short_cigar) && c->short_ascii_ok;
+  const bool fused_pack = !prepacked && (b->max_seq_len >= 512u || short_fuses) && !c->tuning.no_fused_pack;
+  // Every status starts as PENDING = 0: written by the pack kernel where it runs (it visits every pair anyway), by a memset (a
+  // launch of its own, ~5 us + a gap) where it does not -- queued by whoever reads the array first (ensure_status), and not at all
+  // when the call's first launch is tier 5 over the whole batch: that kernel takes every pair as PENDING and leaves every pair with
+  // a status.
+  bool status_unset = prepacked || fused_pack;
+  auto ensure_status = [&]() -> int {
+    if (status_unset) { HIP_TRY(hipMemsetAsync(c->status.p, 0, (size_t)4 * n, st)); status_unset = false; }
+    return 0;
+  };
+  // Inherited budgets: the array is filled (k_budget) by the first launch that needs it; tier 5 applies the rule itself.
+  struct { bool unset; int q, slack, margin; } budget_rule{false, 0, 0, 0};
+  unsigned long long cells_host = 0;      // cells of launches whose partial sums were added up on the host (run_list: a chain of one tier-5 launch)
+  hipEvent_t call_end = c->ev_end;        // the event that carries the end stamp of the call's last kernel
+  bool ct_clean = true;                   // no kernel of this call has written one of the device's counters yet (they are all zero)
+  // (all counters start a call as zero.  A call that ends well zeroes them behind its last read -- queued when the caller already has
+  // its results, executed while the host prepares the next call -- instead of in front of the next call's first kernel: a launch of
+  // ~3 us and the gap behind it, of a 150 us step of 100k short reads)
+  if (!c->counters_zeroed) HIP_TRY(hipMemsetAsync(c->counters.p, 0, CT_BYTES + 8 * 64, st));
+  c->counters_zeroed = false;
   c->ct_used = 0;
   // (ev_start -- the start of the call on the device -- is the start stamp of the FIRST kernel of the call, carried by its own dispatch
   // packet: the pack kernel, or the first wavefront launch.  A hipEventRecord is a barrier packet of its own: ~5 us in front of the
@@ -841,7 +883,10 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       const uint32_t n_chain = n_cur;
       struct Link { int tier; int ct_list; int ct_cells; hipEvent_t e0, e1; bool banded; bool budgeted; bool first_round; uint32_t n_in; bool walked; } link[2];
       int n_links = 0;
-      bool fused_tail = false; uint32_t* tail_out = nullptr; unsigned long long* tail_count = nullptr;
+      bool fused_tail = false; uint32_t* tail_out = nullptr; unsigned long long* tail_count = nullptr; unsigned long long* tail_parts_out = nullptr;
+      bool solo = false, solo_host = false; uint32_t parts_n = 0;      // (see the launch below)
+      const bool ct_clean_before = ct_clean;      // (no kernel of this call has written a counter so far)
+      ct_clean = false;
       long long s_hi = 0;                       // no pair of this chain finishes with a larger score
       const unsigned long long* cur_len_dev = nullptr;
       for (;;) {
@@ -902,8 +947,21 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
           ap.dbg_times = static_cast<unsigned long long*>(c->dbg.p); ap.dbg_cap = cap;
         }
         if (round == 0) { c->stats.lds_bytes_tier0 = tp.lds; c->stats.blocks_per_cu_tier0 = tp.blocks_per_cu; c->stats.waves_per_simd_tier0 = tp.wpe; }
+        ap.budget_q = 0;
+        if (ap.budget && budget_rule.unset) {
+          if (tp.tier == 5) { ap.budget = nullptr; ap.budget_q = budget_rule.q; ap.budget_slack = budget_rule.slack; ap.budget_margin = budget_rule.margin; }
+          else {
+            LAUNCH_K(k_budget, dim3(cdiv(n, 256)), dim3(256), 0, st, ap.meta, n, budget_rule.q, budget_rule.slack, budget_rule.margin, static_cast<int32_t*>(c->budget.p));
+            budget_rule.unset = false;
+          }
+        }
         ap.work = cur; ap.n_work = n_cur; ap.n_work_dev = cur_len_dev;
         ap.only_pending = (unfiltered && round == 0) ? 1 : 0;
+        if (status_unset) {
+          // (the call's first launch)
+          if (tp.tier == 5 && unfiltered && round == 0 && n_cur == n) { ap.only_pending = 0; status_unset = false; }
+          else if (ensure_status()) return -1;
+        }
         ap.launch_cells = ct + L.ct_cells;
         const int bpc_cap = c->tuning.max_blocks_per_cu > 0 ? c->tuning.max_blocks_per_cu : 1 << 20;     // (occupancy experiments)
         // (tier 5: 64 / lanes alignments per wavefront)
@@ -929,9 +987,31 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         if (cigar_now) ap.chunk_units = (uint32_t)std::min<unsigned long long>(4096u, std::max<unsigned long long>(256, ap.arena_units / (4ull * (unsigned)grid)));
         ap.work_shards = 8u;
         if (zero_counter(c, L.ct_cells, 2)) return -1;   // (the launch's cell count and, next to it, the length of its failure list)
+        uint32_t* nxt = spare[flip]; flip ^= 1;
+        // (the chain's ONLY launch -- nothing is enqueued behind it that needs its failure list on the device: the list is made by the
+        // chain's tail kernel together with the bounds and the count of unfinished pairs)
+        fused_tail = n_links == 0 && !(L.budgeted && speculate) && cur_len_dev == nullptr;
+        // Tier 5 keeps its cell count as one partial sum per wavefront; whoever runs behind the launch adds them up.  Where the launch
+        // is such a chain's only one, score-only, over the whole batch, NOTHING runs behind it: the kernel appends its failures to the
+        // next list itself and counts the pairs it does not finish, the partial sums come to the host with the counters (a tail
+        // kernel of 13 us + the gap in front of it, of a 135 us step of 100k configs[1] pairs).
+        // And where no kernel of this call has touched a counter yet (no pack kernel in front: the launch is the call's first kernel), the
+        // wavefronts store their partial sums straight into pinned host memory and the counter block is not copied at all: the chain is
+        // one kernel and a stream synchronisation.  (A 57 KB copy behind the kernel started 16 us after it had ended.)
+        ap.wave_parts = nullptr; ap.fail_list = nullptr; ap.fail_count = nullptr;
+        parts_n = 0; solo = false; solo_host = false;
+        if (tp.tier == 5 && grid > 0 && (size_t)grid <= CT_PARTS_PER_CU * (size_t)c->num_cus) {
+          ap.wave_parts = reinterpret_cast<unsigned long long*>(static_cast<char*>(c->counters.p) + CT_PARTS_OFF);
+          parts_n = (uint32_t)grid;
+          solo = fused_tail && !cigar_now && unfiltered && round == 0 && n_cur == n;
+          solo_host = solo && ct_clean_before && (prepacked || fused_pack) && !c->tuning.no_host_parts;
+          if (solo) { ap.fail_list = nxt; ap.fail_count = ct + L.ct_list; }
+          if (solo_host) ap.wave_parts = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->h_counters) + CT_PARTS_OFF);
+        }
         // (L.e0 / L.e1: start and end of the wavefront kernel, stamped by its own dispatch packet)
         if (tp.tier == 5) {
           wfa_launch_short(ap, tp.wpe, cigar_now, grid, st, L.e0, L.e1);
+          if (solo) call_end = L.e1;      // (the chain's last kernel)
           // (with CIGARs the launch owns n_cur slots above the bump pointer: move it past them for whatever allocates next)
           if (cigar_now) LAUNCH_K(k_bump, dim3(1), dim3(64), 0, st, ap.arena_top, (unsigned long long)n_cur * wfa_short_bt_slot_units(ap.max_score, tp.wpe), ap.arena_units);
         }
@@ -944,14 +1024,11 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
             return -1;
           }
         }
-        uint32_t* nxt = spare[flip]; flip ^= 1;
-        // (the chain's ONLY launch -- nothing is enqueued behind it that needs its failure list on the device: the list is made by the
-        // chain's tail kernel together with the bounds and the count of unfinished pairs)
-        fused_tail = n_links == 0 && !(L.budgeted && speculate) && cur_len_dev == nullptr;
-        tail_out = nxt; tail_count = ct + L.ct_list;
+        tail_out = nxt; tail_count = ct + L.ct_list; tail_parts_out = ct + L.ct_cells;
         if (!fused_tail)
           LAUNCH_K(k_compact, dim3(cdiv(n_cur, compact_block(n_cur))), dim3(compact_block(n_cur)), 0, st, (const uint32_t*)cur, n_cur, cur_len_dev,
-                             static_cast<const uint32_t*>(c->status.p), MASK(WFA_ST_BAND) | MASK(WFA_ST_SCORE), nxt, ct + L.ct_list, ap.work_counter);
+                             static_cast<const uint32_t*>(c->status.p), MASK(WFA_ST_BAND) | MASK(WFA_ST_SCORE), nxt, ct + L.ct_list, ap.work_counter,
+                             (const unsigned long long*)ap.wave_parts, parts_n, ct + L.ct_cells);
         s_hi = std::max<long long>(s_hi, L.banded ? std::min(max_error, 30000) : max_score);
         ++n_links; ++round;
         // what the failures of this round run with next
@@ -984,10 +1061,14 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       // (ev_end -- the end of the chain on the device -- is the end stamp of the chain's LAST kernel: this one in score-only calls,
       // the compaction of the NOMEM pairs behind the backtrace otherwise)
       const hipEvent_t ev_tail = cigar_now ? (hipEvent_t) nullptr : c->ev_end;
-      if (fused_tail)
+      if (!solo) call_end = c->ev_end;
+      if (solo) {
+        // (nothing: the launch did its own bookkeeping)
+      } else if (fused_tail)
         LAUNCH_K_END(k_chain_tail, dim3(std::min<uint32_t>(std::max(cdiv(n_chain, 2048), cdiv(n, 8192)), 256u)), dim3(256), 0, st, ev_tail, (const uint32_t*)chain_list, n_chain,
                                static_cast<const uint32_t*>(c->status.p), MASK(WFA_ST_BAND) | MASK(WFA_ST_SCORE), tail_out, tail_count, ap.work_counter,
-                               (const int32_t*)d_scores, static_cast<const uint32_t*>(c->cells.p), std::min(pen.x, pen.e), item_chars, ct, n);
+                               (const int32_t*)d_scores, static_cast<const uint32_t*>(c->cells.p), std::min(pen.x, pen.e), item_chars, ct, n,
+                               (const unsigned long long*)ap.wave_parts, parts_n, tail_parts_out);
       else
         LAUNCH_K_END(k_trace_bounds, dim3(std::min<uint32_t>(std::max(cdiv(n_chain, 2048), cdiv(n, 8192)), 256u)), dim3(256), 0, st, ev_tail, (const uint32_t*)chain_list, n_chain,
                                static_cast<const uint32_t*>(c->status.p), (const int32_t*)d_scores,
@@ -1118,13 +1199,32 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         HIP_TRY(hipGetLastError());
         // ---- pairs that ran out of arena go into the next pass (CIGAR calls only: score-only calls have no arena) ----
         LAUNCH_K_END(k_compact, dim3(cdiv(n_chain, compact_block(n_chain))), dim3(compact_block(n_chain)), 0, st, c->ev_end, (const uint32_t*)chain_list, n_chain, (const unsigned long long*)nullptr,
-                               static_cast<const uint32_t*>(c->status.p), MASK(WFA_ST_NOMEM), nxt_pending, ct + CT_NOMEM, (unsigned int*)nullptr);
+                               static_cast<const uint32_t*>(c->status.p), MASK(WFA_ST_NOMEM), nxt_pending, ct + CT_NOMEM, (unsigned int*)nullptr,
+                               (const unsigned long long*)nullptr, 0u, (unsigned long long*)nullptr);
       }
       // ---- the chain's one synchronisation --------------------------------------------------------------------------
       // (with it comes the number of pairs of the whole batch that are not finished yet: when this turns out to have been the
       // call's last chain, that IS the end-of-call check -- no launch and no round trip of its own)
       // (k_trace_bounds above counted them)
-      if (read_counters(c)) return -1;
+      if (solo_host) {
+        HIP_TRY(hipStreamSynchronize(st));
+        memset(c->h_counters, 0, CT_N * sizeof(unsigned long long));      // (what the device's counters held before the launch)
+      } else if (read_counters(c, solo ? parts_n : 0u)) return -1;
+      if (solo) {
+        // the launch's partial sums: cells (of the launch, and of the call: kept on the host, the device's counter never sees them), the
+        // pairs of the whole batch that are not finished, the length of the failure list, the pairs flagged for the byte-compare class
+        const unsigned long long* parts = reinterpret_cast<const unsigned long long*>(reinterpret_cast<const char*>(c->h_counters) + CT_PARTS_OFF);
+        unsigned long long sum[4] = {0, 0, 0, 0};
+        for (uint32_t i = 0; i < parts_n; ++i) for (int q = 0; q < 4; ++q) sum[q] += parts[4 * i + q];
+        c->h_counters[link[0].ct_cells] += sum[0];
+        cells_host += sum[0];
+        c->h_counters[CT_UNFIN] = sum[1];
+        if (solo_host) {
+          c->h_counters[link[0].ct_list] = sum[2]; c->h_counters[CT_NRAW] = sum[3];
+          // (the device's counters are as the call found them unless a pair failed or was flagged)
+          if (sum[2] == 0 && sum[3] == 0) ct_clean = true;
+        }
+      }
       unfinished_at_sync = (long long)c->h_counters[CT_UNFIN];
       uint32_t n_in = n_chain;
       for (int l = 0; l < n_links; ++l) {
@@ -1241,6 +1341,8 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       pending = nullptr;
     } else {
       if (zero_counter(c, CT_LIST)) return -1;
+      ct_clean = false;
+      if (ensure_status()) return -1;
       LAUNCH_K(k_compact_len, dim3(cdiv(n, 1024)), dim3(1024), 0, st, n, static_cast<const uint32_t*>(c->status.p), class_mask,
                          ap.meta, bucket_lo, bucket_hi, pending, ct + CT_LIST);
       if (read_counters(c)) return -1;
@@ -1286,7 +1388,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         const int q = c->saved_q[saved_idx].q;
         const int slack = budget_slack;
         if (c->budget.ensure((size_t)4 * n, st)) return -1;
-        LAUNCH_K(k_budget, dim3(cdiv(n, 256)), dim3(256), 0, st, ap.meta, n, q, slack, budget_margin, static_cast<int32_t*>(c->budget.p));
+        budget_rule = {true, q, slack, budget_margin};      // (filled by the first launch that reads it: run_list)
         budgets = static_cast<const int32_t*>(c->budget.p);
         budget_cap = (int)std::min<long long>(max_error, ((long long)q * max_len * budget_margin / 100) / 1024 + slack);
         c->stats.auto_budget = budget_cap;
@@ -1370,6 +1472,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       const unsigned missed_before = c->stats.pairs_budget_missed;
       const bool speculate = !(saved_idx >= 0 && c->saved_q[saved_idx].last_missed == 0);
       if (n_pending && run_list(pending, n_pending, raw, budgets, budget_cap, static_cast<uint32_t*>(c->list_d.p), bucket_list, use_band, speculate)) return -1;
+      budget_rule.unset = false;
       if (saved_idx >= 0) c->saved_q[saved_idx].last_missed = c->stats.pairs_budget_missed - missed_before;
       if (saved_idx >= 0 && (c->stats.pairs_budget_missed - missed_before) * 20u > n_pending) {
         // more than 5 % of the batch missed the inherited budgets: the stream has drifted, sample again next time
@@ -1389,6 +1492,8 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
     if (zero_counter(c, CT_UNFIN)) return -1;
     LAUNCH_K(k_count_unfinished, dim3(std::min<uint32_t>(cdiv(n, 1024), 1024u)), dim3(256), 0, st, n, static_cast<const uint32_t*>(c->status.p), ct + CT_UNFIN);
     HIP_TRY(hipEventRecord(c->ev_end, st));
+    call_end = c->ev_end;
+    ct_clean = false;
     if (read_counters(c)) return -1;
     unfinished_at_sync = (long long)c->h_counters[CT_UNFIN];
   }
@@ -1396,11 +1501,11 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
     fprintf(stderr, "[!] ERROR: %lld of %u alignments were left unfinished\n", unfinished_at_sync, n);
     return -1;
   }
-  c->stats.cells = c->h_counters[CT_CELLS] - sample_cells_call;
+  c->stats.cells = c->h_counters[CT_CELLS] + cells_host - sample_cells_call;
   float ms = 0.f;
   if (!prepacked && !fused_pack) HIP_TRY(hipEventElapsedTime(&ms, c->ev_start, c->ev_pack));
   c->stats.pack_ms = ms;
-  HIP_TRY(hipEventElapsedTime(&ms, c->ev_start, c->ev_end)); c->stats.total_ms = ms;
+  HIP_TRY(hipEventElapsedTime(&ms, c->ev_start, call_end)); c->stats.total_ms = ms;
   // several arena-bound passes under a growable cap: the next call may use twice the arena
   if (compute_cigar && c->arena_limit && c->arena_limit_max > c->arena_limit && c->stats.sub_batches > 1 &&
       c->arena.cap >= c->arena_limit - ((size_t)1 << 20))
@@ -1417,5 +1522,6 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
     if (d_len) *d_len = static_cast<const unsigned int*>(c->cig_len[c->out_set].p);
     c->out_set ^= 1;      // (the next call writes the other set)
   }
+  if (rc == 0 && (ct_clean || hipMemsetAsync(c->counters.p, 0, CT_BYTES + 8 * 64, st) == hipSuccess)) c->counters_zeroed = true;
   return rc;
 }

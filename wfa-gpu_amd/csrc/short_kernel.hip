@@ -59,8 +59,12 @@ template <int L> __device__ __forceinline__ int from_above(int v, int j) {
 // launch of 100k configs[1] pairs was 18 us + the gap between two launches of a 168 us step; here it is ~80 vector instructions per
 // iteration in a kernel whose vector pipe is half idle.)  A pair with a byte outside ACGT leaves with status ALPHABET like in the
 // wavefront kernels that pack while staging (align_kernel.hip).
+// (register budget: the CIGAR variants came out one and three registers above a step of the occupancy table -- 81 and 99 for x, o, e =
+// 2, 3, 1 -- and are compiled for the step below: 1M configs[1] pairs with CIGARs 1.096 -> 1.045 ms per step, 100k the same; the
+// score-only variants sit on their steps, 72 and 80, by themselves)
 template <int L, int X, int OE, bool BT, bool ASCII>
-__global__ void __launch_bounds__(64) wfa_short_kernel(const WfaAlignParams p) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(BT ? (ASCII ? 5 : 6) : 1, 8)))
+wfa_short_kernel(const WfaAlignParams p) {
   static_assert(X >= 1 && X <= 8 && OE >= 1 && OE <= 8, "history of eight scores");
   constexpr int D = X > OE ? X : OE;
   extern __shared__ __attribute__((aligned(16))) uint32_t slds[];
@@ -79,10 +83,23 @@ __global__ void __launch_bounds__(64) wfa_short_kernel(const WfaAlignParams p) {
   uint32_t n_work = p.n_work;
   if (p.n_work_dev) n_work = min(n_work, (uint32_t)*p.n_work_dev);
   const unsigned long long grp_mask = (L == 64) ? ~0ull : (((1ull << L) - 1ull) << (grp * L));
-  unsigned long long blk_cells = 0;
-  uint32_t not_done = 0, n_fail = 0, n_flag = 0;            // (group leaders: pairs of this wavefront's share that did not leave DONE / went to fail_list / were flagged ALPHABET)
+  uint32_t lane_rows = 0;                                   // (group leaders: rows -- score + 1 -- of the alignments they finished; x L = cells)
+  // pairs of this wavefront's share that did not leave DONE / went to fail_list / were flagged ALPHABET: wave-uniform counts (scalar
+  // registers: the kernel's vector registers decide how many wavefronts a SIMD holds)
+  uint32_t not_done = 0, n_fail = 0, n_flag = 0;
+  auto count_of = [](const bool pred) { return (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(pred)); };
   unsigned long long arena_top0 = 0;                        // (the bump pointer as the launch found it: nobody moves it while the launch runs)
-  if constexpr (BT) arena_top0 = *p.arena_top;
+  if constexpr (BT) {
+    if (p.arena_top_known) {
+      // (nobody reads the bump pointer while the launch runs: workgroup 0 moves it past the launch's slots, never beyond the arena)
+      arena_top0 = p.arena_top0_value;
+      if (blockIdx.x == 0 && lane == 0) {
+        const uint32_t tab_units = (uint32_t)(((long long)p.max_score + 2) >> 1), slot = tab_units + (uint32_t)(p.max_score + 1) * (L / 16);
+        const unsigned long long t = arena_top0 + (unsigned long long)n_work * slot;
+        *p.arena_top = t < p.arena_units ? t : p.arena_units;
+      }
+    } else arena_top0 = *p.arena_top;
+  }
 
   // Software pipeline over the iterations of a wavefront.  All wavefronts of a launch start together, do the same amount of work
   // and so stay in step: with the loads of an iteration issued when it starts -- work item -> record and status -> sequences,
@@ -107,7 +124,8 @@ __global__ void __launch_bounds__(64) wfa_short_kernel(const WfaAlignParams p) {
     m.st = p.only_pending ? p.status[pair] : (uint32_t)WFA_ST_PENDING;
     const WfaSeqPair mp = p.meta[pair];
     m.plen = (int)mp.pattern_len; m.tlen = (int)mp.text_len;
-    m.poff = (uint32_t)(mp.pattern_offset_packed >> 2); m.toff = (uint32_t)(mp.text_offset_packed >> 2);
+    // (the packed words: read, or -- ASCII, CIGAR launches -- written)
+    m.poff = (ASCII && !BT) ? 0u : (uint32_t)(mp.pattern_offset_packed >> 2); m.toff = (ASCII && !BT) ? 0u : (uint32_t)(mp.text_offset_packed >> 2);
     m.pasc = ASCII ? (uint32_t)(mp.pattern_offset >> 2) : 0u; m.tasc = ASCII ? (uint32_t)(mp.text_offset >> 2) : 0u;
     if (p.budget) m.budget = p.budget[pair];
     else if (p.budget_q > 0) {
@@ -153,23 +171,26 @@ __global__ void __launch_bounds__(64) wfa_short_kernel(const WfaAlignParams p) {
       uint32_t bad = 0;
       const uint32_t* const ps = m.plen ? asc + m.pasc : reinterpret_cast<const uint32_t*>(p.meta);
       const uint32_t* const ts = m.tlen ? asc + m.tasc : reinterpret_cast<const uint32_t*>(p.meta);
-      if (j < pw) { const uint32_t w = wfa_pack::pack_word(wfa_pack::PackWord{r.a[0], r.a[1], r.a[2], r.a[3]}, (uint32_t)m.plen, (uint32_t)j, bad); Pb[j] = w; packed_out[(size_t)m.poff + j] = w; }
-      if (j < tw) { const uint32_t w = wfa_pack::pack_word(wfa_pack::PackWord{r.b[0], r.b[1], r.b[2], r.b[3]}, (uint32_t)m.tlen, (uint32_t)j, bad); Tb[j] = w; packed_out[(size_t)m.toff + j] = w; }
+      // (the words go to the packed buffer as well where a backtrace kernel will look for them: CIGAR launches.  A pair that leaves a
+      // score-only launch unfinished is packed again by the kernel that takes it over.)
+      if (j < pw) { const uint32_t w = wfa_pack::pack_word(wfa_pack::PackWord{r.a[0], r.a[1], r.a[2], r.a[3]}, (uint32_t)m.plen, (uint32_t)j, bad); Pb[j] = w; if constexpr (BT) packed_out[(size_t)m.poff + j] = w; }
+      if (j < tw) { const uint32_t w = wfa_pack::pack_word(wfa_pack::PackWord{r.b[0], r.b[1], r.b[2], r.b[3]}, (uint32_t)m.tlen, (uint32_t)j, bad); Tb[j] = w; if constexpr (BT) packed_out[(size_t)m.toff + j] = w; }
 #pragma nounroll
-      for (int i = j + L; i < pw; i += L) { const uint32_t w = wfa_pack::pack_word(wfa_pack::load_word(ps, (uint32_t)m.plen, (uint32_t)i), (uint32_t)m.plen, (uint32_t)i, bad); Pb[i] = w; packed_out[(size_t)m.poff + i] = w; }
+      for (int i = j + L; i < pw; i += L) { const uint32_t w = wfa_pack::pack_word(wfa_pack::load_word(ps, (uint32_t)m.plen, (uint32_t)i), (uint32_t)m.plen, (uint32_t)i, bad); Pb[i] = w; if constexpr (BT) packed_out[(size_t)m.poff + i] = w; }
 #pragma nounroll
-      for (int i = j + L; i < tw; i += L) { const uint32_t w = wfa_pack::pack_word(wfa_pack::load_word(ts, (uint32_t)m.tlen, (uint32_t)i), (uint32_t)m.tlen, (uint32_t)i, bad); Tb[i] = w; packed_out[(size_t)m.toff + i] = w; }
-      if ((__builtin_amdgcn_ballot_w64(bad != 0u) & grp_mask) != 0ull) {
+      for (int i = j + L; i < tw; i += L) { const uint32_t w = wfa_pack::pack_word(wfa_pack::load_word(ts, (uint32_t)m.tlen, (uint32_t)i), (uint32_t)m.tlen, (uint32_t)i, bad); Tb[i] = w; if constexpr (BT) packed_out[(size_t)m.toff + i] = w; }
+      const bool flagged = (__builtin_amdgcn_ballot_w64(bad != 0u) & grp_mask) != 0ull;
+      if (flagged) {
         // WFA2 compares raw bytes: this pair belongs to the byte-compare class, which runs after the packed one
         if (j == 0) {
           atomicAdd(p.n_raw, 1ull);
           p.score[m.pair] = -1;
           p.status[m.pair] = WFA_ST_ALPHABET;
           if (p.cells) p.cells[m.pair] = 0;
-          ++n_flag;
         }
         m.st = WFA_ST_ALPHABET;
       }
+      n_flag += count_of(flagged && j == 0);
       return;
     }
 #pragma unroll
@@ -367,19 +388,23 @@ __global__ void __launch_bounds__(64) wfa_short_kernel(const WfaAlignParams p) {
       p.status[pair] = status;
       const uint32_t cells = (status == WFA_ST_DONE) ? (uint32_t)(max(score, 0) + 1) * (uint32_t)L : 0u;
       if (p.cells) p.cells[pair] = cells;
-      blk_cells += cells;
-      if (p.fail_list && (status == WFA_ST_BAND || status == WFA_ST_SCORE)) { p.fail_list[atomicAdd(p.fail_count, 1ull)] = pair; ++n_fail; }      // (rare)
+      lane_rows += (status == WFA_ST_DONE) ? (uint32_t)(max(score, 0) + 1) : 0u;
     }
-    if (j == 0 && w < n_work && !(active && status == WFA_ST_DONE)) ++not_done;      // (skipped pairs -- another class's -- included)
+    {
+      const bool failed = active && j == 0 && p.fail_list && (status == WFA_ST_BAND || status == WFA_ST_SCORE);
+      if (failed) p.fail_list[atomicAdd(p.fail_count, 1ull)] = pair;      // (rare)
+      n_fail += count_of(failed);
+      not_done += count_of(j == 0 && w < n_work && !(active && status == WFA_ST_DONE));      // (skipped pairs -- another class's -- included)
+    }
     // ---- everything moves up one stage
     m0 = m1; m1 = m2; pair2 = pair3;
     { uint32_t* const t = Pw; Pw = Pn; Pn = t; }
     __builtin_amdgcn_wave_barrier();
   }
   // cells of this wavefront (the group leaders counted theirs)
-  for (int d = 32; d > 0; d >>= 1) {
-    blk_cells += __shfl_down(blk_cells, d); not_done += __shfl_down(not_done, d); n_fail += __shfl_down(n_fail, d); n_flag += __shfl_down(n_flag, d);
-  }
+  unsigned long long blk_cells = lane_rows;
+  for (int d = 32; d > 0; d >>= 1) blk_cells += __shfl_down(blk_cells, d);
+  blk_cells *= (unsigned)L;
   if (lane == 0) {
     if (p.wave_parts) {
       ulonglong4* const out = reinterpret_cast<ulonglong4*>(p.wave_parts) + blockIdx.x;

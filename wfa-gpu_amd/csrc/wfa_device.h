@@ -101,6 +101,8 @@ struct WfaAlignParams {
   unsigned long long* wave_parts;
   uint32_t* fail_list;
   unsigned long long* fail_count;
+  int arena_top_known;           // tier 5 with CIGARs: 1 = the bump pointer is arena_top0_value when the launch starts (the host knows: a pass's first
+  unsigned long long arena_top0_value;   // launch) -- the launch moves it past its slots itself (workgroup 0) instead of a one-thread kernel behind it
   // backtrace (CIGAR mode)
   uint8_t* arena;                // base of the arena
   unsigned long long arena_units;        // capacity in 16-byte units

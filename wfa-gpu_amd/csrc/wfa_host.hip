@@ -884,7 +884,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       struct Link { int tier; int ct_list; int ct_cells; hipEvent_t e0, e1; bool banded; bool budgeted; bool first_round; uint32_t n_in; bool walked; } link[2];
       int n_links = 0;
       bool fused_tail = false; uint32_t* tail_out = nullptr; unsigned long long* tail_count = nullptr; unsigned long long* tail_parts_out = nullptr;
-      bool solo = false, solo_host = false; uint32_t parts_n = 0;      // (see the launch below)
+      bool solo = false, parts_on_host = false, skip_read = false; uint32_t parts_n = 0;      // (see the launch below)
       const bool ct_clean_before = ct_clean;      // (no kernel of this call has written a counter so far)
       ct_clean = false;
       long long s_hi = 0;                       // no pair of this chain finishes with a larger score
@@ -998,22 +998,28 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         // And where no kernel of this call has touched a counter yet (no pack kernel in front: the launch is the call's first kernel), the
         // wavefronts store their partial sums straight into pinned host memory and the counter block is not copied at all: the chain is
         // one kernel and a stream synchronisation.  (A 57 KB copy behind the kernel started 16 us after it had ended.)
-        ap.wave_parts = nullptr; ap.fail_list = nullptr; ap.fail_count = nullptr;
-        parts_n = 0; solo = false; solo_host = false;
+        // With CIGARs the backtrace follows the launch; the kernel between them (failure list, bounds, unfinished count: 16 us for 100k
+        // pairs, + the one-thread kernel that moved the arena's bump pointer) goes the same way: the bounds of the scratch come from
+        // the chain's budget (by_bound, below).
+        ap.wave_parts = nullptr; ap.fail_list = nullptr; ap.fail_count = nullptr; ap.arena_top_known = 0; ap.arena_top0_value = 0;
+        parts_n = 0; solo = false; parts_on_host = false; skip_read = false;
         if (tp.tier == 5 && grid > 0 && (size_t)grid <= CT_PARTS_PER_CU * (size_t)c->num_cus) {
           ap.wave_parts = reinterpret_cast<unsigned long long*>(static_cast<char*>(c->counters.p) + CT_PARTS_OFF);
           parts_n = (uint32_t)grid;
-          solo = fused_tail && !cigar_now && unfiltered && round == 0 && n_cur == n;
-          solo_host = solo && ct_clean_before && (prepacked || fused_pack) && !c->tuning.no_host_parts;
+          solo = fused_tail && unfiltered && round == 0 && n_cur == n;
+          parts_on_host = solo && !c->tuning.no_host_parts;
+          skip_read = parts_on_host && !cigar_now && ct_clean_before && (prepacked || fused_pack);
           if (solo) { ap.fail_list = nxt; ap.fail_count = ct + L.ct_list; }
-          if (solo_host) ap.wave_parts = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->h_counters) + CT_PARTS_OFF);
+          if (parts_on_host) ap.wave_parts = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(c->h_counters) + CT_PARTS_OFF);
         }
+        // (a pass's first launch finds the arena's bump pointer at zero: zero_counter(CT_ARENA) above)
+        if (tp.tier == 5 && cigar_now && round == 0) { ap.arena_top_known = 1; ap.arena_top0_value = 0; }
         // (L.e0 / L.e1: start and end of the wavefront kernel, stamped by its own dispatch packet)
         if (tp.tier == 5) {
           wfa_launch_short(ap, tp.wpe, cigar_now, grid, st, L.e0, L.e1);
-          if (solo) call_end = L.e1;      // (the chain's last kernel)
+          if (solo && !cigar_now) call_end = L.e1;      // (the chain's last kernel)
           // (with CIGARs the launch owns n_cur slots above the bump pointer: move it past them for whatever allocates next)
-          if (cigar_now) LAUNCH_K(k_bump, dim3(1), dim3(64), 0, st, ap.arena_top, (unsigned long long)n_cur * wfa_short_bt_slot_units(ap.max_score, tp.wpe), ap.arena_units);
+          if (cigar_now && !ap.arena_top_known) LAUNCH_K(k_bump, dim3(1), dim3(64), 0, st, ap.arena_top, (unsigned long long)n_cur * wfa_short_bt_slot_units(ap.max_score, tp.wpe), ap.arena_units);
         }
         else wfa_launch_align(ap, tp.tier, cigar_now, raw, grid, st, tp.wpe, L.e0, L.e1);
         {
@@ -1061,7 +1067,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       // (ev_end -- the end of the chain on the device -- is the end stamp of the chain's LAST kernel: this one in score-only calls,
       // the compaction of the NOMEM pairs behind the backtrace otherwise)
       const hipEvent_t ev_tail = cigar_now ? (hipEvent_t) nullptr : c->ev_end;
-      if (!solo) call_end = c->ev_end;
+      if (!(solo && !cigar_now)) call_end = c->ev_end;
       if (solo) {
         // (nothing: the launch did its own bookkeeping)
       } else if (fused_tail)
@@ -1108,6 +1114,10 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         unsigned long long ops_need, text_sum;
         if (by_bound) { ops_need = ops_bound + 256; text_sum = text_bound; }
         else {
+          // (a chain without a tail kernel: nobody has formed the sums yet.  Cells and the unfinished count stay with the launch's
+          // partial sums)
+          if (solo) LAUNCH_K(k_trace_bounds, dim3(std::min<uint32_t>(std::max(cdiv(n_chain, 2048), 1u), 256u)), dim3(256), 0, st, (const uint32_t*)chain_list, n_chain,
+                             static_cast<const uint32_t*>(c->status.p), (const int32_t*)d_scores, static_cast<const uint32_t*>(nullptr), std::min(pen.x, pen.e), item_chars, ct, 0u);
           if (read_counters(c)) return -1;
           ops_need = c->h_counters[CT_SUM_OPS] + 256; text_sum = c->h_counters[CT_SUM_TEXT];
         }
@@ -1206,10 +1216,10 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
       // (with it comes the number of pairs of the whole batch that are not finished yet: when this turns out to have been the
       // call's last chain, that IS the end-of-call check -- no launch and no round trip of its own)
       // (k_trace_bounds above counted them)
-      if (solo_host) {
+      if (skip_read) {
         HIP_TRY(hipStreamSynchronize(st));
         memset(c->h_counters, 0, CT_N * sizeof(unsigned long long));      // (what the device's counters held before the launch)
-      } else if (read_counters(c, solo ? parts_n : 0u)) return -1;
+      } else if (read_counters(c, (solo && !parts_on_host) ? parts_n : 0u)) return -1;
       if (solo) {
         // the launch's partial sums: cells (of the launch, and of the call: kept on the host, the device's counter never sees them), the
         // pairs of the whole batch that are not finished, the length of the failure list, the pairs flagged for the byte-compare class
@@ -1219,7 +1229,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         c->h_counters[link[0].ct_cells] += sum[0];
         cells_host += sum[0];
         c->h_counters[CT_UNFIN] = sum[1];
-        if (solo_host) {
+        if (skip_read) {
           c->h_counters[link[0].ct_list] = sum[2]; c->h_counters[CT_NRAW] = sum[3];
           // (the device's counters are as the call found them unless a pair failed or was flagged)
           if (sum[2] == 0 && sum[3] == 0) ct_clean = true;

@@ -56,6 +56,8 @@ typedef struct {
                               launch store its partial sums (cells, unfinished / failed / flagged pairs per wavefront) straight into
                               pinned host memory -- one kernel and a stream synchronisation per call --; 1: they stay on the device and
                               come over with the counter block (a copy behind the kernel)                                           */
+    int short_iterations;  /* tier 5: iterations (groups of 4 / 2 alignments) a wavefront of a launch runs at least, where the list allows
+                              it and four wavefronts per CU remain (0: default)                                                      */
     int emit_pairs;        /* lane-per-alignment CIGAR replay with the sequences staged in LDS: alignments per wavefront
                               (8..64; 0: automatic -- as many as keep the most lanes resident per CU)                          */
 } wfagpu_amd_tuning_t;

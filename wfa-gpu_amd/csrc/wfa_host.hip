@@ -975,7 +975,8 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         // never fewer than four wavefronts per CU (100k pairs: 28 / 20 / 14 / 10 wavefronts per CU = 4 / 5 / 7 / 10 iterations:
         // 0.106 / 0.101 / 0.092 / 0.095 ms; 1M pairs, 35 iterations at full residency: 0.508 ms, 0.619 at 20 per CU).
         if (tp.tier == 5 && grid > 0) {
-          if (c->tuning.max_blocks_per_cu <= 0) grid = std::min(grid, (int)std::max<uint32_t>(units / 7u, 4u * (uint32_t)c->num_cus));
+          const uint32_t iters = c->tuning.short_iterations > 0 ? (uint32_t)c->tuning.short_iterations : 7u;
+          if (c->tuning.max_blocks_per_cu <= 0) grid = std::min(grid, (int)std::max<uint32_t>(units / iters, 4u * (uint32_t)c->num_cus));
           grid = (int)cdiv(units, cdiv(units, (uint32_t)std::max(grid, 1)));
         }
         // (a speculative re-run works on a list whose length only the device knows yet -- a percent of the chain's pairs,

@@ -435,12 +435,23 @@ __device__ __forceinline__ void stage_pairs(const WfaTraceParams& p, const int P
 // replays it again straight into it.  Against walk + emit + compaction: no op list and no text scratch in global memory, one
 // allocation instead of three (every one of them a returning atomic per wavefront on one counter: ~11 ns each, 17 us per
 // 100k-pair kernel just for those), one launch instead of three.
+// Workgroups of LANE_WAVES wavefronts, each with its own pairs and its own share of LDS: what they share is the allocation of their
+// texts (block_alloc: one returning atomic per workgroup -- the 1563 wavefronts of a 100k-pair launch, all at that point within
+// microseconds of each other, queued ~11 ns each for the one counter: configs[1] with CIGARs, backtrace 0.049 -> 0.037 ms.  The same
+// for wfa_emit_kernel, whose wavefronts come by in rounds, changed nothing: 1M x 1 kbp pairs 3.05 / 3.07 ms.)
+constexpr int LANE_WAVES = 4;
+__host__ __device__ inline size_t lane_kernel_wave_bytes(int emit_pairs, int seq_lds_stride, int ops_lds_bytes) {
+  return ((size_t)emit_pairs * seq_lds_stride * 4 + (size_t)emit_pairs * ops_lds_bytes + (size_t)64 * 9 * 8 + 15) & ~(size_t)15;
+}
 template <bool RAW>
-__global__ void __launch_bounds__(TRACE_THREADS) wfa_trace_lane_kernel(const WfaTraceParams p) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t seq_lds[];
+__global__ void __launch_bounds__(LANE_WAVES * 64) wfa_trace_lane_kernel(const WfaTraceParams p) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lane_lds[];
+  __shared__ uint32_t wave_total[LANE_WAVES];
+  __shared__ unsigned long long block_base;
   const int PPW = p.emit_pairs;
-  const int lane = threadIdx.x & 63;
-  const uint32_t gid = blockIdx.x * (uint32_t)PPW + (uint32_t)lane;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint32_t* const seq_lds = lane_lds + (size_t)wv * (lane_kernel_wave_bytes(PPW, p.seq_lds_stride, p.ops_lds_bytes) >> 2);
+  const uint32_t gid = (blockIdx.x * (uint32_t)LANE_WAVES + (uint32_t)wv) * (uint32_t)PPW + (uint32_t)lane;
   uint8_t* const ops_lds = reinterpret_cast<uint8_t*>(seq_lds + (size_t)PPW * p.seq_lds_stride);
   uint2* const tab_cache = reinterpret_cast<uint2*>(ops_lds + (size_t)PPW * p.ops_lds_bytes);      // [lane][9]
   bool active = lane < PPW && gid < p.n_work;
@@ -469,7 +480,7 @@ __global__ void __launch_bounds__(TRACE_THREADS) wfa_trace_lane_kernel(const Wfa
     if (len == 0xFFFFFFFFu) fail = true;
   }
   const uint32_t need_txt = (active && !fail) ? len + 1u : 0u;
-  const unsigned long long txt_off = wave_alloc(p.text_top, need_txt, lane);
+  const unsigned long long txt_off = block_alloc<LANE_WAVES>(p.text_top, need_txt, wave_total, &block_base);
   if (active && !fail && txt_off + need_txt > p.text_cap) fail = true;
   if (active) {
     if (!fail) {
@@ -922,8 +933,8 @@ __global__ void __launch_bounds__(TRACE_THREADS) wfa_trace_group_kernel(const Wf
     }
     len = __shfl(len, lead);
     if (active && !fail && len == 0xFFFFFFFFu) fail = true;
-    unsigned long long txt_off = 0;
-    if (active && !fail && sub == 0) txt_off = atomicAdd(p.text_top, (unsigned long long)len + 1ull);
+    // (one returning atomic per wavefront for the texts of its G alignments)
+    unsigned long long txt_off = wave_alloc(p.text_top, (active && !fail && sub == 0) ? len + 1u : 0u, lane);
     txt_off = shfl64(txt_off, lead);
     if (active && !fail && txt_off + len + 1 > p.text_cap) fail = true;
     if (active && !fail) {
@@ -1018,11 +1029,12 @@ bool wfa_launch_trace(const WfaTraceParams& p, hipStream_t stream, hipEvent_t ev
   if (p.lane_fused) {
     // short alignments: walk + both replays in one kernel, op lists in LDS (sequences, then ops_lds_bytes per lane, then 72 bytes of
     // row-table cache per lane)
-    const size_t lds = (size_t)p.emit_pairs * p.seq_lds_stride * 4 + (size_t)p.emit_pairs * p.ops_lds_bytes + (size_t)64 * 9 * 8;
-    const dim3 grid_f((p.n_work + (uint32_t)p.emit_pairs - 1) / (uint32_t)p.emit_pairs);
+    const size_t lds = (size_t)LANE_WAVES * lane_kernel_wave_bytes(p.emit_pairs, p.seq_lds_stride, p.ops_lds_bytes);
+    const uint32_t per_block = (uint32_t)LANE_WAVES * (uint32_t)p.emit_pairs;
+    const dim3 grid_f((p.n_work + per_block - 1) / per_block), block_f(LANE_WAVES * 64);
     static thread_local size_t allowed[2][16] = {{0}};
-    if (p.raw) { allow_lds(wfa_trace_lane_kernel<true>, lds, allowed[1]); wfa_launch_timed(wfa_trace_lane_kernel<true>, grid_f, block, lds, stream, ev0, ev1, p); }
-    else { allow_lds(wfa_trace_lane_kernel<false>, lds, allowed[0]); wfa_launch_timed(wfa_trace_lane_kernel<false>, grid_f, block, lds, stream, ev0, ev1, p); }
+    if (p.raw) { allow_lds(wfa_trace_lane_kernel<true>, lds, allowed[1]); wfa_launch_timed(wfa_trace_lane_kernel<true>, grid_f, block_f, lds, stream, ev0, ev1, p); }
+    else { allow_lds(wfa_trace_lane_kernel<false>, lds, allowed[0]); wfa_launch_timed(wfa_trace_lane_kernel<false>, grid_f, block_f, lds, stream, ev0, ev1, p); }
     return true;
   }
   uint32_t walk_grid = (p.n_work + WALK_WAVES * 64 - 1) / (WALK_WAVES * 64);

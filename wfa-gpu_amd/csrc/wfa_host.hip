@@ -969,13 +969,13 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         int grid = (int)std::min<uint32_t>(std::min<uint32_t>(units, grid_cap), (uint32_t)(c->num_cus * std::min(tp.blocks_per_cu, bpc_cap)));
         // (tier 5 hands its work out by a grid-stride loop over items of equal cost: a grid that is not resident as a whole, or whose
         // wavefronts do not all run the same number of iterations, ends in a tail -- 100k configs[1] pairs = 25 000 items on 8192
-        // wavefronts of which 7168 were resident: six rounds of iterations for 3.5 rounds of work)
-        // Every wavefront also pays for filling its pipeline (three dependent round trips before its first iteration): with four
-        // iterations each that was a third of the launch.  At least seven iterations per wavefront where the list allows it, but
-        // never fewer than four wavefronts per CU (100k pairs: 28 / 20 / 14 / 10 wavefronts per CU = 4 / 5 / 7 / 10 iterations:
-        // 0.106 / 0.101 / 0.092 / 0.095 ms; 1M pairs, 35 iterations at full residency: 0.508 ms, 0.619 at 20 per CU).
+        // wavefronts of which 7168 were resident: six rounds of iterations for 3.5 rounds of work.  So: as many wavefronts as are
+        // resident, the iterations evened out.  Through round 4 a wavefront also ran at least seven iterations -- fewer, longer-lived
+        // wavefronts measured faster: what they saved was the atomic every wavefront ended with on the call's counter line, not the
+        // filling of their pipelines.  With the partial sums stored instead (WfaAlignParams::wave_parts), 100k pairs: 7 iterations 0.089
+        // ms, 5 (all that is resident) 0.0715; 50k: 0.064 -> 0.0445; 20k: 0.039 -> 0.022; 250k and more: the same.)
         if (tp.tier == 5 && grid > 0) {
-          const uint32_t iters = c->tuning.short_iterations > 0 ? (uint32_t)c->tuning.short_iterations : 7u;
+          const uint32_t iters = c->tuning.short_iterations > 0 ? (uint32_t)c->tuning.short_iterations : 1u;
           if (c->tuning.max_blocks_per_cu <= 0) grid = std::min(grid, (int)std::max<uint32_t>(units / iters, 4u * (uint32_t)c->num_cus));
           grid = (int)cdiv(units, cdiv(units, (uint32_t)std::max(grid, 1)));
         }
@@ -1179,6 +1179,8 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
             tp.emit_pairs = 64;
             while (tp.emit_pairs > 16 && c->lds_per_block_max / ((size_t)tp.emit_pairs * (stride * 4 + (size_t)tp.ops_lds_bytes) + 64 * 72) < 8) tp.emit_pairs -= 8;
           }
+          // (the kernel's workgroups are four wavefronts with a share of LDS each: trace_kernel.hip, LANE_WAVES)
+          while (tp.emit_pairs > 8 && 4 * ((size_t)tp.emit_pairs * (stride * 4 + (size_t)tp.ops_lds_bytes) + 64 * 72 + 16) > c->lds_per_block_max) tp.emit_pairs -= 8;
         }
         tp.packed = ap.packed; tp.meta = ap.meta; tp.work = chain_list; tp.n_work = n_chain;
         tp.x = pen.x; tp.oe = oe; tp.e = pen.e;

@@ -511,10 +511,15 @@ int run_device(const CallArgs& a, Shard& sh) {
   const unsigned pack_threads = a.cfg.host_pack_threads > 0 ? (unsigned)a.cfg.host_pack_threads
                                                             : std::max(2u, std::min(12u, sh.host_threads * 3u / 4u));
   const unsigned prep_threads = host_pack ? pack_threads : std::max(1u, std::min(8u, sh.host_threads / 2u));
-  if (bs == n_all && big) {
+  // (a call that is not big but not tiny either -- BASELINE configs[1]: 100k x 150 bp, 31 MB -- still gains from three or four batches:
+  // record sweep, upload, kernels and scatter of ONE batch are a chain of 0.45 + 0.7 + 0.1 + 0.15 ms, cut in four the upload of a batch
+  // runs under the sweep of the next: 1.46 -> 1.14 ms host to host, with CIGARs 1.87 -> 1.7 at three; more batches lose again)
+  const bool mid = !big && n_all >= ((size_t)1 << 15) && slice_bytes >= ((size_t)8 << 20);
+  if (bs == n_all && (big || mid || a.cfg.batches_per_device > 1)) {
     // (few long pairs: batches of >= 32 MB and >= 8192 pairs -- smaller ones tune no score budgets, csrc/wfa_host.hip, and
     // run twice as long: 16k x 10 kbp pairs, host to host: one batch 25.1 ms, two 22.0, four 43.7)
     const size_t cut = a.cfg.batches_per_device > 0 ? (size_t)a.cfg.batches_per_device
+                     : mid ? (a.cigar ? 3 : 4)
                      : n_all >= ((size_t)1 << 17) ? 16 : std::max<size_t>(1, std::min<size_t>(16, std::min(slice_bytes >> 25, n_all >> 13)));
     bs = (n_all + cut - 1) / cut;
     add_batches(sh.from, sh.to, bs);

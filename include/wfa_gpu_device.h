@@ -58,6 +58,8 @@ typedef struct {
                               come over with the counter block (a copy behind the kernel)                                           */
     int short_iterations;  /* tier 5: iterations (groups of 4 / 2 alignments) a wavefront of a launch runs at least, where the list allows
                               it and four wavefronts per CU remain (0: default)                                                      */
+    int arena_chunk_cap;   /* A/B: largest refill (16-byte units) a workgroup takes from the backtrace arena at a time (0: default, 262144 =
+                              4 MiB; through round 4: 4096)                                                                        */
     int emit_pairs;        /* lane-per-alignment CIGAR replay with the sequences staged in LDS: alignments per wavefront
                               (8..64; 0: automatic -- as many as keep the most lanes resident per CU)                          */
 } wfagpu_amd_tuning_t;

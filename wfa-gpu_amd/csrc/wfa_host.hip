@@ -985,7 +985,14 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         // arena refill size: as large as lets every workgroup hold a few chunks -- each refill is a
         // returning atomic on ONE word (~88 per microsecond on this chip), which at 4 KiB refills
         // was the whole kernel time
-        if (cigar_now) ap.chunk_units = (uint32_t)std::min<unsigned long long>(4096u, std::max<unsigned long long>(256, ap.arena_units / (4ull * (unsigned)grid)));
+        // (a refill stalls the whole workgroup for the atomic's round trip, ~2.5 us: at 64 KiB a time -- the cap through round 4 -- an
+        // alignment of BASELINE configs[4], 45 MB of origin bytes in rows of up to 13 KB, refilled 700 times, every fifth score, with
+        // the CU's only workgroup waiting.  Now: a sixteenth of the arena over the launch's workgroups -- what the launch can
+        // strand in unfinished chunks at its end --, at most 4 MiB.)
+        if (cigar_now) {
+          const unsigned long long cap = c->tuning.arena_chunk_cap > 0 ? (unsigned long long)c->tuning.arena_chunk_cap : 262144ull;
+          ap.chunk_units = (uint32_t)std::min<unsigned long long>(cap, std::max<unsigned long long>(256, ap.arena_units / ((cap > 4096 ? 16ull : 4ull) * (unsigned)grid)));
+        }
         ap.work_shards = 8u;
         if (zero_counter(c, L.ct_cells, 2)) return -1;   // (the launch's cell count and, next to it, the length of its failure list)
         uint32_t* nxt = spare[flip]; flip ^= 1;

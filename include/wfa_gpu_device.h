@@ -79,7 +79,7 @@ typedef struct {
 
 typedef struct {
     const char* d_sequences;             /* device: ASCII buffer, reference layout       */
-    size_t sequences_bytes;
+    size_t sequences_bytes;              /* size of the ASCII buffer (tier 5 indexes it by 32-bit dwords below 16 GiB; 0: judged by packed_bytes) */
     const sequence_pair_t* d_metadata;   /* device: packed offsets filled (see below)    */
     size_t num_pairs;
     size_t packed_bytes;                 /* value returned by wfagpu_amd_fill_packed_offsets */

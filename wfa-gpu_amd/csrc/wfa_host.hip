@@ -791,7 +791,8 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   // kernel in front of the first wavefront launch (0.63 ms per 1M x 1 kbp pairs).  Short reads too where tier 5 (several
   // alignments per wavefront, short_kernel.hip: the sixteen bytes of a word requested ahead instead of the word) takes the penalties:
   // 18 us + the gap between two launches of a 168 us step of 100k configs[1] pairs.  (ASCII dword indices are 32-bit there.)
-  c->short_ascii_ok = b->sequences_bytes < ((size_t)1 << 34);
+  // (sequences_bytes may be missing from a caller's batch record: four times the packed words bound the ASCII layout from above)
+  c->short_ascii_ok = std::max<size_t>(b->sequences_bytes, b->packed_bytes * 4) < ((size_t)1 << 34);
   const bool short_fuses = wfa_short_supported(pen.x, oe, pen.e) && !c->tuning.min_tier && !(compute_cigar && c->tuning.no_short_cigar) && c->short_ascii_ok;
   const bool fused_pack = !prepacked && (b->max_seq_len >= 512u || short_fuses) && !c->tuning.no_fused_pack;
   // Every status starts as PENDING = 0: written by the pack kernel where it runs (it visits every pair anyway), by a memset (a

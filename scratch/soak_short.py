@@ -28,6 +28,13 @@ for it in range(iters):
     base = [rand_pair(maxlen, err) for _ in range(min(n, 600))]
     pairs = [base[i % len(base)] for i in range(n)]
     pairs[0] = (b"", b""); pairs[1] = (b"A", b""); pairs[2] = (b"ACGT" * 10, b"ACGT" * 10)
+    # (round 5) a few pairs with bytes outside ACGT (the byte-compare class: flagged by tier 5 itself where it packs its own reads), the
+    # older paths of the one-kernel call now and then, budgets inherited from the previous call of the stream now and then
+    for q in range(3, n, rng.choice([97, 911, 100000])):
+        pq, tq = pairs[q]
+        if pq: pq = bytearray(pq); pq[rng.randrange(len(pq))] = rng.choice(b"NnRYKM"); pairs[q] = (bytes(pq), tq)
+    al.set_tuning(**rng.choice([{}, {}, {"no_host_parts": 1}, {"no_fused_pack": 1}, {"short_iterations": rng.choice([2, 7])}, {"no_short_cigar": 1}]))
+    al.hint_same_stream(rng.random() < 0.5)
     buf, meta = wfagpu.layout_pairs(pairs)
     so, co, _ = oracle_lib.oracle_batch(buf, meta, pen, cigar=True, nthreads=16)
     batch = al.upload(buf, meta)

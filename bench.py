@@ -379,9 +379,12 @@ def resident_leg(name, n_pairs, max_error, steps, warmup, device, seed, tuning, 
     last = {}
     band = wl["band"]
 
+    # (the scores of every step go into ONE device buffer, like the results array of a caller of launch_alignments*)
+    d_scores_buf = torch.empty(max(len(meta), 1), dtype=torch.int32, device=torch.device("cuda", device))
+
     def step():
         last["out"] = al.align(batch, PEN, max_error=max_error, compute_cigar=wl["cigar"], band=band[0] if band else -1,
-                               band_width=band[1] if band else 0, fetch=False)
+                               band_width=band[1] if band else 0, fetch=False, d_scores=d_scores_buf)
         st = al.stats()
         acc["align_ms"] += st.align_ms
         acc["pack_ms"] += st.pack_ms

@@ -419,13 +419,16 @@ class DeviceAligner:
             raise RuntimeError(f"wfagpu_amd_pack_device failed ({rc})")
         return d_packed.cpu().numpy().view(np.uint32), d_flags.cpu().numpy()
 
-    def align(self, batch, penalties, max_error, compute_cigar, band=-1, band_width=0, fetch=True):
+    def align(self, batch, penalties, max_error, compute_cigar, band=-1, band_width=0, fetch=True, d_scores=None):
         """Returns (scores ndarray, cigars list or None).  With fetch=False results stay on the device
-        and (d_scores tensor, (text_ptr, off_ptr, len_ptr)) is returned."""
+        and (d_scores tensor, (text_ptr, off_ptr, len_ptr)) is returned.  d_scores: the caller's int32 device tensor for the scores
+        (the C interface takes the caller's buffer: a loop of calls need not allocate one per call)."""
         torch = self.torch
         dev = torch.device("cuda", self.device)
         n = batch.num_pairs
-        d_scores = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        if d_scores is None:
+            d_scores = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        assert d_scores.dtype == torch.int32 and d_scores.numel() >= max(n, 1) and d_scores.is_cuda
         t, o, l = C.c_void_p(), C.c_void_p(), C.c_void_p()
         pen = Penalties(*penalties)
         rc = self.lib.wfagpu_amd_align_device(self.ctx, C.byref(batch), pen, int(max_error), int(band), int(band_width),

@@ -453,7 +453,9 @@ def cli_wall(n_pairs=1_000_000, length=1000, error=0.05, max_error=300, runs=2):
             st = re.search(r"\[wfagpu timing\] device 0 [^\n]*", r.stderr)
             bu = re.search(r"\[wfagpu timing\]   bring-up: [^\n]*", r.stderr)
             rd = re.search(r"File read: ([0-9.]+)s", r.stderr)
-            stages.append(((st.group(0)[len("[wfagpu timing] "):] if st else "") + (" | " + bu.group(0)[len("[wfagpu timing]   "):] if bu else "")) or None)
+            cs = re.search(r"\[cli stages\] [^\n]*", r.stderr)      # (the tool's own stages: read, results array, call, output, release)
+            stages.append(((st.group(0)[len("[wfagpu timing] "):] if st else "") + (" | " + bu.group(0)[len("[wfagpu timing]   "):] if bu else "") +
+                           (" | " + cs.group(0)[1:] if cs else "")) or None)
             reads.append(float(rd.group(1)) if rd else None)
     best = min(walls)
     return {"what": "bin/wfa.affine.gpu -i <1M x 1 kbp @ 5 % .seq> -x -e 300, fresh process per run: the 'Wall time' line it prints",

@@ -7,6 +7,7 @@
  * "score<TAB>CIGAR" lines (score negative, as WFA2's align_benchmark does).
  */
 #include <getopt.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -15,6 +16,28 @@
 #include "../utils/logger.h"
 #include "../utils/sequence_reader.h"
 #include "../utils/wf_clock.h"
+
+/* The first device query of a process initialises the HIP runtime (0.2-0.3 s) and starts bringing the device up in the background
+ * (wfa_launch.hip): it runs on a thread of its own while the main thread parses the options and reads the input -- a 2 GB .seq file is
+ * 0.25 s --, and is joined before anything asks about the device. */
+static int g_ndev = 0;
+static double g_query_seconds = 0.0;
+static void* device_query_thread(void* arg) {
+    (void)arg;
+    const double t0 = wf_now_seconds();
+    get_num_cuda_devices(&g_ndev);
+    if (g_ndev > 0) {
+        int major = 0, minor = 0;
+        get_cuda_capability(0, &major, &minor);
+        char* name = get_cuda_dev_name(0);
+        LOG_INFO("Using HIP device \"%s\" with capability %d.%d (%d visible)", name, major, minor, g_ndev)
+        free(name);
+        /* (the query above started bringing device 0 up in the background; the call will be sharded over every visible device) */
+        if (g_ndev > 1) wfagpu_amd_warmup();
+    }
+    g_query_seconds = wf_now_seconds() - t0;
+    return NULL;
+}
 
 static void usage(const char* prog) {
     printf("Options:\n[Input/Output]\n"
@@ -58,18 +81,6 @@ int main(int argc, char** argv) {
     long n_read = 0, max_distance = -1, batch_size = -1, band_arg = -2, tpb = -1, workers = -1;
     bool print_out = false, verbose = false, cigar = false, check = false, stage_times = false;
 
-    int ndev = 0;
-    get_num_cuda_devices(&ndev);
-    if (ndev == 0) { LOG_ERROR("No HIP devices detected.") exit(-1); }
-    {
-        int major = 0, minor = 0;
-        get_cuda_capability(0, &major, &minor);
-        char* name = get_cuda_dev_name(0);
-        LOG_INFO("Using HIP device \"%s\" with capability %d.%d (%d visible)", name, major, minor, ndev)
-        free(name);
-    }
-    /* (the query above started bringing device 0 up in the background; this call will be sharded over every visible device) */
-    if (ndev > 1) wfagpu_amd_warmup();
 
     int c;
     opterr = 0;      /* (unknown options are skipped silently: see the default case) */
@@ -112,15 +123,25 @@ int main(int argc, char** argv) {
     const affine_penalties_t penalties = {x, o, e};
     LOG_INFO("Penalties: M=0, X=%d, O=%d, E=%d.", x, o, e)
 
+    /* (started here, behind the option checks -- no exit path of the tool leaves it running --, joined right behind the read) */
+    pthread_t query_thread;
+    const bool query_started = pthread_create(&query_thread, NULL, device_query_thread, NULL) == 0;
+    if (!query_started) device_query_thread(NULL);
     LOG_INFO("Reading sequences file...")
     sequence_set_t set;
     memset(&set, 0, sizeof set);
-    double t0 = wf_now_seconds();
+    const double t_start = wf_now_seconds();
+    double t0 = t_start;
     const bool ok = seq_path ? read_seq_file(&set, seq_path, (size_t)(n_read > 0 ? n_read : 0))
                              : read_fasta_pair_files(&set, q_path, t_path, (size_t)(n_read > 0 ? n_read : 0));
+    const double t_read = wf_now_seconds() - t0;
+    if (query_started) pthread_join(query_thread, NULL);
+    const double t_query_wait = wf_now_seconds() - t0 - t_read;
     if (!ok) { LOG_ERROR("Error reading input.") exit(1); }
     if (set.num_pairs == 0) { LOG_ERROR("No sequence pairs found in the input.") exit(1); }
-    LOG_INFO("File read: %.3fs (%zu pairs)", wf_now_seconds() - t0, set.num_pairs)
+    LOG_INFO("File read: %.3fs (%zu pairs)", t_read, set.num_pairs)
+
+    if (g_ndev == 0) { LOG_ERROR("No HIP devices detected.") exit(-1); }
 
     if (max_distance < 0) {   /* tools/aligner.c:319-338 */
         max_distance = (long)(MAX(set.sequences_metadata[0].text_len, set.sequences_metadata[0].pattern_len) * 0.1);
@@ -143,6 +164,7 @@ int main(int argc, char** argv) {
     }
 
     wfa_alignment_result_t* results = NULL;
+    const double t_res0 = wf_now_seconds();
     /* (the reference starts every CIGAR buffer at max_distance * 5 bytes: 1.5 GB of calloc for a million 1 kbp pairs, 0.4 s of the
      * tool's run time.  An RLE CIGAR of score s has at most s operations, each at most ~5 characters with its match run; the typical
      * one is a quarter of that bound, and a buffer that is too small grows when the results are scattered) */
@@ -150,6 +172,7 @@ int main(int argc, char** argv) {
         LOG_ERROR("Can not initialise CIGAR buffer.")
         exit(-1);
     }
+    const double t_results = wf_now_seconds() - t_res0;
     wfa_alignment_options_t opt;
     memset(&opt, 0, sizeof opt);
     opt.max_error = (int)max_distance; opt.threads_per_block = (int)tpb; opt.num_workers = (int)workers;
@@ -168,6 +191,7 @@ int main(int argc, char** argv) {
     const double secs = wf_now_seconds() - t0;
     printf("Alignment computed. Wall time: %.3fs (%.3f alignments per second)\n", secs, (double)num_alignments / secs);
 
+    const double t_out0 = wf_now_seconds();
     if (out_path || print_out) {
         FILE* fp = stderr;
         if (!print_out) {
@@ -187,8 +211,15 @@ int main(int argc, char** argv) {
         }
         if (!print_out) fclose(fp);
     }
+    const double t_output = wf_now_seconds() - t_out0, t_free0 = wf_now_seconds();
     destroy_wfa_results(results, num_alignments);
+    const double t_free_results = wf_now_seconds() - t_free0;
     free_sequence_set(&set);
+    (void)t_free_results;
+    if (stage_times)
+        fprintf(stderr, "[cli stages] read %.3f s, device query %.3f on a thread of its own (%.3f of it behind the read), results array %.3f, alignment call %.3f, "
+                        "output %.3f, release %.3f; %.3f since the options were parsed\n",
+                t_read, g_query_seconds, t_query_wait, t_results, secs, t_output, wf_now_seconds() - t_free0, wf_now_seconds() - t_start);
     if (check && wfagpu_amd_check_failures() > 0) {
         LOG_ERROR("%ld alignments failed the -c verification.", wfagpu_amd_check_failures())
         return 2;

@@ -219,7 +219,17 @@ bool read_seq_file(sequence_set_t* set, const char* path, size_t max_pairs) {
             /* (bytes of a truncated strip: known after the fill; an upper bound sizes the buffer) */
             for (unsigned i = 0; i < n_now; ++i) if (st[i].take) total_bytes = st[i].first_byte + st[i].bytes;
         }
-        set->sequences_buffer = (char*)malloc(total_bytes + 64);
+        /* (a large buffer on huge pages where the kernel hands them out on request: 2 GB of sequences are 500k first-touch faults in
+         * the strips' threads and 0.2 s of unmapping at the end on 4 KiB pages; still a free()-able block) */
+        set->sequences_buffer = NULL;
+        if (total_bytes + 64 >= ((size_t)32 << 20)) {
+            void* big = NULL;
+            if (posix_memalign(&big, (size_t)2 << 20, total_bytes + 64) == 0) {
+                (void)madvise(big, total_bytes + 64, MADV_HUGEPAGE);
+                set->sequences_buffer = (char*)big;
+            }
+        }
+        if (!set->sequences_buffer) set->sequences_buffer = (char*)malloc(total_bytes + 64);
         set->sequences_metadata = (sequence_pair_t*)malloc((pairs ? pairs : 1) * sizeof(sequence_pair_t));
         if (!set->sequences_buffer || !set->sequences_metadata) { LOG_ERROR("Out of memory reading %s", path) ok = false; break; }
         set->sequences_buffer_size = total_bytes + 64;

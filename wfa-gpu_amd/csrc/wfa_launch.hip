@@ -35,7 +35,6 @@
 #include <chrono>
 #include <condition_variable>
 #include <functional>
-#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -92,63 +91,6 @@ void parallel_for(unsigned nt, const std::function<void(unsigned)>& fn) {
   fn(0);
   for (auto& t : pool) t.join();
 }
-
-// The same with threads that outlive the call: a std::thread costs ~20-40 us to start, one after the other -- a parallel_for of
-// twelve was 0.3 ms before its first strip, twice per batch of a call's prep stage (a third of the prep of a 62 500-pair batch, most of
-// that of a 25 000-pair one).  One pool per place that loops over batches (a device's prep stage, a lane's scatter); run() is called
-// by one thread at a time (the stage's own), which takes strip 0 itself.  Workers sleep on a condition variable between runs.
-class WorkerPool {
- public:
-  WorkerPool() = default;
-  WorkerPool(const WorkerPool&) = delete;
-  WorkerPool& operator=(const WorkerPool&) = delete;
-  ~WorkerPool() { shutdown(); }
-  void run(unsigned nt, const std::function<void(unsigned)>& fn) {
-    if (nt <= 1) { fn(0); return; }
-    {
-      std::lock_guard<std::mutex> l(mu_);
-      while (th_.size() + 1 < nt) th_.emplace_back([this] { worker(); });
-      job_ = &fn; job_nt_ = nt; next_ = 1; pending_ = nt - 1; ++gen_;
-    }
-    cv_.notify_all();
-    fn(0);
-    std::unique_lock<std::mutex> l(mu_);
-    cv_done_.wait(l, [&] { return pending_ == 0; });
-    job_ = nullptr;
-  }
-  void shutdown() {
-    { std::lock_guard<std::mutex> l(mu_); stop_ = true; }
-    cv_.notify_all();
-    for (auto& t : th_) t.join();
-    th_.clear();
-    stop_ = false;
-  }
- private:
-  void worker() {
-    unsigned long long seen = 0;
-    std::unique_lock<std::mutex> l(mu_);
-    for (;;) {
-      cv_.wait(l, [&] { return stop_ || gen_ != seen; });
-      if (stop_) return;
-      seen = gen_;
-      while (job_ && next_ < job_nt_) {
-        const unsigned t = next_++;
-        const std::function<void(unsigned)>* const f = job_;
-        l.unlock();
-        (*f)(t);
-        l.lock();
-        if (--pending_ == 0) cv_done_.notify_one();
-      }
-    }
-  }
-  std::mutex mu_;
-  std::condition_variable cv_, cv_done_;
-  std::vector<std::thread> th_;
-  const std::function<void(unsigned)>* job_ = nullptr;
-  unsigned job_nt_ = 0, next_ = 0, pending_ = 0;
-  unsigned long long gen_ = 0;
-  bool stop_ = false;
-};
 
 // Best effort: run a device's host threads (this one and the ones it starts: they inherit the mask) on the cores of the
 // NUMA node its GPU hangs off, so that the staging copies and the scatter of eight devices do not all cross the socket
@@ -271,7 +213,6 @@ int check_batch(const CallArgs& a, size_t from, size_t to, int batch_idx, unsign
 // single-threaded by contract (lib/aligner.h of the reference is not re-entrant); a mutex per slot guards the cache anyway.
 struct Lane {
   wfagpu_amd_ctx_t* ctx = nullptr;
-  std::unique_ptr<WorkerPool> scatter_pool;      // (the threads of the lane's scatter: kept between batches and calls)
   int32_t* d_scores[2] = {nullptr, nullptr}; size_t scores_cap[2] = {0, 0};      // (alternate like the context's CIGAR buffers)
   struct Out {
     char* text = nullptr; size_t text_cap = 0;
@@ -306,7 +247,6 @@ struct DevState {
   int sharers = 1;                             // slots sharing the physical device when the lanes were created (their arena caps are shares)
   double bring_clock[MAX_LANES + 3] = {0};     // (timing: when the bring-up thread had the upload stream, lane k, the download stream: now_ms())
   HostStage stage[STAGE_RING];
-  std::unique_ptr<WorkerPool> prep_pool;       // (the threads of the prep stage: kept between batches and calls)
   Lane lane[MAX_LANES];
   wfagpu_amd_tuning_t tuning{};                // what the contexts were created with
   size_t arena_limit_cfg = 0;
@@ -566,16 +506,15 @@ int run_device(const CallArgs& a, Shard& sh) {
     slice_bytes = hi0 > lo0 ? hi0 - lo0 : 0;      // (an estimate: the records of a call are laid out in order by every known caller)
   }
   const bool big = n_all >= ((size_t)1 << 17) || (slice_bytes >= ((size_t)128 << 20) && n_all >= 256);
-  const bool mid = !big && n_all >= ((size_t)1 << 15) && slice_bytes >= ((size_t)8 << 20);      // (not big, not tiny: below)
   // 2-bit packing on the host (a quarter of the bytes over PCIe) when this device's share of the host threads allows
-  // (mid-size calls too since the prep stage's threads are a pool: 100k x 150 bp host to host 1.03 -> 0.90 ms)
-  const bool host_pack = a.cfg.host_pack > 0 || (a.cfg.host_pack == 0 && sh.host_threads >= 4 && (big || mid));
+  const bool host_pack = a.cfg.host_pack > 0 || (a.cfg.host_pack == 0 && sh.host_threads >= 4 && big);
   const unsigned pack_threads = a.cfg.host_pack_threads > 0 ? (unsigned)a.cfg.host_pack_threads
                                                             : std::max(2u, std::min(12u, sh.host_threads * 3u / 4u));
   const unsigned prep_threads = host_pack ? pack_threads : std::max(1u, std::min(8u, sh.host_threads / 2u));
   // (a call that is not big but not tiny either -- BASELINE configs[1]: 100k x 150 bp, 31 MB -- still gains from three or four batches:
   // record sweep, upload, kernels and scatter of ONE batch are a chain of 0.45 + 0.7 + 0.1 + 0.15 ms, cut in four the upload of a batch
   // runs under the sweep of the next: 1.46 -> 1.14 ms host to host, with CIGARs 1.87 -> 1.7 at three; more batches lose again)
+  const bool mid = !big && n_all >= ((size_t)1 << 15) && slice_bytes >= ((size_t)8 << 20);
   if (bs == n_all && (big || mid || a.cfg.batches_per_device > 1)) {
     // (few long pairs: batches of >= 32 MB and >= 8192 pairs -- smaller ones tune no score budgets, csrc/wfa_host.hip, and
     // run twice as long: 16k x 10 kbp pairs, host to host: one batch 25.1 ms, two 22.0, four 43.7)
@@ -650,10 +589,7 @@ int run_device(const CallArgs& a, Shard& sh) {
   std::vector<StageTimes> t_lane(K), t_scat(K);
 
   // ---- stage 0: spans and packed offsets (host only) -----------------------------------------------------------------
-  if (!d.prep_pool) d.prep_pool.reset(new WorkerPool());
-  for (int k = 0; k < K; ++k) if (!d.lane[k].scatter_pool) d.lane[k].scatter_pool.reset(new WorkerPool());
   std::thread prepper([&] {
-    WorkerPool& pool = *d.prep_pool;
     if (host_pack && hipSetDevice(sh.device) != hipSuccess) { fl.fail(-1); return; }
     for (int i = 0; i < nb; ++i) {
       if (fl.rc.load()) return;
@@ -670,7 +606,7 @@ int run_device(const CallArgs& a, Shard& sh) {
       struct Strip { size_t lo = SIZE_MAX, hi = 0, bytes = 0; unsigned max_len = 0; size_t outside = SIZE_MAX; };
       std::vector<Strip> strip(nt);
       auto words = [](size_t len) { return (len + 15) / 16 + 1; };
-      pool.run(nt, [&](unsigned t) {
+      parallel_for(nt, [&](unsigned t) {
         Strip st;
         const size_t j1 = b.from + n * (t + 1) / nt;
         for (size_t j = b.from + n * t / nt; j < j1; ++j) {
@@ -724,7 +660,7 @@ int run_device(const CallArgs& a, Shard& sh) {
       }
       std::atomic<int> bad{0};
       const double t_pack0 = now_ms();
-      pool.run(nt, [&](unsigned t) {
+      parallel_for(nt, [&](unsigned t) {
         const size_t j0 = b.from + n * t / nt, j1 = b.from + n * (t + 1) / nt;
         if (wfagpu_host_pack_strip(a.seq, a.seq_bytes, a.meta + j0, j1 - j0, strip_off[t], stage)) bad.store(1);
       });
@@ -879,7 +815,7 @@ int run_device(const CallArgs& a, Shard& sh) {
       };
       // strips of consecutive pairs per thread
       const unsigned nt = (unsigned)std::min<size_t>(std::min(8u, lane_threads), a.cigar ? (n + 8191) / 8192 : (n + 131071) / 131072);
-      d.lane[k].scatter_pool->run(std::max(1u, nt), [&](unsigned t) { work(n * t / std::max(1u, nt), n * (t + 1) / std::max(1u, nt)); });
+      parallel_for(std::max(1u, nt), [&](unsigned t) { work(n * t / std::max(1u, nt), n * (t + 1) / std::max(1u, nt)); });
       t_scat[k].scatter += now_ms() - t0;
       if (bad.load()) { fl.fail(-1); return; }
       if (a.check) { const double t1 = now_ms(); check_batch(a, b.from, b.to, i, lane_threads); t_scat[k].check += now_ms() - t1; }

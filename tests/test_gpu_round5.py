@@ -228,3 +228,43 @@ def test_short_reads_packed_by_their_own_tier(cigar):
     assert stats["default"][1] > 23000      # (tier 5 took the batch)
     # (the same work accounting whichever way the sums reach the host)
     assert stats["default"] == stats["parts_on_device"] == stats["pack_kernel"] == stats["default_again"], stats
+
+
+@pytest.mark.parametrize("cigar", [False, True])
+def test_mid_size_call_is_cut_into_batches(cigar):
+    """A call that is neither big (128k+ pairs) nor tiny -- 40 000 pairs of 150 bases, 12 MB -- is cut into four batches (three with
+    CIGARs) so that the upload of one runs under the record sweep of the next (wfa_launch.hip): results complete and in input order,
+    equal to the checker's, pairs with bytes outside ACGT and a pair that leaves the short-read tier included."""
+    import ctypes as C
+    lib = wfagpu.load()
+    buf_a, meta_a = wfagpu.generate_pairs(40000, 150, 0.02, seed=61)
+    pairs = wfagpu.pairs_from_layout(buf_a, meta_a)
+    rng = random.Random(61)
+    for q in rng.sample(range(40000), 25):
+        p, t = pairs[q]
+        p = bytearray(p); p[rng.randrange(len(p))] = ord("N"); pairs[q] = (bytes(p), t)
+    p, t = pairs[12345]
+    pairs[12345] = (p, t[:30] + t[75:])
+    buf, meta = wfagpu.layout_pairs(pairs)
+    so, co = _truth(buf, meta, PEN, cigar=cigar)
+    al = wfagpu.Aligner()
+    assert lib.wfagpu_initialize_aligner(C.byref(al))
+    try:
+        for p, t in pairs:
+            assert lib.wfagpu_add_sequences(C.byref(al), p, t)
+        assert lib.wfagpu_initialize_parameters(C.byref(al), wfagpu.Penalties(*PEN))
+        assert lib.wfagpu_set_batch_size(C.byref(al), len(pairs))      # (one batch as far as the caller goes: the CLI's default)
+        al.alignment_options.max_error = int(so.max()) + 4
+        al.alignment_options.compute_cigar = cigar
+        for _ in range(2):
+            assert lib.wfagpu_align(C.byref(al))
+            n = al.num_sequence_pairs
+            s = np.array([al.results[i].error for i in range(n)], dtype=np.int64)
+            assert np.array_equal(s, np.asarray(so))
+            if cigar:
+                assert [C.string_at(al.results[i].cigar.buffer).decode() for i in range(n)] == co
+            st = wfagpu.last_launch_stats()
+            assert st["batches"] == (3 if cigar else 4), st
+    finally:
+        lib.wfagpu_destroy_aligner(C.byref(al))
+        lib.wfagpu_amd_release_cache()

@@ -207,6 +207,10 @@ def host_to_host(buf, meta, wl, max_error, n_devices=1, reps=8, registered=False
         return out
 
     lib.wfagpu_amd_release_cache()
+    # (what an earlier leg of this process held goes back to the driver here, and the driver wipes released memory before it hands it
+    # out again: a large allocation right behind a large release waits for that -- a cold call of 511 ms instead of 27-34 seen once
+    # for cfg4 behind the headline's 60 GB.  A cold call of a fresh process has nothing to wait for: give the wipe a moment.)
+    time.sleep(0.3)
     calls = timed(3 + reps)
     ms = [c[0] for c in calls]
     steady = sorted(calls[3:], key=lambda c: c[0])
@@ -440,6 +444,15 @@ def cli_wall(n_pairs=1_000_000, length=1000, error=0.05, max_error=300, runs=2):
         subprocess.run([gen, "-n", str(n_pairs), "-l", str(length), "-e", str(error), "-s", "9", "-t", str(min(16, usable_cores())), "-o", seq],
                        check=True, timeout=600, capture_output=True)
         gen_s = time.perf_counter() - t0
+        # One untimed run on a small file first: on a box that has just been handed out the tool's shared objects (the HIP runtime,
+        # its code-object compiler, this library) still come off the image's disk, and the first process that maps them waits for
+        # that -- 381 ms and 129 ms for the first two timed runs on such a box against 60-70 ms on one that has run anything (the
+        # pattern of BENCH_r04's 321 / 120 ms).  The timed runs below are fresh processes all the same.
+        small = os.path.join(tmp, "small.seq")
+        subprocess.run([gen, "-n", "2000", "-l", str(length), "-e", str(error), "-s", "8", "-o", small], check=True, timeout=600, capture_output=True)
+        t0 = time.perf_counter()
+        subprocess.run([cli, "-i", small, "-x", "-e", str(max_error)], capture_output=True, text=True, timeout=600)
+        first_process_s = round(time.perf_counter() - t0, 3)
         walls, proc, stages, reads = [], [], [], []
         for _ in range(runs):
             t0 = time.perf_counter()
@@ -461,7 +474,8 @@ def cli_wall(n_pairs=1_000_000, length=1000, error=0.05, max_error=300, runs=2):
     return {"what": "bin/wfa.affine.gpu -i <1M x 1 kbp @ 5 % .seq> -x -e 300, fresh process per run: the 'Wall time' line it prints",
             "unit": "alignments/s", "pairs": n_pairs, "value": round(max(w[1] for w in walls), 1), "wall_s": [w[0] for w in walls],
             "alignments_per_s": [w[1] for w in walls], "best_wall_ms": round(best[0] * 1e3, 1), "process_s": proc, "file_read_s": reads,
-            "stage_clocks": stages, "generate_s": round(gen_s, 2)}
+            "stage_clocks": stages, "generate_s": round(gen_s, 2),
+            "untimed_first_process_s": first_process_s, "untimed_first_process": "the tool on 2000 pairs, once, before the timed runs: maps the shared objects on a box that may not have run anything yet"}
 
 
 def ont_banded_leg(n=1024, length=30_000, reps=2):

@@ -66,7 +66,8 @@ typedef struct {
 
 typedef struct {
     int device;            /* HIP device ordinal                                         */
-    void* stream;          /* hipStream_t to run on; NULL: the context creates its own   */
+    void* stream;          /* hipStream_t to run on; NULL: the context creates its own (hipStreamNonBlocking: it is NOT ordered
+                              behind the device's null stream -- see "Stream ordering" below); the null stream itself: null_stream */
     size_t arena_bytes;    /* backtrace arena (origin bytes + row headers); 0: automatic */
     size_t text_bytes;     /* CIGAR text arena; 0: automatic                             */
     size_t arena_limit_bytes; /* cap for the automatic arena size (0: none); a batch that needs
@@ -75,7 +76,18 @@ typedef struct {
                               needed several passes (launch_alignments* no longer use it: a call that regrows its arena
                               stalls behind the driver's wipe of the memory it has just released) */
     wfagpu_amd_tuning_t tuning;
+    int null_stream;       /* 1: run on the device's NULL (legacy default) stream -- the handle 0 cannot say so through `stream`,
+                              where 0 means "create my own".  PyTorch's default stream is this one
+                              (torch.cuda.current_stream().cuda_stream == 0 unless a torch.cuda.Stream is current). */
 } wfagpu_amd_config_t;
+
+/* Stream ordering.  Every kernel and copy of a context runs on ITS stream (wfagpu_amd_stream).  The device buffers a call is
+ * given -- sequences, metadata, d_packed / d_flags / d_scores -- must be COMPLETE on that stream's timeline when the call is
+ * made: produced on the same stream, or by work that has finished (synchronised) or that the context's stream has been made
+ * to wait for (hipStreamWaitEvent).  A context that created its own stream is non-blocking: a fill or copy still queued on
+ * another stream -- the null stream included -- races with the call's kernels (the reference copies synchronously around its
+ * kernels: tests/test_packing_kernel.cu:225-306, lib/sequence_alignment.cu:87-147).  The calls themselves are blocking:
+ * their results are complete when they return. */
 
 typedef struct {
     const char* d_sequences;             /* device: ASCII buffer, reference layout       */

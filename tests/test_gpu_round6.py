@@ -1,0 +1,79 @@
+"""Round-6 additions, through the C-ABI on the GPU:
+  * stream ordering of the device-resident entry points (EXPERIMENTS R5.8: the one red the path ever showed was the ctypes stub
+    zero-filling on torch's null stream while the pack kernel ran on the context's own non-blocking stream);
+  * wfagpu_amd_config_t::null_stream and a context on a torch.cuda.Stream.
+The reference copies synchronously around its kernels (tests/test_packing_kernel.cu:225-306).
+"""
+import ctypes as C
+import os
+import random
+
+import numpy as np
+import pytest
+
+import oracle_lib
+import wfagpu
+from test_oracle import _rand_pairs
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _pack_expected(pairs, hm):
+    """(offset in words, words incl. the spare zero, flag) per sequence, from the checker's packer."""
+    o = oracle_lib.oracle()
+    out = []
+    for i, (p, t) in enumerate(pairs):
+        for seq, off in ((p, int(hm[i]["pattern_offset_packed"])), (t, int(hm[i]["text_offset_packed"]))):
+            nw = (len(seq) + 15) // 16
+            words = (C.c_uint32 * (nw + 1))()
+            bad = o.oracle_pack2(seq, len(seq), words)
+            out.append((off // 4, np.frombuffer(words, dtype=np.uint32)[:nw].copy(), bad))
+    return out
+
+
+def _check_pack(packed, flags, expected):
+    for j, (w0, words, bad) in enumerate(expected):
+        assert flags[j] == bad, j
+        if not bad:
+            assert np.array_equal(packed[w0:w0 + len(words)], words), j
+        assert packed[w0 + len(words)] == 0, j
+
+
+@pytest.mark.parametrize("mode", ["own_stream_after_null_fill", "null_stream", "torch_stream"])
+def test_pack_soak_behind_a_busy_null_stream(mode):
+    """200 x (pack + compare) on a context created AFTER a large asynchronous fill was queued on the null stream, with another
+    large fill queued in front of every call: the binding's own zero-fills of the output tensors sit behind it on torch's stream
+    while the context packs on its stream.  Every mode must order the two (R5.8 failed once in ~10^3 runs without)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = random.Random(86)
+    pairs = [(b"GATTACA", b"GATACA"), (b"ACGT" * 9, b"ACGT" * 9 + b"A"), (b"T" * 33, b"C" * 16), (b"A", b"G")]
+    pairs += _rand_pairs(rng, 201, 110) + [(b"ACGNACGT", b"acgt"), (b"", b"A"), (b"", b""), (b"C" * 109, b"")]
+    buf, meta = wfagpu.layout_pairs(pairs)
+    big = torch.empty(1 << 28, dtype=torch.uint8, device=dev)      # 256 MiB: a fill of ~0.1 ms and more
+    big.fill_(1)
+    stream = torch.cuda.Stream(dev) if mode == "torch_stream" else None
+    ctx_mgr = torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.default_stream(dev))
+    with ctx_mgr:
+        al = wfagpu.DeviceAligner(0, null_stream=(mode == "null_stream"))
+        try:
+            if mode == "own_stream_after_null_fill":
+                assert al._ctx_stream is None
+            batch = al.upload(buf, meta)
+            expected = _pack_expected(pairs, batch._meta_host)
+            for it in range(200):
+                big.fill_(it & 0x7F)
+                big.fill_((it + 1) & 0x7F)
+                packed, flags = al.pack(batch)
+                _check_pack(packed, flags, expected)
+            # and the whole path behind a busy stream: scores land in a tensor torch has just filled
+            so, co, _ = oracle_lib.oracle_batch(buf, meta, (2, 3, 1), cigar=True, nthreads=8)
+            for it in range(20):
+                big.fill_(it)
+                d_scores = torch.full((len(pairs),), -7, dtype=torch.int32, device=dev)
+                s, c = al.align(batch, (2, 3, 1), max_error=120, compute_cigar=True, d_scores=d_scores)
+                assert np.array_equal(s, np.asarray(so)) and c == co
+        finally:
+            al.close()
+    torch.cuda.synchronize()

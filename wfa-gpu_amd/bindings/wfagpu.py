@@ -53,7 +53,8 @@ class Tuning(C.Structure):  # wfagpu_amd_tuning_t: all zero = the defaults
 
 class Config(C.Structure):  # wfagpu_amd_config_t
     _fields_ = [("device", C.c_int), ("stream", C.c_void_p), ("arena_bytes", C.c_size_t), ("text_bytes", C.c_size_t),
-                ("arena_limit_bytes", C.c_size_t), ("arena_limit_max_bytes", C.c_size_t), ("tuning", Tuning)]
+                ("arena_limit_bytes", C.c_size_t), ("arena_limit_max_bytes", C.c_size_t), ("tuning", Tuning),
+                ("null_stream", C.c_int)]
 
 
 class LaunchConfig(C.Structure):  # wfagpu_amd_launch_config_t: all zero = automatic
@@ -337,8 +338,15 @@ def host_pack(buf, meta, packed_bytes, scalar=False):
 class DeviceAligner:
     """Owns a wfagpu_amd context on one GPU and runs resident batches through the C-ABI."""
 
-    def __init__(self, device=0, arena_bytes=0, text_bytes=0, use_torch_stream=True, arena_limit_bytes=0, **tuning):
-        """tuning: fields of wfagpu_amd_tuning_t (min_tier=2, force_band=1, ...)."""
+    def __init__(self, device=0, arena_bytes=0, text_bytes=0, use_torch_stream=True, arena_limit_bytes=0, null_stream=False, **tuning):
+        """tuning: fields of wfagpu_amd_tuning_t (min_tier=2, force_band=1, ...).
+
+        Streams (include/wfa_gpu_device.h, "Stream ordering"): with a torch.cuda.Stream current, the context runs on it and is
+        ordered with the binding's own tensor work by construction.  torch's DEFAULT stream has the handle 0, which the C
+        interface reads as "create my own" (a non-blocking stream, NOT ordered behind the null stream): the binding then
+        drains torch's current stream before every call that hands the context a tensor (`_inputs_ready`) -- a zero-fill still
+        queued on the null stream would otherwise race with the context's kernels (EXPERIMENTS R5.8).  null_stream=True runs the
+        context on the null stream itself (wfagpu_amd_config_t::null_stream)."""
         import torch
         self.torch = torch
         self.lib = load()
@@ -346,11 +354,27 @@ class DeviceAligner:
         torch.cuda.set_device(device)
         cfg = Config(device=device, stream=None, arena_bytes=arena_bytes, text_bytes=text_bytes,
                      arena_limit_bytes=arena_limit_bytes, tuning=Tuning(**tuning))
-        if use_torch_stream:
-            cfg.stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        self._ctx_stream = None     # handle of the context's stream when torch knows it (0: the null stream); None: the context's own
+        if null_stream:
+            cfg.null_stream = 1
+            self._ctx_stream = 0
+        elif use_torch_stream:
+            h = torch.cuda.current_stream(device).cuda_stream
+            if h:
+                cfg.stream = C.c_void_p(h)
+                self._ctx_stream = h
         self.ctx = C.c_void_p()
         if self.lib.wfagpu_amd_create(C.byref(self.ctx), C.byref(cfg)) != 0:
             raise RuntimeError("wfagpu_amd_create failed")
+
+    def _inputs_ready(self):
+        """Everything queued on torch's current stream (fills, copies of the tensors about to be handed over) is complete
+        before the context's own stream touches them.  Nothing to do when both are the same stream."""
+        cur = self.torch.cuda.current_stream(self.device)
+        if self._ctx_stream is not None and cur.cuda_stream == self._ctx_stream:
+            return
+        if not cur.query():
+            cur.synchronize()
 
     def hint_same_stream(self, on=True):
         """The following batches come from the same stream of reads as the last one: score budgets learnt from a sample are
@@ -414,6 +438,7 @@ class DeviceAligner:
         dev = torch.device("cuda", self.device)
         d_packed = torch.zeros(batch.packed_bytes // 4 + 4, dtype=torch.int32, device=dev)
         d_flags = torch.zeros(2 * batch.num_pairs, dtype=torch.uint8, device=dev)
+        self._inputs_ready()      # (the two fills above run on torch's stream, the pack kernel on the context's)
         rc = self.lib.wfagpu_amd_pack_device(self.ctx, C.byref(batch), d_packed.data_ptr(), d_flags.data_ptr())
         if rc != 0:
             raise RuntimeError(f"wfagpu_amd_pack_device failed ({rc})")
@@ -431,6 +456,7 @@ class DeviceAligner:
         assert d_scores.dtype == torch.int32 and d_scores.numel() >= max(n, 1) and d_scores.is_cuda
         t, o, l = C.c_void_p(), C.c_void_p(), C.c_void_p()
         pen = Penalties(*penalties)
+        self._inputs_ready()
         rc = self.lib.wfagpu_amd_align_device(self.ctx, C.byref(batch), pen, int(max_error), int(band), int(band_width),
                                               bool(compute_cigar), d_scores.data_ptr(), C.byref(t), C.byref(o),
                                               C.byref(l))

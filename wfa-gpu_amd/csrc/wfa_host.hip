@@ -409,7 +409,9 @@ int wfagpu_amd_create(wfagpu_amd_ctx_t** out, const wfagpu_amd_config_t* cfg) {
   c->device = dev;
   // (a context that fails half-way is torn down again: wfagpu_amd_destroy copes with whatever exists so far)
   auto init = [&]() -> int {
-    if (cfg && cfg->stream) {
+    if (cfg && cfg->null_stream) {
+      c->stream = nullptr;      // (the device's null stream: ordered with every blocking stream of the process)
+    } else if (cfg && cfg->stream) {
       c->stream = static_cast<hipStream_t>(cfg->stream);
     } else {
       HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -442,7 +444,7 @@ int wfagpu_amd_create(wfagpu_amd_ctx_t** out, const wfagpu_amd_config_t* cfg) {
 void wfagpu_amd_destroy(wfagpu_amd_ctx_t* c) {
   if (!c) return;
   hipSetDevice(c->device);
-  if (c->stream) hipStreamSynchronize(c->stream);
+  hipStreamSynchronize(c->stream);      // (nullptr: the null stream)
   c->free_retired();
   for (DevBuf* b : {&c->packed, &c->flags, &c->status, &c->cells, &c->bt_final, &c->list_a, &c->list_b, &c->list_c, &c->list_d, &c->list_e, &c->work_ctr, &c->sample, &c->ratio, &c->budget,
                     &c->counters, &c->arena, &c->ops, &c->text[0], &c->text[1], &c->text_scratch, &c->cig_off[0], &c->cig_off[1], &c->cig_len[0], &c->cig_len[1], &c->gring, &c->dbg})

@@ -67,7 +67,7 @@ def kernel_source_hash():
     h = hashlib.sha1()
     import glob
     csrc = os.path.join(ROOT, "wfa-gpu_amd", "csrc")
-    files = [os.path.join(csrc, f) for f in ("align_kernel.hip", "short_kernel.hip", "trace_kernel.hip", "pack_kernel.hip", "pack_device.h", "wfa_device.h")]
+    files = [os.path.join(csrc, f) for f in ("align_kernel.hip", "short_kernel.hip", "short_kernel_impl.h", "trace_kernel.hip", "pack_kernel.hip", "pack_device.h", "wfa_device.h")]
     files.append(os.path.join(ROOT, "wfa-gpu_amd", "Makefile"))      # (the compiler flags of the kernels)
     for f in files + sorted(glob.glob(os.path.join(csrc, "align", "*.inc"))):      # (the score loops and cells of align_kernel.hip)
         h.update(open(f, "rb").read())

@@ -29,7 +29,7 @@ def exp_batch(buf, meta, pen):
 rng = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 total = diff = 0
 for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
-    pen = rng.choice([(2, 3, 1), (1, 2, 1), (4, 6, 1), (1, 0, 1), (3, 1, 1), (7, 2, 1)])
+    pen = rng.choice([(2, 3, 1), (1, 2, 1), (4, 6, 1), (1, 0, 1), (3, 1, 1), (7, 2, 1)] if len(sys.argv) <= 3 else [(5, 3, 2), (3, 1, 4), (7, 2, 3), (1, 0, 2), (2, 0, 3), (3, 5, 2), (8, 4, 4), (1, 4, 2), (6, 1, 3)])
     pairs = []
     for _ in range(20000):
         L = rng.randint(1, 60)

@@ -894,14 +894,16 @@ def test_one_kernel_backtrace_of_short_alignments(max_error, pen):
 
 @pytest.mark.parametrize("pen,expect_short", [((2, 3, 1), True), ((4, 6, 2), True), ((1, 2, 1), True), ((1, 0, 1), True), ((4, 6, 1), True),
                                               ((3, 4, 1), True), ((7, 7, 1), True), ((8, 2, 1), True), ((6, 9, 3), True),
-                                              ((5, 3, 2), False), ((9, 2, 1), False), ((2, 8, 1), False)])
+                                              ((5, 3, 2), True), ((3, 1, 4), True), ((7, 2, 3), True), ((3, 5, 2), True), ((1, 0, 2), True), ((8, 4, 4), True),
+                                              ((2, 0, 3), True), ((3, 1, 5), False), ((9, 2, 1), False), ((2, 8, 1), False)])
 def test_short_wavefront_tier_scores(pen, expect_short):
     """Score-only batches of short reads run on tier 5 (short_kernel.hip: four or two alignments per wavefront, rings in
     registers, neighbours by DPP row shifts) once their budgets are tuned: 20k x 150 bp pairs at 2 %, with every 200th pair at
     12 % (below the 99th percentile the budgets come from: it misses its budget and is re-run in the ordinary tiers), pairs whose lengths differ so much that their diagonal window does
     not fit a group (BAND failure -> ordinary tiers), empty and one-base sequences.  Every score equals the checker's.  The tier
-    is compiled for every penalty set with e == 1 and max(x, o + e) <= 8 once a common factor is divided out (a ring of up to
-    eight M registers per lane); other sets take the ordinary path."""
+    is compiled for every penalty set with e <= 4 and max(x, o + e) <= 8 once a common factor is divided out (rings of up to
+    eight M -- and, for e > 1, I and D -- registers per lane; the reference's own test sets (5,3,2), (3,5,2), (3,1,4):
+    tests/test_api.c:59-219); other sets take the ordinary path."""
     n = 20000
     buf, meta = wfagpu.generate_pairs(n, 150, 0.02, seed=515)
     hard, mh = wfagpu.generate_pairs(n // 200 + 1, 150, 0.12, seed=516)

@@ -200,6 +200,12 @@ size_t wfa_short_lds_bytes(const WfaAlignParams& p, int lanes, bool with_bt);
 void wfa_launch_short(const WfaAlignParams& p, int lanes, bool with_bt, int grid, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 int wfa_short_max_blocks_per_cu(const WfaAlignParams& p, int lanes, bool with_bt);     // (wavefronts a CU holds: registers and LDS)
 unsigned long long wfa_short_bt_slot_units(int max_score, int lanes);     // (with_bt: arena units every work item of the launch owns)
+// Tier 5's instantiations are picked from tables [x - 1][o + e - 1]; one translation unit (one code object) per gap extension e:
+// short_kernel.hip holds e = 1, short_kernel_e2/3/4.hip the others (short_kernel_impl.h is the kernel).
+struct WfaShortEntry { void (*launch)(const WfaAlignParams&, int, hipStream_t, hipEvent_t, hipEvent_t); int (*occ)(size_t); };
+const WfaShortEntry* wfa_short_entry_e2(int ascii, int bt, int l32, int idx);
+const WfaShortEntry* wfa_short_entry_e3(int ascii, int bt, int l32, int idx);
+const WfaShortEntry* wfa_short_entry_e4(int ascii, int bt, int l32, int idx);
 // Code-object priming: one empty launch per kernel translation unit (see the definitions).
 void wfa_prime_pack(hipStream_t stream);
 void wfa_prime_align(hipStream_t stream);

@@ -12,6 +12,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <signal.h>
+#include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
 
 #include "../include/wfa_gpu_abi.h"
@@ -157,6 +160,46 @@ static void readers(void) {
     }
     memset(&s, 0, sizeof s);
     CHECK(read_seq_file(&s, path_buf[0], 1000000) && s.num_pairs == 11000);      /* -n past the end of the file */
+    /* inputs that cannot be mapped -- a FIFO, /dev/stdin, `-i <(zcat x.seq.gz)`: st_size 0 -- go through the getline reader: the same
+     * records and bytes as the mapped read of the same file, with and without -n (such inputs came back as zero pairs) */
+    {
+        char fifo[4200];
+        snprintf(fifo, sizeof fifo, "%s.fifo", path_buf[0]);
+        unlink(fifo);
+        CHECK(mkfifo(fifo, 0600) == 0);
+        for (int round = 0; round < 2; ++round) {
+            const size_t limit = round ? 1234 : 0;
+            const pid_t pid = fork();
+            CHECK(pid >= 0);
+            if (pid == 0) {      /* the writer: the file into the pipe (a reader that stops early, -n, just closes it) */
+                signal(SIGPIPE, SIG_IGN);
+                FILE* in = fopen(path_buf[0], "rb"); FILE* out = fopen(fifo, "wb");
+                if (!in || !out) _exit(2);
+                char chunk[65536]; size_t got;
+                while ((got = fread(chunk, 1, sizeof chunk, in)) > 0) if (fwrite(chunk, 1, got, out) != got) break;
+                fclose(in); fclose(out);
+                _exit(0);
+            }
+            sequence_set_t piped;
+            memset(&piped, 0, sizeof piped);
+            CHECK(read_seq_file(&piped, fifo, limit));
+            int status = 0;
+            CHECK(waitpid(pid, &status, 0) == pid);
+            sequence_set_t mapped;
+            memset(&mapped, 0, sizeof mapped);
+            CHECK(read_seq_file(&mapped, path_buf[0], limit));
+            CHECK(piped.num_pairs == (limit ? limit : 11000u) && piped.num_pairs == mapped.num_pairs);
+            check_set(&piped);
+            for (size_t i = 0; i < piped.num_pairs; ++i) {
+                const sequence_pair_t *a = &piped.sequences_metadata[i], *b = &mapped.sequences_metadata[i];
+                CHECK(a->pattern_len == b->pattern_len && a->text_len == b->text_len && a->has_N == b->has_N);
+                CHECK(memcmp(piped.sequences_buffer + a->pattern_offset, mapped.sequences_buffer + b->pattern_offset, a->pattern_len) == 0);
+                CHECK(memcmp(piped.sequences_buffer + a->text_offset, mapped.sequences_buffer + b->text_offset, a->text_len) == 0);
+            }
+            free_sequence_set(&piped); free_sequence_set(&mapped);
+        }
+        unlink(fifo);
+    }
     /* the file is parsed in strips by several threads (sequence_reader.c): the same records and the same bytes from 1, 2, 3, 7
      * and 32 strips, with -n cutting inside a strip, at a strip's first pair and beyond the file; lines with CR LF, blank lines
      * and a doubled pattern line (the last one counts) across the cuts */

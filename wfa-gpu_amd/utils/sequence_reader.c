@@ -153,16 +153,45 @@ static void run_strips(strip_t* st, unsigned n, bool fill) {
     for (unsigned i = 1; i < n; ++i) { if (started[i]) pthread_join(th[i], NULL); else strip_sweep(&st[i]); }
 }
 
+/* The reference's reader as it is (utils/sequence_reader.c:137-227: one getline loop): for inputs that cannot be mapped -- a FIFO,
+ * /dev/stdin, a process substitution (`-i <(zcat x.seq.gz)`): st_size says 0 for those -- and when mmap fails.  Same layout, same
+ * error cases, blank lines skipped, CR LF accepted, -n honoured. */
+static bool read_seq_stream(sequence_set_t* set, int fd, const char* path, size_t max_pairs) {
+    FILE* f = fdopen(fd, "r");
+    if (!f) { LOG_ERROR("Can not open %s", path) close(fd); return false; }
+    char *line = NULL, *pat = NULL;
+    size_t cap = 0, pat_cap = 0, plen = 0;
+    bool have_pat = false, ok = true;
+    ssize_t len;
+    while ((len = getline(&line, &cap, f)) >= 0) {
+        const size_t n = chomp(line, len);
+        if (n == 0) continue;
+        if (line[0] == '>') {
+            if (n > pat_cap) { char* np = (char*)realloc(pat, n + 1); if (!np) { LOG_ERROR("Out of memory reading %s", path) ok = false; break; } pat = np; pat_cap = n; }
+            memcpy(pat, line + 1, n - 1); plen = n - 1; have_pat = true;
+        } else if (line[0] == '<') {
+            if (!have_pat) { LOG_ERROR("Malformed .seq file %s: text without pattern.", path) ok = false; break; }
+            if (!set_append(set, pat, plen, line + 1, n - 1)) { ok = false; break; }
+            have_pat = false;
+            if (max_pairs && set->num_pairs >= max_pairs) break;
+        } else { LOG_ERROR("Malformed .seq file %s: lines must start with '>' or '<'.", path) ok = false; break; }
+    }
+    free(line); free(pat); fclose(f);
+    return ok;
+}
+
 bool read_seq_file(sequence_set_t* set, const char* path, size_t max_pairs) {
     const int fd = open(path, O_RDONLY);
     if (fd < 0) { LOG_ERROR("Can not open %s", path) return false; }
     struct stat sb;
     if (fstat(fd, &sb) != 0) { LOG_ERROR("Can not stat %s", path) close(fd); return false; }
+    /* (only a regular file has a size to map and to cut into strips) */
+    if (!S_ISREG(sb.st_mode)) return read_seq_stream(set, fd, path, max_pairs);
     const size_t size = (size_t)sb.st_size;
     if (size == 0) { close(fd); return true; }
     const char* base = (const char*)mmap(NULL, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (base == MAP_FAILED) return read_seq_stream(set, fd, path, max_pairs);
     close(fd);
-    if (base == MAP_FAILED) { LOG_ERROR("Can not map %s", path) return false; }
     (void)madvise((void*)base, size, MADV_WILLNEED);
     /* (with -n only the head of the file is looked at: grown until it holds the pairs asked for) */
     unsigned nt = reader_threads(size);
@@ -231,7 +260,12 @@ bool read_seq_file(sequence_set_t* set, const char* path, size_t max_pairs) {
         }
         if (!set->sequences_buffer) set->sequences_buffer = (char*)malloc(total_bytes + 64);
         set->sequences_metadata = (sequence_pair_t*)malloc((pairs ? pairs : 1) * sizeof(sequence_pair_t));
-        if (!set->sequences_buffer || !set->sequences_metadata) { LOG_ERROR("Out of memory reading %s", path) ok = false; break; }
+        if (!set->sequences_buffer || !set->sequences_metadata) {
+            LOG_ERROR("Out of memory reading %s", path)
+            free(set->sequences_buffer); free(set->sequences_metadata);      /* (whichever of the two was allocated) */
+            set->sequences_buffer = NULL; set->sequences_metadata = NULL;
+            ok = false; break;
+        }
         set->sequences_buffer_size = total_bytes + 64;
         set->metadata_capacity = pairs ? pairs : 1;
         run_strips(st, n_now, true);

@@ -57,8 +57,27 @@ WORKLOADS = {
                   desc="16k HiFi-shaped 10 kbp pairs, 3% error, exact (unbanded), score+CIGAR"),
     "cfg5": dict(pairs=1024, length=30_000, error=0.10, cigar=True, max_error=9000, band=None, steps=25,
                  desc="1024 ONT-shaped 30 kbp pairs, 10% error, exact (unbanded), -e 9000, score+CIGAR"),
+    # the reference's kernels take any penalties (lib/kernels/sequence_distance_kernel.cu:57-160) and its own tests run (5,3,2),
+    # (3,5,2) and (3,1,4) (tests/test_api.c:59-219, tests/test-aligner.sh:11-48): configs[2] / configs[1] under those sets
+    "cfg3_x5o3e2": dict(pairs=1_000_000, length=1000, error=0.05, cigar=True, max_error=600, band=None, steps=50, pen=(5, 3, 2), pairs_like="cfg3",
+                        desc="1M synthetic 1 kbp pairs, 5% error, x=5,o=3,e=2, score+CIGAR"),
+    "cfg3_x3o1e4": dict(pairs=1_000_000, length=1000, error=0.05, cigar=True, max_error=700, band=None, steps=50, pen=(3, 1, 4), pairs_like="cfg3",
+                        desc="1M synthetic 1 kbp pairs, 5% error, x=3,o=1,e=4, score+CIGAR"),
+    "cfg2_x5o3e2": dict(pairs=100_000, length=150, error=0.02, cigar=False, max_error=90, band=None, steps=2000, pen=(5, 3, 2), pairs_like="cfg2",
+                        desc="100k synthetic 150 bp pairs, 2% error, x=5,o=3,e=2, score-only"),
 }
-PEN = (2, 3, 1)
+PEN = (2, 3, 1)      # BASELINE.json's penalties; a workload's own: wl.get("pen", PEN)
+
+
+def pen_of(wl):
+    return tuple(wl.get("pen", PEN))
+
+
+# What one wave instruction of the hot loop's slow class takes on a SIMD (profiles/r04/valu_classes.txt) and what the lean cells cost per
+# 64-diagonal chunk (align/cells_hot.inc): the design's own issue bound, cells/s = 1024 SIMDs x clock / 4.2 x 64 / 28 -- the one yardstick
+# on which configs[2], [3] and [4] (and every penalty set) are comparable.
+ISSUE_CYCLES_PER_VALU = 4.2
+VALU_PER_CHUNK = 28
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -122,7 +141,7 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(buf, meta, compute_cigar, budget_pairs):
+def cpu_baseline(buf, meta, compute_cigar, budget_pairs, pen=PEN):
     """Times the CPU ground truth on the host cores on a bounded sample of the same workload:
     the reference's own WFA2 (oracle/_ref, kind 'reference') when it is there, else the C port."""
     import oracle_lib
@@ -134,10 +153,10 @@ def cpu_baseline(buf, meta, compute_cigar, budget_pairs):
     cores = min(usable_cores(), 64)
     if oracle_lib.have_ref():
         kind = "reference"
-        run = lambda m, nt: oracle_lib.ref_batch(sub, m, PEN, cigar=compute_cigar, memory_mode=1, nthreads=nt)
+        run = lambda m, nt: oracle_lib.ref_batch(sub, m, pen, cigar=compute_cigar, memory_mode=1, nthreads=nt)
     else:
         kind = "port"
-        run = lambda m, nt: oracle_lib.oracle_batch(sub, m, PEN, cigar=compute_cigar, nthreads=nt)
+        run = lambda m, nt: oracle_lib.oracle_batch(sub, m, pen, cigar=compute_cigar, nthreads=nt)
     reps = 0
     t0 = time.perf_counter()
     while True:
@@ -162,7 +181,7 @@ def cpu_baseline(buf, meta, compute_cigar, budget_pairs):
         try:
             reps2, t2 = 0, time.perf_counter()
             while True:
-                oracle_lib.refcpu_batch(sub, pairs_meta, PEN, cigar=compute_cigar, nthreads=cores)
+                oracle_lib.refcpu_batch(sub, pairs_meta, pen, cigar=compute_cigar, nthreads=cores)
                 reps2 += 1
                 d2 = time.perf_counter() - t2
                 if d2 >= 1.0 or reps2 >= 100:
@@ -193,7 +212,7 @@ def host_to_host(buf, meta, wl, max_error, n_devices=1, reps=8, registered=False
     band = wl["band"]
     opt = wfagpu.Options(max_error=max_error, threads_per_block=band[1] if band else 64, num_workers=0,
                          band=band[0] if band else -1, batch_size=n, num_alignments=n,
-                         penalties=wfagpu.Penalties(*PEN), compute_cigar=wl["cigar"])
+                         penalties=wfagpu.Penalties(*pen_of(wl)), compute_cigar=wl["cigar"])
     fn = lib.launch_alignments if wl["cigar"] else lib.launch_alignments_distance
     wfagpu.configure_launch(num_devices=n_devices, tuning=tuning or {}, **(launch_cfg or {}))
     meta = meta.copy()
@@ -300,9 +319,17 @@ def build_roofline(workload, st, main_ms, launches_per_step, all_ms, compute_cig
         busy = pmc["SQ_ACTIVE_INST_VALU"] * 4.0                              # VALU-busy SIMD-cycles of the launch (work-invariant)
         peak = simds * clock / 1e9                                           # G SIMD-cycles per second the chip has
         ach = busy / secs / 1e9
-        r.update({"bound": "valu-issue", "unit": "G VALU-busy SIMD-cycles/s", "achieved": round(ach, 2), "peak": round(peak, 2),
-                  "frac": round(ach / peak, 4),
-                  "frac_formula": "SQ_ACTIVE_INST_VALU x 4 / live kernel seconds / (1024 SIMDs x clock of the PMC pass)",
+        # `frac`: VALU busy INSIDE the PMC pass (busy SIMD-cycles / SIMD-cycles of that pass: a measurement); the same busy cycles over
+        # the faster un-profiled launch at the PMC pass's clock (`frac_live_upper_bound`) is an upper bound, not a measurement.
+        busy_pmc = busy / simds / cyc
+        issue_peak = simds * clock / ISSUE_CYCLES_PER_VALU * 64.0 / VALU_PER_CHUNK          # cells/s of the design's hot loop at full issue
+        r.update({"bound": "valu-issue", "unit": "G VALU-busy SIMD-cycles/s", "achieved": round(busy_pmc * peak, 2), "peak": round(peak, 2),
+                  "frac": round(busy_pmc, 4),
+                  "frac_formula": "SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), both of the committed PMC pass",
+                  "frac_live_upper_bound": round(ach / peak, 4),
+                  "issue_bound_cells_per_s": round(issue_peak, 1),
+                  "issue_bound_frac": round(cells / secs / issue_peak, 4),
+                  "issue_bound_formula": "cells/s / (1024 SIMDs x clock / 4.2 cycles per wave instruction x 64 cells / 28 instructions per chunk)",
                   "clock_ghz_pmc_pass": round(clock / 1e9, 3), "pmc_kernel_ms": round(pmc["_ms_GRBM_GUI_ACTIVE"], 4),
                   "valu_busy_pmc_pass": round(busy / simds / cyc, 4),
                   "salu_busy_pmc_pass": round(pmc["SQ_ACTIVE_INST_SCA"] * 4 / simds / cyc, 4) if pmc.get("SQ_ACTIVE_INST_SCA") else None,
@@ -315,6 +342,10 @@ def build_roofline(workload, st, main_ms, launches_per_step, all_ms, compute_cig
                 if c in pmc:
                     r[k] = round(pmc[c] / pmc["SQ_WAVE_CYCLES"], 3)
     else:
+        # (no counters for this command: the issue bound at the chip's nominal engine clock)
+        nominal = 1024 * 2.4e9 / ISSUE_CYCLES_PER_VALU * 64.0 / VALU_PER_CHUNK
+        r.update({"issue_bound_cells_per_s": round(nominal, 1), "issue_bound_frac": round(cells / secs / nominal, 4) if secs > 0 else None,
+                  "issue_bound_formula": "cells/s / (1024 SIMDs x 2.4 GHz nominal / 4.2 cycles per wave instruction x 64 cells / 28 instructions per chunk)"})
         r.update({"bound": "hbm", "unit": "GB/s", "achieved": r["hbm_algorithmic_GBps"], "peak": HBM_PEAK_GBS, "frac": r["hbm_algorithmic_frac"],
                   "frac_formula": "SURVEY 8(d) algorithmic bytes / live kernel seconds / 8 TB/s (no PMC pass committed for this command: "
                                   "the kernel is issue-bound, see DESIGN.md)"})
@@ -325,8 +356,11 @@ def parity_sample(buf, meta, wl, n_pairs, d_scores, ptrs, st, band):
     """Parity spot check OUTSIDE the timed region: a sample of the last timed step's outputs against the checker."""
     import oracle_lib
     import wfagpu
+    PEN = pen_of(wl)      # (this function's penalties)
     try:
         k = min(2000 if wl["length"] <= 1000 else (64 if wl["length"] <= 10000 else 8), n_pairs)
+        if band and wl.get("force_band"):
+            k = min(1024, n_pairs)      # (the banded-CIGAR corrections are counted on a larger sample: scores against the band rule and WFA2 scores only)
         scores = d_scores[:k].cpu().numpy()
         if oracle_lib.have_ref():
             so, co = oracle_lib.ref_batch(buf, meta[:k], PEN, cigar=wl["cigar"], memory_mode=0, nthreads=min(16, usable_cores()))
@@ -346,6 +380,8 @@ def parity_sample(buf, meta, wl, n_pairs, d_scores, ptrs, st, band):
                     # (CIGAR mode reports the cost of the CIGAR returned: below the rule's forward score where two gaps of a kind
                     # that the band made the search open back to back print as one)
                     "pairs_below_the_rules_forward_score": int((scores < want).sum()),
+                    # (each such place saves whole gap openings: the reported cost below the rule's forward score, min .. max)
+                    "saved_below_the_rule_min_max": [int((want - scores)[scores < want].min()), int((want - scores)[scores < want].max())] if (scores < want).any() else [0, 0],
                     "equal_to_the_reference_band_rule": int((scores == want).sum()),
                     "reference_band_rule_recall": float(((sr >= 0) & (sr == so)).mean())}
         return {"pairs": k, "bit_exact_vs_oracle": bool(np.array_equal(scores, so)) and (not wl["cigar"] or cg == co)}
@@ -353,10 +389,11 @@ def parity_sample(buf, meta, wl, n_pairs, d_scores, ptrs, st, band):
         return {"error": str(ex)}
 
 
-def make_pairs(name, n_pairs, seed):
+def make_pairs(name, n_pairs, seed, world=1):
+    """(world: ranks generating at once on this host -- each takes its share of the cores, not 16 threads apiece)"""
     import wfagpu
     wl = WORKLOADS[name]
-    return wfagpu.generate_pairs(n_pairs, wl["length"], wl["error"], seed=seed, nthreads=min(16, usable_cores()))
+    return wfagpu.generate_pairs(n_pairs, wl["length"], wl["error"], seed=seed, nthreads=max(1, min(16, usable_cores() // max(1, world))))
 
 
 def settle(seconds=3.0):
@@ -387,7 +424,7 @@ def resident_leg(name, n_pairs, max_error, steps, warmup, device, seed, tuning, 
     d_scores_buf = torch.empty(max(len(meta), 1), dtype=torch.int32, device=torch.device("cuda", device))
 
     def step():
-        last["out"] = al.align(batch, PEN, max_error=max_error, compute_cigar=wl["cigar"], band=band[0] if band else -1,
+        last["out"] = al.align(batch, pen_of(wl), max_error=max_error, compute_cigar=wl["cigar"], band=band[0] if band else -1,
                                band_width=band[1] if band else 0, fetch=False, d_scores=d_scores_buf)
         st = al.stats()
         acc["align_ms"] += st.align_ms
@@ -453,13 +490,15 @@ def cli_wall(n_pairs=1_000_000, length=1000, error=0.05, max_error=300, runs=2):
         t0 = time.perf_counter()
         subprocess.run([cli, "-i", small, "-x", "-e", str(max_error)], capture_output=True, text=True, timeout=600)
         first_process_s = round(time.perf_counter() - t0, 3)
-        walls, proc, stages, reads = [], [], [], []
+        walls, proc, stages, reads, waits = [], [], [], [], []
         for _ in range(runs):
             t0 = time.perf_counter()
             # (--stage-times: the library's own stage clocks of the call on stderr, so that a slow run says where it was slow)
             r = subprocess.run([cli, "-i", seq, "-x", "-e", str(max_error), "--stage-times"], capture_output=True, text=True, timeout=600)
             proc.append(round(time.perf_counter() - t0, 3))
             m = re.search(r"Wall time: ([0-9.]+)s \(([0-9.]+) alignments per second\)", r.stdout)
+            bw = re.search(r"Device bring-up waited for before the clock: ([0-9.]+)s", r.stdout)
+            waits.append(float(bw.group(1)) if bw else None)
             if r.returncode != 0 or not m:
                 return {"error": f"exit code {r.returncode}: {(r.stderr or r.stdout)[-300:]}"}
             walls.append((float(m.group(1)), float(m.group(2))))
@@ -474,11 +513,18 @@ def cli_wall(n_pairs=1_000_000, length=1000, error=0.05, max_error=300, runs=2):
     return {"what": "bin/wfa.affine.gpu -i <1M x 1 kbp @ 5 % .seq> -x -e 300, fresh process per run: the 'Wall time' line it prints",
             "unit": "alignments/s", "pairs": n_pairs, "value": round(max(w[1] for w in walls), 1), "wall_s": [w[0] for w in walls],
             "alignments_per_s": [w[1] for w in walls], "best_wall_ms": round(best[0] * 1e3, 1), "process_s": proc, "file_read_s": reads,
+            # (the tool waits for the device's background bring-up in FRONT of its clock -- the reference's CUDA context exists when its
+            # clock starts, its allocations and module load do not: the wait is reported beside the wall it is not part of)
+            "bring_up_wait_s": waits, "bring_up_wait_ms": round(min(w for w in waits if w is not None) * 1e3, 1) if any(w is not None for w in waits) else None,
+            "wall_plus_bring_up_wait_ms": round(min((w[0] + (bw or 0.0)) for w, bw in zip(walls, waits)) * 1e3, 1),
             "stage_clocks": stages, "generate_s": round(gen_s, 2),
             "untimed_first_process_s": first_process_s, "untimed_first_process": "the tool on 2000 pairs, once, before the timed runs: maps the shared objects on a box that may not have run anything yet"}
 
 
-def ont_banded_leg(n=1024, length=30_000, reps=2):
+ONT_POINTS = ((512, 25), (1024, 25), (1024, 100))      # (beta, lambda) kept in the default line; --ont-banded-only runs the whole grid
+
+
+def ont_banded_leg(n=1024, length=30_000, reps=2, full=False):
     """The reference's only published experiment, in shape (README.md:125-137 of the reference, img/approximate-time.png /
     approximate-recall.png; BASELINE.md section 1: exact ~4400 s against beta 512 ~990-1900 s and beta 1024 ~1640-5070 s, recall
     96.8-99.9 %, on a Nanopore set): ONT-shaped 30 kbp pairs, the exact search against the adaptive band over the same grid,
@@ -493,7 +539,9 @@ def ont_banded_leg(n=1024, length=30_000, reps=2):
             ("long_read_shaped", lambda: wfagpu.generate_pairs_model(n, length, seed=1001, error=0.06, indel_frac=0.6, indel_mean=2.5, long_frac=0.02,
                                                                      long_min=30, long_max=150, cluster=0.3, nthreads=nt), 12000))
     out = {"what": f"{n} x {length // 1000} kbp pairs, penalties x=2,o=3,e=1, score + CIGAR, resident batch; ms = best of {reps} steps after a warm-up",
-           "grid": "beta x lambda = the reference's README.md:125-137"}
+           "grid": "beta x lambda = the reference's README.md:125-137" if full else
+                   "three operating points of the reference's beta x lambda grid (README.md:125-137); the whole grid: `bench.py --ont-banded-only`, "
+                   "committed as profiles/r06/ont_banded_grid.json"}
     for name, gen, me in sets:
         buf, meta = gen()
         al = wfagpu.DeviceAligner(0)
@@ -517,6 +565,8 @@ def ont_banded_leg(n=1024, length=30_000, reps=2):
                "rows": []}
         for beta in (352, 512, 1024):
             for lam in (10, 25, 50, 100, 750):
+                if not full and (beta, lam) not in ONT_POINTS:
+                    continue
                 r, sc = run(lam, beta)
                 rec["rows"].append({"beta": beta, "lambda": lam, "ms": round(r[0], 2), "kernel_ms": round(r[1], 2), "tier": r[3],
                                     "speedup": round(ex[0] / r[0], 2), "kernel_speedup": round(ex[1] / r[1], 2),
@@ -529,42 +579,79 @@ def ont_banded_leg(n=1024, length=30_000, reps=2):
     return out
 
 
-def extra_config(name, steps, warmup):
-    """A short leg of another BASELINE configuration on this GPU, everything the headline carries in small: resident value,
-    kernel time + issue fraction, parity sample, host-to-host rate, CPU baseline."""
+def extra_config(name, steps, warmup, data=None, h2h_leg=True, cpu_leg=True):
+    """A short leg of another configuration on this GPU, everything the headline carries in small: resident value,
+    kernel time + issue fraction + cells/s, parity sample, host-to-host rate, CPU baseline.  data: the pairs of a workload that shares
+    another's (configs[2] under other penalties: the headline's own pairs)."""
     wl = WORKLOADS[name]
     force_band = bool(wl.get("force_band"))
     tuning = {"force_band": 1} if force_band else {}
     t0 = time.perf_counter()
     n = wl["pairs"]
-    buf, meta = make_pairs(name, n, 1000)
-    # (host to host FIRST, on a device nobody has just released tens of GB on: see settle())
-    settle(2.0)
+    buf, meta = data if data is not None else make_pairs(wl.get("pairs_like", name), n, 1000)
     h2h_out = {}
-    try:
-        h2h = host_to_host(buf, meta, wl, wl["max_error"], tuning=tuning, reps=3)
-        h2h_out = {"host_to_host_value": h2h["pageable"]["warm"], "host_to_host_ms_per_call": h2h["pageable"]["warm_ms"],
-                   "host_to_host_cold_ms": h2h["pageable"]["cold_ms"], "host_to_host_calls_ms": h2h["pageable"]["calls_ms"],
-                   "host_to_host_max_over_median": h2h["pageable"]["max_over_median"]}
-    except Exception as ex:
-        h2h_out = {"host_to_host_value": None, "host_to_host_error": str(ex)}
+    if h2h_leg:
+        # (host to host FIRST, on a device nobody has just released tens of GB on: see settle())
+        settle(2.0)
+        try:
+            h2h = host_to_host(buf, meta, wl, wl["max_error"], tuning=tuning, reps=3)
+            h2h_out = {"host_to_host_value": h2h["pageable"]["warm"], "host_to_host_ms_per_call": h2h["pageable"]["warm_ms"],
+                       "host_to_host_cold_ms": h2h["pageable"]["cold_ms"], "host_to_host_calls_ms": h2h["pageable"]["calls_ms"],
+                       "host_to_host_max_over_median": h2h["pageable"]["max_over_median"]}
+        except Exception as ex:
+            h2h_out = {"host_to_host_value": None, "host_to_host_error": str(ex)}
     rec, buf, meta = resident_leg(name, n, wl["max_error"], steps, warmup, 0, 1000, tuning, True, use_pmc=True, data=(buf, meta))
     rf = rec["roofline"]
-    out = {"workload": wl["desc"], "pairs": n, "steps": steps, "warmup": warmup,
+    out = {"workload": wl["desc"], "pairs": n, "steps": steps, "warmup": warmup, "penalties": "x=%d,o=%d,e=%d" % pen_of(wl),
            "value": round(n * steps / rec["elapsed"], 1), "unit": "alignments/s", "ms_per_step": round(rec["ms_per_step"], 3),
            "gcups": round(rec["dptt"] * steps / rec["elapsed"] / 1e9, 2),
-           "kernel_ms": rf["kernel_ms"], "tier": rf["tier"], "roofline_bound": rf["bound"], "roofline_frac": rf["frac"],
+           "kernel_ms": rf["kernel_ms"], "tier": rf["tier"], "cells_per_launch": rf["cells_per_launch"], "cells_per_s": rf["cells_per_s"],
+           "issue_bound_frac": rf.get("issue_bound_frac"), "roofline_bound": rf["bound"], "roofline_frac": rf["frac"],
            "roofline_source": rf["traffic_source"], "pmc_stale": rf["pmc_stale"],
            "stage_ms_per_step": rec["stage_ms_per_step"], "pairs_per_tier": rec["tiers"]["pairs_per_tier"],
            "pairs_banded": rec["tiers"]["pairs_banded"], "auto_budget": rec["tiers"]["auto_budget"],
            "parity_sample": rec["parity_sample"]}
     out.update(h2h_out)
-    if not force_band:
+    if not force_band and cpu_leg:
         per_pair_us = 2.0 if wl["length"] <= 200 else 95.0 * (wl["length"] / 1000.0) ** 2
-        cb = cpu_baseline(buf, meta, wl["cigar"], int(max(16, min(n, 4e6 / per_pair_us))))
+        cb = cpu_baseline(buf, meta, wl["cigar"], int(max(16, min(n, 4e6 / per_pair_us))), pen=pen_of(wl))
         out["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample", "reference_shim") if k in cb}
     out["leg_s"] = round(time.perf_counter() - t0, 1)
     return out
+
+
+def summary_of(out):
+    """The numbers SURVEY.md section 8(d) asks for, flat and short: resident value, the reference's own metric (wall of
+    launch_alignments, PCIe both ways), the CLI's printed wall time, the CPU baselines, every other configuration's value and the main
+    kernel's fractions."""
+    rf = out.get("roofline") or {}
+    cb = out.get("cpu_baseline") or {}
+    cw = out.get("cli_wall") or {}
+    sm = {"value": out.get("value"), "ms_per_step": out.get("ms_per_step"),
+          "host_to_host_value": out.get("host_to_host_value"), "host_to_host_ms_per_call": out.get("host_to_host_ms_per_call"),
+          "host_to_host_cold_ms": out.get("host_to_host_cold_ms"), "host_to_host_max_over_median": out.get("host_to_host_max_over_median"),
+          "cli_wall_value": out.get("cli_wall_value"), "cli_wall_ms": cw.get("best_wall_ms"), "cli_bring_up_wait_ms": cw.get("bring_up_wait_ms"),
+          "cpu_baseline_value": cb.get("value"), "cpu_baseline_cores": cb.get("cores"),
+          "cpu_baseline_shim_value": (cb.get("reference_shim") or {}).get("value"),
+          "main_kernel_ms": rf.get("kernel_ms"), "cells_per_s": rf.get("cells_per_s"), "valu_busy_frac": rf.get("frac") if rf.get("bound") == "valu-issue" else None,
+          "issue_bound_frac": rf.get("issue_bound_frac"), "hbm_algorithmic_frac": rf.get("hbm_algorithmic_frac"),
+          "parity_sample_ok": (out.get("parity_sample") or {}).get("bit_exact_vs_oracle"),
+          "n_gpus": out.get("n_gpus"), "library_call_value": out.get("library_call_value")}
+    for key, leg in (out.get("configs") or {}).items():
+        sm[f"{key}_value"] = leg.get("value")
+        sm[f"{key}_kernel_ms"] = leg.get("kernel_ms")
+        if key.startswith("cfg3_") or key == "cfg2_x5o3e2":
+            sm[f"{key}_cells_per_s"] = leg.get("cells_per_s")
+            sm[f"{key}_tier"] = leg.get("tier")
+        if leg.get("host_to_host_value") is not None:
+            sm[f"{key}_host_to_host_value"] = leg.get("host_to_host_value")
+        ps = leg.get("parity_sample") or {}
+        sm[f"{key}_parity_ok"] = ps.get("bit_exact_vs_oracle", ps.get("valid_and_cost_equals_score"))
+    ob = out.get("ont_banded") or {}
+    for ds in ("iid_10pct", "long_read_shaped"):
+        if isinstance(ob.get(ds), dict):
+            sm[f"ont_{ds}_exact_ms"] = ob[ds].get("exact_ms")
+    return sm
 
 
 def main():
@@ -618,7 +705,7 @@ def main():
     if args.mode == "library":
         return library_mode(args, wl, n_pairs, max_error, steps)
     if args.ont_banded_only:
-        print(json.dumps({"ont_banded": ont_banded_leg()}))
+        print(json.dumps({"ont_banded": ont_banded_leg(full=True)}))
         return
 
     dist = None
@@ -636,7 +723,7 @@ def main():
     if wl.get("force_band"):
         tuning["force_band"] = 1      # (part of the workload: cfg4b IS configs[3] on the banded kernels)
         args.force_band = True
-    data = make_pairs(args.workload, n_pairs, shardlib.shard_seed(1000, rank))
+    data = make_pairs(WORKLOADS[args.workload].get("pairs_like", args.workload), n_pairs, shardlib.shard_seed(1000, rank), world=world)
     pre = {}
     if rank == 0 and world == 1:
         # The legs that measure COLD calls come first, before this process has allocated (and released) anything big:
@@ -686,7 +773,7 @@ def main():
             "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {wl['desc']}", "pairs_per_gpu_per_step": n_pairs, "length": wl["length"],
-                       "error": wl["error"], "penalties": "x=2,o=3,e=1", "max_error": max_error,
+                       "error": wl["error"], "penalties": "x=%d,o=%d,e=%d" % pen_of(wl), "max_error": max_error,
                        "compute_cigar": wl["cigar"],
                        "budgets": "tuned on a sample in the warm-up, inherited by the timed steps (same stream of reads)" if rec["inherit"]
                                   else "tuned on a sample in every step",
@@ -710,15 +797,23 @@ def main():
             # ~10-30 s of CPU work: bounded sample of the same workload
             per_pair_us = 2.0 if wl["length"] <= 200 else 95.0 * (wl["length"] / 1000.0) ** 2
             budget = int(max(16, min(n_pairs, 20e6 / per_pair_us)))
-            out["cpu_baseline"] = cpu_baseline(buf, meta, wl["cigar"], budget)
+            out["cpu_baseline"] = cpu_baseline(buf, meta, wl["cigar"], budget, pen=pen_of(wl))
         if default_cmd and args.workload == "cfg3" and not args.no_configs:
+            out["configs"] = {}
+            # configs[2] under the reference's other penalty sets, on the headline's own pairs (resident legs only)
+            for key, name, k, w in (("cfg3_x5o3e2", "cfg3_x5o3e2", 6, 2), ("cfg3_x3o1e4", "cfg3_x3o1e4", 6, 2)):
+                try:
+                    out["configs"][key] = extra_config(name, k, w, data=(buf, meta), h2h_leg=False, cpu_leg=False)
+                except Exception as ex:
+                    out["configs"][key] = {"error": str(ex)}
             del buf, meta, data
             # the other BASELINE GPU configurations, short legs (~60 s together)
-            out["configs"] = {}
-            for key, name, k, w in (("cfg2", "cfg2", 400, 5), ("cfg2_with_cigar", "cfg2c", 200, 5), ("cfg4", "cfg4", 8, 3), ("cfg4_band_forced", "cfg4b", 8, 3),
-                                    ("cfg5", "cfg5", 4, 2)):
+            for key, name, k, w, h2h_leg, cpu_leg in (("cfg2", "cfg2", 400, 5, True, True), ("cfg2_with_cigar", "cfg2c", 200, 5, True, True),
+                                                      ("cfg2_x5o3e2", "cfg2_x5o3e2", 400, 5, False, False),
+                                                      ("cfg4", "cfg4", 8, 3, True, True), ("cfg4_band_forced", "cfg4b", 8, 3, True, True),
+                                                      ("cfg5", "cfg5", 4, 2, True, True)):
                 try:
-                    out["configs"][key] = extra_config(name, k, w)
+                    out["configs"][key] = extra_config(name, k, w, h2h_leg=h2h_leg, cpu_leg=cpu_leg)
                 except Exception as ex:
                     out["configs"][key] = {"error": str(ex)}
             for key, leg in out["configs"].items():      # (flat copies: the driver's record keeps top-level scalars)
@@ -732,6 +827,8 @@ def main():
                     out["ont_banded_beta1024_lambda100_recall"] = r1024[0]["recall"]
             except Exception as ex:
                 out["ont_banded"] = {"error": str(ex)}
+        # (the LAST key of the line -- the driver's record keeps the tail of a long line -- is `summary`, the contract's numbers in one
+        # flat object: added where the line is printed)
     if dist is not None:
         # N > 1: the ranks above never share anything but the barrier.  The reference's user calls launch_alignments()
         # ONCE and the library shards the call over the N devices from one process: host RAM bandwidth, the PCIe root and
@@ -762,7 +859,35 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        out.pop("summary", None)
+        out["summary"] = summary_of(out)      # (the last key, whatever was added since)
         print(json.dumps(out))
+
+
+def device_topology(n):
+    """PCIe bus id and NUMA node of the first n HIP devices (sysfs): with the per-device stage times, what makes the first record of
+    a real multi-GPU node diagnosable from its line alone (which devices share a root, which host threads sat on which node)."""
+    import ctypes as C
+    import wfagpu
+    out = []
+    try:
+        hip = wfagpu._hiprt()
+        hip.hipDeviceGetPCIBusId.argtypes = [C.c_char_p, C.c_int, C.c_int]
+        hip.hipDeviceGetPCIBusId.restype = C.c_int
+    except Exception as ex:
+        return [{"error": str(ex)}]
+    for d in range(n):
+        b = C.create_string_buffer(64)
+        rc = hip.hipDeviceGetPCIBusId(b, 64, d)
+        bdf = b.value.decode().lower() if rc == 0 else None
+        node = None
+        if bdf:
+            try:
+                node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read().strip())
+            except (OSError, ValueError):
+                node = None
+        out.append({"device": d, "pcie_bdf": bdf, "numa_node": node})
+    return out
 
 
 def library_mode(args, wl, n_pairs, max_error, steps):
@@ -778,7 +903,7 @@ def library_mode(args, wl, n_pairs, max_error, steps):
     band = wl["band"]
     opt = wfagpu.Options(max_error=max_error, threads_per_block=band[1] if band else 64, num_workers=0,
                          band=band[0] if band else -1, batch_size=n, num_alignments=n,
-                         penalties=wfagpu.Penalties(*PEN), compute_cigar=wl["cigar"])
+                         penalties=wfagpu.Penalties(*pen_of(wl)), compute_cigar=wl["cigar"])
     fn = lib.launch_alignments if wl["cigar"] else lib.launch_alignments_distance
     wfagpu.configure_launch(num_devices=args.gpus, virtual_devices=args.virtual_devices,
                             tuning={"force_band": 1} if args.force_band else {})
@@ -802,12 +927,16 @@ def library_mode(args, wl, n_pairs, max_error, steps):
                 "host_pack_threads": d["host_pack_threads"], "upload_ms": round(d["upload_ms"], 2), "device_ms": round(d["device_ms"], 2),
                 "device_wait_ms": round(d["device_wait_ms"], 2), "scatter_ms": round(d["scatter_ms"], 2)}
                for i, d in enumerate(wfagpu.last_launch_stats_per_device())]
+    topo = {t.get("device"): t for t in device_topology(nd.value)}
+    for d in per_dev:      # (where the slot's device sits: PCIe bus id, NUMA node)
+        d.update({k: v for k, v in (topo.get(d["device"]) or {}).items() if k != "device"})
     dptt = int((meta["pattern_len"].astype(np.int64) * meta["text_len"].astype(np.int64)).sum())
     out = {"metric": "alignments_per_sec", "value": round(n * steps / elapsed, 1), "unit": "alignments/s",
+           "host_cores": usable_cores(), "host_numa_nodes": len([d for d in os.listdir("/sys/devices/system/node") if d.startswith("node")]) if os.path.isdir("/sys/devices/system/node") else None,
            "n_gpus": args.gpus, "steps": steps, "warmup": max(1, args.warmup), "ms_per_step": round(elapsed / steps * 1e3, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
            "config": {"workload": f"{args.workload}: {wl['desc']}", "pairs_per_gpu_per_step": n_pairs, "length": wl["length"],
-                      "error": wl["error"], "penalties": "x=2,o=3,e=1", "max_error": max_error, "compute_cigar": wl["cigar"],
+                      "error": wl["error"], "penalties": "x=%d,o=%d,e=%d" % pen_of(wl), "max_error": max_error, "compute_cigar": wl["cigar"],
                       "sharding": f"one launch_alignments() call sharded in-library over {args.gpus} devices, no collective",
                       "mode": "library (host buffer -> host results, PCIe inclusive)"},
            "gcups": round(dptt * steps / elapsed / 1e9, 2), "first_result": int(res[0].error),
@@ -825,7 +954,8 @@ def cpu_harness(args, rank, world, n_pairs, steps):
     import wfagpu
     dist = shardlib.init_distributed("gloo") if (world > 1 or (args.force_dist and "WORLD_SIZE" in os.environ)) else None
     n = min(n_pairs, 64)
-    buf, meta = wfagpu.generate_pairs(n, 120, 0.05, seed=shardlib.shard_seed(1000, rank))
+    gen_threads = max(1, min(16, usable_cores() // max(1, world)))      # (what make_pairs gives a rank of the GPU run)
+    buf, meta = wfagpu.generate_pairs(n, 120, 0.05, seed=shardlib.shard_seed(1000, rank), nthreads=gen_threads)
     state = {}
 
     def step():
@@ -842,7 +972,7 @@ def cpu_harness(args, rank, world, n_pairs, steps):
     if rank == 0:
         print(json.dumps({"metric": "alignments_per_sec", "harness_only": True, "n_gpus": world, "steps": steps,
                           "warmup": args.warmup, "value": n * steps * world / elapsed, "unit": "alignments/s",
-                          "ms_per_step": elapsed / steps * 1e3, "scaling": "weak", "library_call": excl,
+                          "ms_per_step": elapsed / steps * 1e3, "scaling": "weak", "library_call": excl, "generator_threads_per_rank": gen_threads,
                           "per_rank": [{"rank": r, "ms_per_step": e / steps * 1e3, "value": n * steps / e} for r, e in enumerate(per_rank)]}))
 
 

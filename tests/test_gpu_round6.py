@@ -77,3 +77,39 @@ def test_pack_soak_behind_a_busy_null_stream(mode):
         finally:
             al.close()
     torch.cuda.synchronize()
+
+
+def _truth(buf, meta, pen, cigar=True):
+    if oracle_lib.have_ref():
+        return oracle_lib.ref_batch(buf, meta, pen, cigar=cigar, memory_mode=0, nthreads=16)
+    s, c, _ = oracle_lib.oracle_batch(buf, meta, pen, cigar=cigar, nthreads=16)
+    return s, c
+
+
+def test_small_batch_of_long_reads_tries_the_widest_lds_budget_first():
+    """44 x 30 kbp pairs under -e 14000 (too few pairs for a budget sample; the caller's ceiling only fits the HBM-ring tier): the
+    chain first runs under the largest budget the hybrid tier holds -- 40 pairs at 10 % finish there --, the 4 pairs at 16 % miss it
+    and are escalated to the HBM ring.  Scores and CIGAR strings are the checker's either way (the same pairs
+    took 170 ms on tier 3 against 70 on the hybrid tier)."""
+    pen = (2, 3, 1)
+    buf_a, meta_a = wfagpu.generate_pairs(40, 30_000, 0.10, seed=77)
+    buf_b, meta_b = wfagpu.generate_pairs(4, 30_000, 0.16, seed=78)
+    pairs = wfagpu.pairs_from_layout(buf_a, meta_a) + wfagpu.pairs_from_layout(buf_b, meta_b)
+    buf, meta = wfagpu.layout_pairs(pairs)
+    so, co = _truth(buf, meta, pen)
+    assert int(so[:40].max()) < 10_000 < int(so[40:].min()) and int(so.max()) < 14_000
+    al = wfagpu.DeviceAligner(0)
+    try:
+        batch = al.upload(buf, meta)
+        for cigar in (True, False):
+            s, c = al.align(batch, pen, max_error=14_000, compute_cigar=cigar)
+            st = al.stats()
+            assert np.array_equal(s, so)
+            if cigar:
+                assert c == co
+            assert st.pairs_tier[4] == 40 and st.pairs_tier[3] == 4, list(st.pairs_tier)
+        # a ceiling the hybrid tier holds is taken as it is
+        s, c = al.align(batch, pen, max_error=9_500, compute_cigar=True)
+        assert np.array_equal(s, so) and c == co
+    finally:
+        al.close()

@@ -918,6 +918,25 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
           fprintf(stderr, "[!] ERROR: sequences of %u bases do not fit the LDS staging area\n", max_len);
           return -1;
         }
+        // The last resort (tier 3: the whole ring in HBM / L2) costs 2.4x the hybrid tier per cell (1024 x 30 kbp pairs whose scores are
+        // ~8200: 170 ms under -e 12000 against 70 ms under -e 9000, BENCH_r05 ont_banded.long_read_shaped) -- and the budget that sent
+        // the pairs there is the caller's guess of a CEILING (the CLI's default: a tenth of the length times the largest penalty).
+        // Where no budgets were tuned (batches too small for a sample, the exact re-run of a banded launch's misses) and the caller's
+        // budget only fits tier 3, the chain first runs under the LARGEST budget an LDS tier holds; whoever misses it is escalated like
+        // any other failure (4x the budget: the HBM ring then).  Results stay exact: a pair that finishes within a budget has its
+        // optimal score, whatever the budget was (the window argument of the kernel).
+        if (ap.band_width == 0 && tp.tier == 3 && !budget_round && !c->tuning.min_tier && !raw && max_score > 256 && max_score <= 30000 && max_len <= 32766u) {
+          int lo_s = 128, hi_s = max_score;      // fits(lo_s) assumed, fits(hi_s) false
+          TierPlan tq;
+          auto fits = [&](const int S) { WfaAlignParams probe = ap; return plan_tier(c, probe, S, max_len, cigar_now, raw, &tq, few_pairs) && tq.tier != 3; };
+          if (fits(lo_s)) {
+            while (hi_s - lo_s > 8) { const int mid = lo_s + (hi_s - lo_s) / 2; if (fits(mid)) lo_s = mid; else hi_s = mid; }
+            // (worth a pass of its own only when it covers most of the caller's range: below half of it the pairs that the caller
+            // expects near its ceiling would all run twice)
+            if (lo_s >= max_score / 2 && plan_tier(c, ap, lo_s, max_len, cigar_now, raw, &tp, few_pairs) && tp.tier != 3) max_score = lo_s;
+            else if (!plan_tier(c, ap, max_score, max_len, cigar_now, raw, &tp, few_pairs)) return -1;
+          }
+        }
         L.tier = tp.tier;
         if (tp.tier == 3 || tp.tier == 4) {
           ap.ring16 = max_len <= 32766u ? 1 : 0;

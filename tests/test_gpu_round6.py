@@ -107,7 +107,8 @@ def test_small_batch_of_long_reads_tries_the_widest_lds_budget_first():
             assert np.array_equal(s, so)
             if cigar:
                 assert c == co
-            assert st.pairs_tier[4] == 40 and st.pairs_tier[3] == 4, list(st.pairs_tier)
+            # (a pair that runs out of arena on the HBM-ring tier is launched again in the next pass and counted again)
+            assert st.pairs_tier[4] == 40 and st.pairs_tier[3] >= 4 and sum(st.pairs_tier[:3]) == 0, list(st.pairs_tier)
         # a ceiling the hybrid tier holds is taken as it is
         s, c = al.align(batch, pen, max_error=9_500, compute_cigar=True)
         assert np.array_equal(s, so) and c == co

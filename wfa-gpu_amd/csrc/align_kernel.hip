@@ -202,6 +202,12 @@ wfa_align_kernel(const WfaAlignParams p) {
   // re-centring jump the generic cells range-check every read.
   constexpr bool HOT = !GLOBAL_RING && sizeof(OffT) == 2;
   constexpr bool HM_ROW = HOT && !HYBRID && NW == 1 && !BANDED;
+  // TILED (round 6): the origin bytes of the one-wave exact tier go into a block of TILES that the alignment owns as a whole --
+  // 64-byte tiles of 4 scores x 16 diagonals, tile (s >> 2, (k - wlo) >> 4) at a fixed pitch, byte (s & 3) * 16 + ((k - wlo) & 15) -- instead
+  // of one bump-allocated row per score behind a row table (wfa_device.h).  The backward walk of a 1 kbp alignment then touches ~35
+  // cache lines instead of 74 (55 origin bytes on 55 lines + 19 lines of row table: wfa_walk_kernel is bound by random 64-byte
+  // accesses), and a score of the lean loops neither sizes, claims nor records a row: no refill test, no row-table entry.
+  constexpr bool TILED = BT && HOT && !HYBRID && NW == 1 && !BANDED;
   const int GZ = BANDED ? 4 * dm + 2 : 0;
   const int x = p.x, oe = p.oe, e = p.e;
 
@@ -273,6 +279,7 @@ wfa_align_kernel(const WfaAlignParams p) {
     const int pwords = RAW ? ((plen + 3) >> 2) + 1 : ((plen + 15) >> 4) + 1;
     const int twords = RAW ? ((tlen + 3) >> 2) + 1 : ((tlen + 15) >> 4) + 1;
 
+    typedef __attribute__((address_space(1))) uint8_t* GlobalBytes;
     uint32_t status = WFA_ST_DONE;
     int s = 0;
     uint32_t ncells = 1;
@@ -401,7 +408,26 @@ wfa_align_kernel(const WfaAlignParams p) {
         return base != WFA_ROW_NONE;
       };
       // ---- score 0: M[0][0] = extend(0) ------------------------------------------------------
-      if constexpr (BT) {
+      // (TILED) the alignment's block of tiles: 64-byte header {marker, wlo, tile columns, budget} + ((budget >> 2) + 1) groups of
+      // tile_cols tiles + four tiles of slack (the lanes of a row's last chunk beyond its upper limit store their bytes further right:
+      // into tiles of LATER scores of the block, which those scores overwrite, or into the slack)
+      uint32_t tile_cols = 0;
+      GlobalBytes tiles0 = nullptr;             // byte address of tile (0, 0)
+      if constexpr (BT && TILED) {
+        tile_cols = (uint32_t)(whi - wlo + 16) >> 4;
+        const uint32_t block_units = 4u + 4u * (((uint32_t)budget >> 2) + 1u) * tile_cols + 16u;
+        if (chunk_left < block_units + 3u && !refill_arena(block_units + 3u)) status = WFA_ST_NOMEM;
+        if (status == WFA_ST_DONE) {
+          tab_base = (chunk_cur + 3u) & ~3u;          // (tiles are cache lines: the block starts on one)
+          chunk_left -= (tab_base - chunk_cur) + block_units; chunk_cur = tab_base + block_units;
+          GlobalBytes const blk = (GlobalBytes)(uintptr_t)cold_params()->arena + (size_t)tab_base * 16u;
+          if (tid == 0) {
+            uint32_t* const hdr = reinterpret_cast<uint32_t*>(p.arena + (size_t)tab_base * 16u);
+            hdr[0] = WFA_ROW_NONE; hdr[1] = (uint32_t)wlo; hdr[2] = tile_cols; hdr[3] = (uint32_t)budget;
+          }
+          tiles0 = blk + 64;
+        }
+      } else if constexpr (BT) {
         // the row table (8 bytes per score up to the budget) and the one-cell row of score 0
         const uint32_t tab_units = (uint32_t)(((long long)budget + 2) >> 1);
         if (chunk_left < tab_units + 1 && !refill_arena(tab_units + 1)) status = WFA_ST_NOMEM;
@@ -411,6 +437,9 @@ wfa_align_kernel(const WfaAlignParams p) {
           if (tid == 0) p.arena[(size_t)row_s * 16] = 0;     // (its row-table entry: tab_set(0, ...) below)
         }
       }
+      // byte address of the tile row of score sc (TILED): tile (sc >> 2, 0), in-tile row sc & 3; and of a diagonal inside it
+      auto tile_row = [&](const int sc) -> GlobalBytes { return tiles0 + ((size_t)((uint32_t)sc >> 2) * tile_cols * 64u + ((uint32_t)sc & 3u) * 16u); };
+      auto tile_off = [&](const int kk) -> uint32_t { const uint32_t d = (uint32_t)(kk - wlo); return d + 3u * (d & ~15u); };
       uint32_t d0 = 0;
       if (tid == 0) {
         // longest common prefix from (0,0): both sequences start word-aligned
@@ -486,7 +515,7 @@ wfa_align_kernel(const WfaAlignParams p) {
           if (lane <= (score & 63)) tab[(score & ~63) + lane] = make_uint2((uint32_t)tabv_row, (uint32_t)tabv_lo);
         }
       };
-      if constexpr (BT) { if (status == WFA_ST_DONE) tab_set(0, row_s, 0); }
+      if constexpr (BT && !TILED) { if (status == WFA_ST_DONE) tab_set(0, row_s, 0); }
       #include "align/cells_generic.inc"
       #include "align/cells_hot.inc"
       #include "align/band_window.inc"
@@ -507,15 +536,9 @@ wfa_align_kernel(const WfaAlignParams p) {
       }
       if constexpr (BT) {
         if (status == WFA_ST_DONE) {
-          tab_flush(s);
-          bool walked = false;
-          if constexpr (NW == 1 && !GLOBAL_RING) {
-            if (cold_params()->walk_in_kernel) {
-              #include "align/walk_epilogue.inc"
-            }
-          }
-          // (WFA_ROW_NONE: walked here -- wfa_walk_kernel skips the pair, the replay finds the op list through cigar_off)
-          if (tid == 0 && status == WFA_ST_DONE) cold_params()->bt_final_row[pair] = walked ? WFA_ROW_NONE : tab_base;
+          if constexpr (!TILED) tab_flush(s);
+          // (the pair's block of tiles, or its row table: wfa_device.h)
+          if (tid == 0) cold_params()->bt_final_row[pair] = tab_base;
         }
       }
     }

@@ -227,6 +227,49 @@ __device__ __forceinline__ uint32_t replay(const uint8_t* ops, uint32_t nops, co
 
 constexpr int TRACE_THREADS = 64;
 
+// Where the origin bytes of a pair are (wfa_device.h): behind a row table -- [score] = {arena unit of the row, lo} --, or (the one-wave
+// exact tier, round 6) in the pair's block of TILES: a 64-byte header {WFA_ROW_NONE, wlo, tile columns, budget}, then 64-byte tiles of
+// 4 scores x 16 diagonals, tile (s >> 2, (k - wlo) >> 4), byte (s & 3) * 16 + ((k - wlo) & 15).
+struct BtBlock { const uint8_t* blk; bool tiled; int wlo; uint32_t cols; };
+__device__ __forceinline__ BtBlock bt_block(const WfaTraceParams& p, const uint32_t pair) {
+  BtBlock b;
+  b.blk = p.arena + (size_t)p.bt_final_row[pair] * 16;
+  const uint4 hdr = *reinterpret_cast<const uint4*>(b.blk);
+  b.tiled = hdr.x == WFA_ROW_NONE; b.wlo = (int)hdr.y; b.cols = hdr.z;
+  return b;
+}
+// The wave- and group-per-alignment kernels read origin bytes through a tile in LDS, one row of it per lane: TILE_LDS_W bytes.  Row of
+// score sr around diagonal k into dst; kbase: the diagonal of dst[0].  Row-table layout: 16 bytes, diagonals k-8 .. k+7 (one unaligned
+// load).  Tiles: the two 16-diagonal tile columns whose 32 diagonals have k at least 8 from either end (two aligned 16-byte loads).
+// Every lane sets the same kbase (it depends on k and the pair only).  Rows of scores < 0 and bytes outside the block read as 0.
+constexpr int TILE_LDS_W = 32;
+__device__ __forceinline__ void fetch_bt_rows(const WfaTraceParams& p, const BtBlock& bb, const int sr, const int k, int& kbase, uint8_t* dst) {
+  uint4 v0 = make_uint4(0, 0, 0, 0), v1 = make_uint4(0, 0, 0, 0);
+  if (bb.tiled) {
+    const int c0 = ((k - bb.wlo) - 8) >> 4;      // (arithmetic shift: -1 for diagonals 0..7 of the window)
+    kbase = bb.wlo + c0 * 16;
+    if (sr >= 0) {
+      const uint8_t* const row = bb.blk + 64u + (size_t)((uint32_t)sr >> 2) * bb.cols * 64u + ((uint32_t)sr & 3u) * 16u;
+      if (c0 >= 0 && (uint32_t)c0 < bb.cols) v0 = *reinterpret_cast<const uint4*>(row + (size_t)c0 * 64u);
+      if (c0 + 1 >= 0 && (uint32_t)(c0 + 1) < bb.cols) v1 = *reinterpret_cast<const uint4*>(row + (size_t)(c0 + 1) * 64u);
+    }
+  } else {
+    kbase = k - 8;
+    if (sr >= 0) {
+      const uint2 row = reinterpret_cast<const uint2*>(bb.blk)[sr];
+      // (entries of scores without a wavefront are stale: their cells are never consulted, but the address must be a safe one)
+      const long long off = (long long)row.x * 16 + ((long long)kbase - (int)row.y);
+      if (off >= 0 && (unsigned long long)off + 16 <= p.arena_bytes) {
+        struct __attribute__((packed, aligned(1))) U16 { uint32_t w[4]; };
+        const U16 t = *reinterpret_cast<const U16*>(p.arena + off);
+        v0 = make_uint4(t.w[0], t.w[1], t.w[2], t.w[3]);
+      }
+    }
+  }
+  reinterpret_cast<uint4*>(dst)[0] = v0;
+  reinterpret_cast<uint4*>(dst)[1] = v1;
+}
+
 // The backward walk of ONE alignment (one lane): follows the origin bytes from the final cell to (0, 0) and leaves the operations
 // as a byte list that grows downwards from q_end (op number n, 0 = last operation of the alignment, is byte q_end[-1-n]; q_end is
 // 4-byte aligned, four ops go out as one word).  tab_cache: this lane's 8 row-table entries of LDS.  false: broken trace.
@@ -235,24 +278,50 @@ __device__ __forceinline__ bool walk_ops(const WfaTraceParams& p, const uint32_t
   bool fail = false;
   uint32_t nops = 0, word = 0;
   {
-    // row table of the pair: [score] = {arena unit of the origin bytes, lo}
-    const uint2* tab = reinterpret_cast<const uint2*>(p.arena + (size_t)p.bt_final_row[pair] * 16);
+    // row table of the pair: [score] = {arena unit of the origin bytes, lo} -- or (the one-wave exact tier, round 6) the pair's block of
+    // TILES: a 64-byte header {WFA_ROW_NONE, wlo, tile columns, budget}, then 64-byte tiles of 4 scores x 16 diagonals, tile
+    // (s >> 2, (k - wlo) >> 4), byte (s & 3) * 16 + ((k - wlo) & 15): no table to consult, and the ~55 origin bytes of a 1 kbp
+    // alignment sit on ~35 cache lines instead of 55 + 19 lines of row table
+    const uint8_t* const blk = p.arena + (size_t)p.bt_final_row[pair] * 16;
+    const uint2* tab = reinterpret_cast<const uint2*>(blk);
+    const uint4 hdr = *reinterpret_cast<const uint4*>(blk);
+    const bool tiled = hdr.x == WFA_ROW_NONE;
+    const int t_wlo = (int)hdr.y; const uint32_t t_cols = hdr.z;
     int k = tlen - plen, s = score;
     int state = 0;  // 0: M, 1: I, 2: D
     int cached = -1;
     while (s > 0) {
       if (nops >= need_ops) { fail = true; break; }
-      if ((s >> 3) != cached) {
-        cached = s >> 3;
-        const uint4* src = reinterpret_cast<const uint4*>(tab + (cached << 3));
-        const uint4 a = src[0], b = src[1], c2 = src[2], d = src[3];
-        tab_cache_lane[0] = make_uint2(a.x, a.y); tab_cache_lane[1] = make_uint2(a.z, a.w);
-        tab_cache_lane[2] = make_uint2(b.x, b.y); tab_cache_lane[3] = make_uint2(b.z, b.w);
-        tab_cache_lane[4] = make_uint2(c2.x, c2.y); tab_cache_lane[5] = make_uint2(c2.z, c2.w);
-        tab_cache_lane[6] = make_uint2(d.x, d.y); tab_cache_lane[7] = make_uint2(d.z, d.w);
+      uint32_t code;
+      if (tiled) {
+        // (the tile is kept in this lane's 64 bytes of LDS -- the row-table cache of the other layout -- until the walk leaves it: a
+        // mismatch at x = 2 stays in its tile every other step)
+        const uint32_t d = (uint32_t)(k - t_wlo);
+        if ((d >> 4) >= t_cols) { fail = true; break; }      // (a broken trace must not leave the block)
+        const int tile_id = (int)(((uint32_t)s >> 2) * t_cols + (d >> 4));
+        if (tile_id != cached) {
+          cached = tile_id;
+          const uint4* src = reinterpret_cast<const uint4*>(blk + 64u + (size_t)tile_id * 64u);
+          const uint4 a = src[0], b = src[1], c2 = src[2], d4 = src[3];
+          tab_cache_lane[0] = make_uint2(a.x, a.y); tab_cache_lane[1] = make_uint2(a.z, a.w);
+          tab_cache_lane[2] = make_uint2(b.x, b.y); tab_cache_lane[3] = make_uint2(b.z, b.w);
+          tab_cache_lane[4] = make_uint2(c2.x, c2.y); tab_cache_lane[5] = make_uint2(c2.z, c2.w);
+          tab_cache_lane[6] = make_uint2(d4.x, d4.y); tab_cache_lane[7] = make_uint2(d4.z, d4.w);
+        }
+        code = reinterpret_cast<const uint8_t*>(tab_cache_lane)[((uint32_t)s & 3u) * 16u + (d & 15u)];
+      } else {
+        if ((s >> 3) != cached) {
+          cached = s >> 3;
+          const uint4* src = reinterpret_cast<const uint4*>(tab + (cached << 3));
+          const uint4 a = src[0], b = src[1], c2 = src[2], d = src[3];
+          tab_cache_lane[0] = make_uint2(a.x, a.y); tab_cache_lane[1] = make_uint2(a.z, a.w);
+          tab_cache_lane[2] = make_uint2(b.x, b.y); tab_cache_lane[3] = make_uint2(b.z, b.w);
+          tab_cache_lane[4] = make_uint2(c2.x, c2.y); tab_cache_lane[5] = make_uint2(c2.z, c2.w);
+          tab_cache_lane[6] = make_uint2(d.x, d.y); tab_cache_lane[7] = make_uint2(d.z, d.w);
+        }
+        const uint2 row = tab_cache_lane[s & 7];
+        code = p.arena[(size_t)row.x * 16 + (uint32_t)(k - (int)row.y)];
       }
-      const uint2 row = tab_cache_lane[s & 7];
-      const uint32_t code = p.arena[(size_t)row.x * 16 + (uint32_t)(k - (int)row.y)];
       uint32_t op;
       if (state == 0) {
         const uint32_t org = code & BT_M_MASK;
@@ -688,10 +757,10 @@ __global__ void __launch_bounds__(TRACE_THREADS) wfa_trace_wave_kernel(const Wfa
   const int seq_cap = p.walk_only ? 0 : p.seq_words_cap;
   uint32_t* Pw = wlds;
   uint32_t* Tw = Pw + seq_cap;
-  uint8_t* tile = reinterpret_cast<uint8_t*>(Tw + seq_cap);     // [64 rows][16 bytes]
-  uint8_t* ops_lds = tile + 64 * 16;                                    // [ops_lds_bytes]
+  uint8_t* tile = reinterpret_cast<uint8_t*>(Tw + seq_cap);     // [64 rows][32 bytes] (16 used by the row-table layout, 32 by tiles)
+  uint8_t* ops_lds = tile + 64 * TILE_LDS_W;                            // [ops_lds_bytes]
   char* text_lds = reinterpret_cast<char*>(ops_lds + p.ops_lds_bytes);  // [text_lds_bytes]
-  constexpr int TILE_W = 16, TILE_H = 64;
+  constexpr int TILE_H = 64;
   for (uint32_t w = blockIdx.x; w < p.n_work; w += gridDim.x) {
     const uint32_t pair = __builtin_amdgcn_readfirstlane(p.work ? p.work[w] : w);
     if (p.status[pair] != WFA_ST_DONE) continue;
@@ -725,32 +794,20 @@ __global__ void __launch_bounds__(TRACE_THREADS) wfa_trace_wave_kernel(const Wfa
     uint8_t* const q_end = q_begin + need_ops;
     uint8_t* q = q_end;
     if (!fail) {
-      const uint2* tab = reinterpret_cast<const uint2*>(p.arena + (size_t)p.bt_final_row[pair] * 16);
+      const BtBlock bb = bt_block(p, pair);
       int k = tlen - plen, s = score, state = 0;       // state 0: M, 1: I, 2: D
       int s_top = -1, kbase = 0;
+      const int tile_w = bb.tiled ? 32 : 16;
       while (s > 0) {
-        if (s > s_top || s_top - s >= TILE_H || (unsigned)(k - kbase) >= (unsigned)TILE_W) {
-          // new tile: scores s .. s-63, diagonals k-8 .. k+7
-          s_top = s; kbase = k - TILE_W / 2;
+        if (s > s_top || s_top - s >= TILE_H || (unsigned)(k - kbase) >= (unsigned)tile_w) {
+          // new tile: scores s .. s-63, diagonals k-8 .. k+7 (row-table layout) / the two 16-diagonal tile columns around k (tiles)
+          s_top = s;
           __builtin_amdgcn_wave_barrier();
-          const int sr = s - lane;
-          uint4 v = make_uint4(0, 0, 0, 0);
-          if (sr >= 0) {
-            const uint2 row = tab[sr];
-            // (entries of scores without a wavefront are stale: their cells are never consulted, but the address
-            //  must be a safe one)
-            const long long off = (long long)row.x * 16 + ((long long)kbase - (int)row.y);
-            if (off >= 0 && (unsigned long long)off + 16 <= p.arena_bytes) {
-              struct __attribute__((packed, aligned(1))) U16 { uint32_t w[4]; };
-              const U16 t = *reinterpret_cast<const U16*>(p.arena + off);
-              v = make_uint4(t.w[0], t.w[1], t.w[2], t.w[3]);
-            }
-          }
-          reinterpret_cast<uint4*>(tile)[lane] = v;
+          fetch_bt_rows(p, bb, s - lane, k, kbase, tile + lane * TILE_LDS_W);
           __builtin_amdgcn_wave_barrier();
         }
         if (q == q_begin) { fail = true; break; }
-        const uint32_t code = tile[(s_top - s) * TILE_W + (k - kbase)];
+        const uint32_t code = tile[(s_top - s) * TILE_LDS_W + (k - kbase)];
         uint8_t op;
         if (state == 0) {
           const uint32_t org = code & BT_M_MASK;
@@ -838,13 +895,13 @@ __global__ void __launch_bounds__(TRACE_THREADS) wfa_trace_wave_kernel(const Wfa
 template <bool RAW, int G>
 __global__ void __launch_bounds__(TRACE_THREADS) wfa_trace_group_kernel(const WfaTraceParams p) {
   extern __shared__ __attribute__((aligned(16))) uint32_t glds[];
-  constexpr int L = 64 / G, TILE_W = 16, TILE_H = L;       // one row per lane of the group (short alignments: taller tiles cost more than they save)
+  constexpr int L = 64 / G, TILE_H = L;       // one row per lane of the group (short alignments: taller tiles cost more than they save)
   const int lane = threadIdx.x & 63, grp = lane / L, sub = lane % L, lead = grp * L;
-  const size_t share_words = ((size_t)2 * p.seq_words_cap * 4 + (size_t)TILE_H * TILE_W + (size_t)p.ops_lds_bytes + (size_t)p.text_lds_bytes + 15) / 16 * 4;
+  const size_t share_words = ((size_t)2 * p.seq_words_cap * 4 + (size_t)TILE_H * TILE_LDS_W + (size_t)p.ops_lds_bytes + (size_t)p.text_lds_bytes + 15) / 16 * 4;
   uint32_t* Pw = glds + (size_t)grp * share_words;
   uint32_t* Tw = Pw + p.seq_words_cap;
-  uint8_t* tile = reinterpret_cast<uint8_t*>(Tw + p.seq_words_cap);       // [L rows][16 bytes]
-  uint8_t* ops_lds = tile + TILE_H * TILE_W;
+  uint8_t* tile = reinterpret_cast<uint8_t*>(Tw + p.seq_words_cap);       // [L rows][32 bytes]
+  uint8_t* ops_lds = tile + TILE_H * TILE_LDS_W;
   char* text_lds = reinterpret_cast<char*>(ops_lds + p.ops_lds_bytes);
   for (uint32_t base = blockIdx.x * G; base < p.n_work; base += gridDim.x * G) {
     const uint32_t w = base + grp;
@@ -876,29 +933,19 @@ __global__ void __launch_bounds__(TRACE_THREADS) wfa_trace_group_kernel(const Wf
     uint8_t* const q_end = q_begin + need_ops;
     uint8_t* q = q_end;
     if (active && !fail) {
-      const uint2* tab = reinterpret_cast<const uint2*>(p.arena + (size_t)p.bt_final_row[pair] * 16);
+      const BtBlock bb = bt_block(p, pair);
       int k = tlen - plen, s = score, state = 0;       // state 0: M, 1: I, 2: D
       int s_top = -1, kbase = 0;
+      const int tile_w = bb.tiled ? 32 : 16;
       while (s > 0) {
-        if (s > s_top || s_top - s >= TILE_H || (unsigned)(k - kbase) >= (unsigned)TILE_W) {
-          // new tile for this group: scores s .. s-L+1, diagonals k-8 .. k+7 (lane `sub` fetches row s - sub)
-          s_top = s; kbase = k - TILE_W / 2;
-          const int sr = s - sub;
-          uint4 v = make_uint4(0, 0, 0, 0);
-          if (sr >= 0) {
-            const uint2 row = tab[sr];
-            const long long off = (long long)row.x * 16 + ((long long)kbase - (int)row.y);
-            if (off >= 0 && (unsigned long long)off + 16 <= p.arena_bytes) {
-              struct __attribute__((packed, aligned(1))) U16 { uint32_t w[4]; };
-              const U16 t = *reinterpret_cast<const U16*>(p.arena + off);
-              v = make_uint4(t.w[0], t.w[1], t.w[2], t.w[3]);
-            }
-          }
-          reinterpret_cast<uint4*>(tile)[sub] = v;
+        if (s > s_top || s_top - s >= TILE_H || (unsigned)(k - kbase) >= (unsigned)tile_w) {
+          // new tile for this group: scores s .. s-L+1, diagonals around k (lane `sub` fetches row s - sub)
+          s_top = s;
+          fetch_bt_rows(p, bb, s - sub, k, kbase, tile + sub * TILE_LDS_W);
           __builtin_amdgcn_wave_barrier();
         }
         if (q == q_begin) { fail = true; break; }
-        const uint32_t code = tile[(s_top - s) * TILE_W + (k - kbase)];
+        const uint32_t code = tile[(s_top - s) * TILE_LDS_W + (k - kbase)];
         uint8_t op;
         if (state == 0) {
           const uint32_t org = code & BT_M_MASK;
@@ -976,7 +1023,7 @@ void allow_lds(K kernel, size_t lds, size_t (&allowed)[16]) {
 
 template <bool RAW, int G>
 void launch_group(const WfaTraceParams& p, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
-  const size_t share = ((size_t)2 * p.seq_words_cap * 4 + (size_t)(64 / G) * 16 + (size_t)p.ops_lds_bytes + (size_t)p.text_lds_bytes + 15) / 16 * 16;
+  const size_t share = ((size_t)2 * p.seq_words_cap * 4 + (size_t)(64 / G) * TILE_LDS_W + (size_t)p.ops_lds_bytes + (size_t)p.text_lds_bytes + 15) / 16 * 16;
   const size_t lds = share * G;
   const uint32_t blocks = (p.n_work + G - 1) / G;
   const uint32_t grid = blocks < 8192u ? blocks : 8192u;
@@ -987,8 +1034,8 @@ void launch_group(const WfaTraceParams& p, hipStream_t stream, hipEvent_t ev0, h
 
 template <bool RAW>
 void launch_wave(const WfaTraceParams& p, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
-  const size_t lds = p.walk_only ? (size_t)64 * 16 + (size_t)p.ops_lds_bytes
-                                 : (size_t)2 * p.seq_words_cap * 4 + 64 * 16 + (size_t)p.ops_lds_bytes + (size_t)p.text_lds_bytes;
+  const size_t lds = p.walk_only ? (size_t)64 * TILE_LDS_W + (size_t)p.ops_lds_bytes
+                                 : (size_t)2 * p.seq_words_cap * 4 + 64 * TILE_LDS_W + (size_t)p.ops_lds_bytes + (size_t)p.text_lds_bytes;
   const uint32_t grid = p.n_work < 8192u ? p.n_work : 8192u;
   static thread_local size_t allowed[16] = {0};
   allow_lds(wfa_trace_wave_kernel<RAW>, lds, allowed);

@@ -762,6 +762,14 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   // many pairs as the arena is expected to hold, so a small arena costs passes, not repeated work.
   double est_pair_bytes = 0.25 * ((double)std::min<unsigned>(max_error, 2 * max_len) + 1) * ((double)std::min<unsigned>(max_error, 2 * max_len) + 1) +
                           16.0 * std::min<unsigned>(max_error, 2 * max_len) + 4096.0;
+  // The one-wave exact tier hands every alignment a block of TILES up front (align_kernel.hip, TILED): a 64-byte tile per 4 scores x 16
+  // diagonals over the whole window of the budget, whatever part of it the wavefronts visit -- about twice the diamond's bytes.
+  auto tiled_pair_bytes = [&](const long long B) -> double {
+    const int w = window_width(B, pen.o, pen.e, batch_max_len);
+    if (w > 1024) return 0.0;      // (wider wavefronts run on the multi-wave tiers: rows behind a row table)
+    return 64.0 * (double)((w + 15) / 16) * (double)(B / 4 + 1) + 512.0;
+  };
+  est_pair_bytes = std::max(est_pair_bytes, tiled_pair_bytes(std::min<long long>(max_error, 2ll * batch_max_len * std::max(pen.x, pen.e))));
   if (compute_cigar) {
     // arena: expected need, bounded by configuration / free memory / 32-bit unit addressing
     size_t want = c->arena_cfg;
@@ -859,7 +867,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   if (budgets) {
     // tight budgets make the wavefront a diamond: at most half the budget square of origin bytes
     const double B = budget_cap;
-    est_pair_bytes = 0.5 * (B + 1) * (B + 1) + 16.0 * B + 2048.0;
+    est_pair_bytes = std::max(0.5 * (B + 1) * (B + 1) + 16.0 * B + 2048.0, tiled_pair_bytes(budget_cap));
   }
   while (n_pending > 0) {
     c->stats.sub_batches++;
@@ -946,20 +954,12 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
           if (c->gring.ensure(stride * g, st)) return -1;
           ap.gring = c->gring.p; ap.gring_stride = stride;
         }
-        // The one-wave LDS tiers walk a finished alignment back themselves (align/walk_epilogue.inc) when what follows is the
-        // lane-per-alignment replay -- sequences of 64 pairs stageable in LDS, no pair of the chain short enough for the
-        // one-kernel backtrace of short alignments (which walks by itself) -- and the ring's LDS holds a tile and the op list.
-        {
-          const unsigned per_seq_w = raw ? (max_len + 3) / 4 + 1 : (max_len + 15) / 16 + 1;
-          const bool lane_replay = (size_t)64 * ((2 * per_seq_w) | 1u) * 4 <= (48u << 10);
-          const size_t ring_bytes = (size_t)(ap.dm + 2 * ap.de + ((tp.tier == 0 && ap.band_width <= 0) ? 1 : 0)) * (size_t)ap.rs * 2;
-          const int s_cap = std::min(ap.max_score, 30000);
-          L.walked = cigar_now && tp.tier == 0 && c->tuning.kernel_walk && lane_replay && s_cap > 124 &&
-                     ring_bytes >= (size_t)64 * 16 + (((size_t)s_cap + 3) & ~(size_t)3) + 16;
-          ap.walk_in_kernel = L.walked ? 1 : 0;
-          ap.cigar_off = static_cast<unsigned long long*>(c->cig_off[c->out_set].p);
-          ap.cigar_len = static_cast<uint32_t*>(c->cig_len[c->out_set].p);
-        }
+        // (tuning.kernel_walk -- the one-wave kernels walking their own alignments back, measured a loss in round 5 -- went with the row
+        // table it read: round 6's tiles make wfa_walk_kernel itself cheap)
+        L.walked = false;
+        ap.walk_in_kernel = 0;
+        ap.cigar_off = static_cast<unsigned long long*>(c->cig_off[c->out_set].p);
+        ap.cigar_len = static_cast<uint32_t*>(c->cig_len[c->out_set].p);
         ap.dbg_times = nullptr; ap.dbg_cap = 0;
         if (c->tuning.timed_barriers && round == 0 && cigar_now && !raw && !L.banded && (tp.tier == 1 || tp.tier == 4)) {
           const int nw = tp.tier == 1 ? 4 : 16;
@@ -1134,7 +1134,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         // (it needs both sequences of a pair plus ~1 KiB in LDS; sequences at the very edge of what the align tiers stage do
         // not leave that: the lane-per-alignment walk + windowed emit take any length)
         tp.wave_kernel = (tp.seq_lds_stride == 0 && c->tuning.trace_mode != 1 &&
-                          (size_t)2 * tp.seq_words_cap * 4 + 64 * 16 + 64 <= c->lds_per_block_max) ? 1 : 0;
+                          (size_t)2 * tp.seq_words_cap * 4 + 64 * 32 + 64 <= c->lds_per_block_max) ? 1 : 0;      // (64 * 32: the tile, trace_kernel.hip TILE_LDS_W)
         // Scratch sizes.  Lane-per-alignment kernels with a bounded score: from the bound (no pair of the chain finished
         // above s_hi), no round trip.  The wave kernels size their LDS from the largest score of the pass and the
         // unbounded tier has no bound: those read the sums k_trace_bounds has just formed.
@@ -1162,7 +1162,7 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
         {
           // op list (one byte per score point of the largest score of the pass) and CIGAR text of one alignment in LDS,
           // within 40 KiB per wavefront so that at least four of them fit a CU
-          const size_t seq_b = (size_t)2 * tp.seq_words_cap * 4 + 1024;
+          const size_t seq_b = (size_t)2 * tp.seq_words_cap * 4 + 2048;      // (+ the tile: 64 rows of 32 bytes)
           size_t room = seq_b < (40u << 10) ? (40u << 10) - seq_b : 0;
           const size_t smax = by_bound ? (size_t)s_hi : (size_t)c->h_counters[CT_MAX_SCORE];
           tp.ops_lds_bytes = (int)(((smax + 3) & ~(size_t)3) <= room ? ((smax + 15) & ~(size_t)15) : 0);
@@ -1171,11 +1171,11 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
           // Several alignments per wavefront (64/G lanes and one LDS share each) for SHORT op lists only (2 kbp reads, G = 8:
           // 262k pairs 13.2 -> 6.6 ms).  With hundreds of operations per alignment the replays of the groups diverge and
           // the wavefront per alignment wins again (16k x 10 kbp: 2.7 ms against 4.0 ms with G = 4).
-          const size_t share = seq_b - 1024 + (size_t)tp.ops_lds_bytes + (size_t)tp.text_lds_bytes;
+          const size_t share = seq_b - 2048 + (size_t)tp.ops_lds_bytes + (size_t)tp.text_lds_bytes;
           tp.group = 1;
           if (c->tuning.trace_mode == 0 && tp.ops_lds_bytes > 0 && smax <= 512)
             for (int g = 8; g >= 2; g >>= 1)
-              if ((share + (size_t)(64 / g) * 16 + 16) * g <= (40u << 10) && n_chain >= (uint32_t)g * 1024u) { tp.group = g; break; }
+              if ((share + (size_t)(64 / g) * 32 + 16) * g <= (40u << 10) && n_chain >= (uint32_t)g * 1024u) { tp.group = g; break; }
         }
         // LONG alignments, one wavefront each: the wavefront kernel only walks; the replay is the staged lane-per-alignment kernel's
         // with as many pairs per wavefront (8, 16, ...) as fit LDS next to three more wavefronts (a replay is one serial chain:

@@ -232,6 +232,10 @@ typedef struct {
                                  1: always, -1: never (ASCII goes up, the pack kernel runs).  A batch holding a byte outside
                                  ACGT always goes up as ASCII                                                           */
     int host_pack_threads;    /* threads packing a batch (0: three quarters of a device's share of the host threads, 2..12)         */
+    int ascii_every;          /* host_pack automatic, big calls: every n-th batch of a device's slice (the first one included) goes up as
+                                 ASCII and is packed by the wavefront kernels while they stage it -- the host's packing threads and the PCIe
+                                 link then share the call's bytes instead of the packing alone setting its pace (1M x 1 kbp pairs: the pack
+                                 of 2 GB takes 12 threads 24-27 ms, the device 28).  0: default (3), -1: never, n >= 2: every n-th      */
     int bring_up;             /* 0: the first device query of the process (get_num_cuda_devices, get_cuda_SM_count -- what the CLI
                                  and wfagpu_set_default_options call before any alignment) starts bringing the caller's
                                  CURRENT device up in a background thread: streams, lanes, code objects (all devices:

@@ -23,7 +23,8 @@ lanes = int(sys.argv[7]) if len(sys.argv) > 7 else 0
 nbatch = int(sys.argv[8]) if len(sys.argv) > 8 else 0
 bpc = int(sys.argv[9]) if len(sys.argv) > 9 else 0
 wfagpu.configure_launch(timing=int(os.environ.get("TIMING", "0")), lanes_per_device=lanes, batches_per_device=nbatch, tuning={"max_blocks_per_cu": bpc},
-                        host_pack=int(os.environ.get("HOST_PACK", "0")), host_pack_threads=int(os.environ.get("PACK_THREADS", "0")))
+                        host_pack=int(os.environ.get("HOST_PACK", "0")), host_pack_threads=int(os.environ.get("PACK_THREADS", "0")),
+                        ascii_every=int(os.environ.get("ASCII_EVERY", "0")))
 buf, meta = wfagpu.generate_pairs(n, length, err, seed=int(os.environ.get("SEED", "7")), nthreads=16)
 bl = os.environ.get("BENCHLIKE", "")
 if bl and bl[0] == "x":

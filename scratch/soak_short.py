@@ -21,7 +21,8 @@ def rand_pair(maxlen, err):
         else: a = rng.randint(0, len(p)); p[a:a] = bytes(rng.choice(b"ACGT") for _ in range(rng.randint(1, 6)))
     return (bytes(p), t) if rng.random() < 0.5 else (t, bytes(p))
 for it in range(iters):
-    pen = rng.choice([(2, 3, 1), (4, 6, 2), (1, 2, 1), (6, 9, 3), (3, 6, 3), (1, 0, 1), (4, 6, 1), (7, 7, 1), (8, 2, 1), (5, 1, 1), (3, 4, 1)])
+    pen = rng.choice([(2, 3, 1), (4, 6, 2), (1, 2, 1), (6, 9, 3), (3, 6, 3), (1, 0, 1), (4, 6, 1), (7, 7, 1), (8, 2, 1), (5, 1, 1), (3, 4, 1),
+                      (5, 3, 2), (3, 1, 4), (7, 2, 3), (3, 5, 2), (1, 0, 2), (2, 0, 3), (8, 4, 4), (1, 4, 2), (6, 1, 3), (2, 2, 4), (5, 0, 3)])      # (round 6: gap extensions 2..4 on tier 5)
     n = rng.choice([64, 500, 9000, 12000])
     maxlen = rng.choice([30, 150, 300, 600])
     err = rng.choice([0.0, 0.01, 0.03, 0.08])

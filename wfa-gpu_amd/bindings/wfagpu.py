@@ -61,7 +61,7 @@ class LaunchConfig(C.Structure):  # wfagpu_amd_launch_config_t: all zero = autom
     _fields_ = [("num_devices", C.c_int), ("virtual_devices", C.c_int), ("lanes_per_device", C.c_int),
                 ("batches_per_device", C.c_int), ("arena_limit_bytes", C.c_size_t), ("input_pool_bytes", C.c_size_t),
                 ("numa_pin", C.c_int), ("timing", C.c_int), ("tuning", Tuning), ("host_pack", C.c_int),
-                ("host_pack_threads", C.c_int), ("bring_up", C.c_int)]
+                ("host_pack_threads", C.c_int), ("ascii_every", C.c_int), ("bring_up", C.c_int)]
 
 
 class LaunchStats(C.Structure):  # wfagpu_amd_launch_stats_t

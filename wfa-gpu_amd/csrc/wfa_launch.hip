@@ -641,7 +641,14 @@ int run_device(const CallArgs& a, Shard& sh) {
       b.packed_bytes = packed_bytes;
       uint32_t* stage = nullptr;
       double tp0 = 0;
-      if (host_pack) {
+      // Host packing in automatic mode shares a big call with the PCIe link: every ascii_every-th batch (the first one included: nothing
+      // to pack in front of the first upload) goes up as ASCII -- four times the bytes, no packing -- and the wavefront kernels pack it
+      // while they stage it (reads of 512 bases and more: WfaAlignParams::ascii).  1M x 1 kbp pairs: packing all sixteen batches takes
+      // twelve threads 24-27 ms, as long as the kernels take -- the packing set the pace of the call; with every third batch as ASCII
+      // the packers and the link need ~20 ms each.
+      const int ascii_every = a.cfg.ascii_every < 0 ? 0 : (a.cfg.ascii_every >= 2 ? a.cfg.ascii_every : 3);
+      const bool pack_this = host_pack && !(a.cfg.host_pack == 0 && big && nb >= 6 && ascii_every && b.max_len >= 512u && (i % ascii_every) == 0);
+      if (pack_this) {
         tp0 = now_ms();
         // (the staging buffer last carried batch i - STAGE_RING: its copy must have left the host)
         if (i >= STAGE_RING) {
@@ -665,7 +672,7 @@ int run_device(const CallArgs& a, Shard& sh) {
         if (wfagpu_host_pack_strip(a.seq, a.seq_bytes, a.meta + j0, j1 - j0, strip_off[t], stage)) bad.store(1);
       });
       if (i == 0) prep0_detail[2] = now_ms() - t_pack0;
-      if (host_pack) {
+      if (pack_this) {
         // (a byte outside ACGT: those pairs need their ASCII on the device, the whole batch goes up as it is)
         b.host_packed = bad.load() == 0;
         t_prep_thread.pack += now_ms() - tp0;

@@ -45,10 +45,10 @@ typedef struct {
     int no_short_cigar;    /* A/B and test hook: CIGAR calls never take tier 5 (several alignments per wavefront)               */
     int no_fused_pack;     /* A/B: always run the pack kernel (default: reads of 512 bases and more -- and shorter ones where tier 5, several
                               alignments per wavefront, takes the penalties -- are packed by the wavefront kernels while they stage them) */
-    int kernel_walk;       /* 1: the one-wave wavefront kernels walk a finished alignment back themselves (align/walk_epilogue.inc:
-                              tiles through the freed ring LDS, op list into the arena) and wfa_walk_kernel does not run.  Off by
-                              default: measured on BASELINE configs[2] the backtrace pass drops from 3.05 to 1.45 ms but the serial
-                              walk costs the wavefront kernel 2.45 ms of instruction issue (25.4 -> 27.9 ms): EXPERIMENTS.md       */
+    int kernel_walk;       /* retired in round 6 (accepted, ignored): the one-wave wavefront kernels walking a finished alignment back
+                              themselves -- measured a loss in round 5 (the backtrace pass 3.05 -> 1.45 ms, the wavefront kernel
+                              25.4 -> 27.9 ms: EXPERIMENTS.md) -- went with the row table it read; the tile layout of the origin
+                              bytes makes wfa_walk_kernel itself cheap                                                           */
     int exact_two_waves;   /* A/B hook: the exact search takes two waves per alignment where it would take four                 */
     int band_tier;         /* A/B hook: wavefronts per alignment of the banded kernels -- 1: one, 2: two, 3: four, 4: sixteen (0: by
                               the wavefronts a CU ends up holding, plan_tier)                                                    */
@@ -232,10 +232,9 @@ typedef struct {
                                  1: always, -1: never (ASCII goes up, the pack kernel runs).  A batch holding a byte outside
                                  ACGT always goes up as ASCII                                                           */
     int host_pack_threads;    /* threads packing a batch (0: three quarters of a device's share of the host threads, 2..12)         */
-    int ascii_every;          /* host_pack automatic, big calls: every n-th batch of a device's slice (the first one included) goes up as
-                                 ASCII and is packed by the wavefront kernels while they stage it -- the host's packing threads and the PCIe
-                                 link then share the call's bytes instead of the packing alone setting its pace (1M x 1 kbp pairs: the pack
-                                 of 2 GB takes 12 threads 24-27 ms, the device 28).  0: default (3), -1: never, n >= 2: every n-th      */
+    int ascii_every;          /* A/B hook, host_pack automatic, big calls: n >= 2: every n-th batch of a device's slice (the first one
+                                 included) goes up as ASCII and is packed by the wavefront kernels while they stage it (measured a loss:
+                                 profiles/r06/ab_ascii_every.txt); 0: off                                                             */
     int bring_up;             /* 0: the first device query of the process (get_num_cuda_devices, get_cuda_SM_count -- what the CLI
                                  and wfagpu_set_default_options call before any alignment) starts bringing the caller's
                                  CURRENT device up in a background thread: streams, lanes, code objects (all devices:

@@ -641,12 +641,12 @@ int run_device(const CallArgs& a, Shard& sh) {
       b.packed_bytes = packed_bytes;
       uint32_t* stage = nullptr;
       double tp0 = 0;
-      // Host packing in automatic mode shares a big call with the PCIe link: every ascii_every-th batch (the first one included: nothing
-      // to pack in front of the first upload) goes up as ASCII -- four times the bytes, no packing -- and the wavefront kernels pack it
-      // while they stage it (reads of 512 bases and more: WfaAlignParams::ascii).  1M x 1 kbp pairs: packing all sixteen batches takes
-      // twelve threads 24-27 ms, as long as the kernels take -- the packing set the pace of the call; with every third batch as ASCII
-      // the packers and the link need ~20 ms each.
-      const int ascii_every = a.cfg.ascii_every < 0 ? 0 : (a.cfg.ascii_every >= 2 ? a.cfg.ascii_every : 3);
+      // A/B (wfagpu_amd_launch_config_t::ascii_every >= 2): every n-th batch of a big call goes up as ASCII -- four times the bytes, no
+      // packing -- and the wavefront kernels pack it while they stage it.  The idea: packing all sixteen batches of 1M x 1 kbp pairs takes
+      // twelve threads 24-27 ms, as long as the kernels take.  Measured (scratch/ab_ascii_every.sh, alternating processes, warm calls):
+      // all packed 34.3-35.3 ms, every 3rd / 2nd / 4th batch as ASCII 35.6-36.5 / 35.8-36.4 / 35.7-36.4: the packing does not set the
+      // pace (profiles/r06/ab_ascii_every.txt).  Off by default.
+      const int ascii_every = a.cfg.ascii_every >= 2 ? a.cfg.ascii_every : 0;
       const bool pack_this = host_pack && !(a.cfg.host_pack == 0 && big && nb >= 6 && ascii_every && b.max_len >= 512u && (i % ascii_every) == 0);
       if (pack_this) {
         tp0 = now_ms();

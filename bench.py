@@ -57,6 +57,10 @@ WORKLOADS = {
                   desc="16k HiFi-shaped 10 kbp pairs, 3% error, exact (unbanded), score+CIGAR"),
     "cfg5": dict(pairs=1024, length=30_000, error=0.10, cigar=True, max_error=9000, band=None, steps=25,
                  desc="1024 ONT-shaped 30 kbp pairs, 10% error, exact (unbanded), -e 9000, score+CIGAR"),
+    # the last-resort tier (the whole ring in HBM / L2: what every long pair gets whose budget no LDS tier holds -- the counterpart of the
+    # reference's global ring, lib/kernels/sequence_distance_kernel.cu:214-249) on configs[4]'s pairs: tuning.min_tier = 3 (profiling leg)
+    "cfg5t3": dict(pairs=1024, length=30_000, error=0.10, cigar=True, max_error=9000, band=None, steps=10, tuning={"min_tier": 3}, pairs_like="cfg5",
+                   desc="1024 ONT-shaped 30 kbp pairs, 10% error, exact, -e 9000, score+CIGAR, forced onto the HBM-ring tier (tuning.min_tier = 3)"),
     # the reference's kernels take any penalties (lib/kernels/sequence_distance_kernel.cu:57-160) and its own tests run (5,3,2),
     # (3,5,2) and (3,1,4) (tests/test_api.c:59-219, tests/test-aligner.sh:11-48): configs[2] / configs[1] under those sets
     "cfg3_x5o3e2": dict(pairs=1_000_000, length=1000, error=0.05, cigar=True, max_error=600, band=None, steps=50, pen=(5, 3, 2), pairs_like="cfg3",
@@ -586,6 +590,7 @@ def extra_config(name, steps, warmup, data=None, h2h_leg=True, cpu_leg=True):
     wl = WORKLOADS[name]
     force_band = bool(wl.get("force_band"))
     tuning = {"force_band": 1} if force_band else {}
+    tuning.update(wl.get("tuning", {}))
     t0 = time.perf_counter()
     n = wl["pairs"]
     buf, meta = data if data is not None else make_pairs(wl.get("pairs_like", name), n, 1000)
@@ -723,6 +728,7 @@ def main():
     if wl.get("force_band"):
         tuning["force_band"] = 1      # (part of the workload: cfg4b IS configs[3] on the banded kernels)
         args.force_band = True
+    tuning.update(wl.get("tuning", {}))      # (switches that are part of a workload: cfg5t3)
     data = make_pairs(WORKLOADS[args.workload].get("pairs_like", args.workload), n_pairs, shardlib.shard_seed(1000, rank), world=world)
     pre = {}
     if rank == 0 and world == 1:

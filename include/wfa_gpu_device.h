@@ -108,7 +108,9 @@ typedef struct {
     float pack_ms;
     float align_ms;        /* all align launches                                          */
     float trace_ms;
-    float total_ms;        /* first launch to last completion                             */
+    float total_ms;        /* from the start of the call's first pack or wavefront kernel to the end of its last kernel (list
+                              bookkeeping in front of the first wavefront launch -- a status memset, the length-bucket compaction,
+                              the budget kernel -- lies outside it: microseconds)                                         */
     int align_launches;
     /* work accounting */
     unsigned long long cells;          /* wavefront cells computed (sum of widths)        */

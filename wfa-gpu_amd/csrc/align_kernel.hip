@@ -227,6 +227,14 @@ wfa_align_kernel(const WfaAlignParams p) {
   const int bkm = p.book_mask;                                // row book: 64 (or more) entries indexed by score & bkm
   int* red = reinterpret_cast<int*>(Tw + p.seq_words_cap);    // [3][8] per-score reduction slots (NW > 1)
   uint32_t* bslot = reinterpret_cast<uint32_t*>(red + 24);    // [2] broadcast slots
+  // "A cell of this score touched a sequence end" (multi-wave lean loops): one LDS word PER SCORE PARITY, set by the waves that see it,
+  // read by every wave behind the score's barrier.  With a single sticky word a wave that is already computing score s + 1 could set it
+  // before a slower wave had done its read for score s -- the waves would then leave the loop at different scores with their barrier
+  // counts still matching (silent corruption; never observed, not excluded: ADVICE r5).  A wave cannot be two scores ahead of another
+  // one (the barrier of s + 1 stands between), so two words do.  They are words 7 of the reduction slots 0 and 1, which the careful
+  // loop never uses (it works on words 0..6 and re-initialises all 24 when a lean loop hands over); the banded search, which never
+  // runs the careful loop but scans re-centrings through red[0 .. NW-1], takes words 22 and 23.
+  auto touch_flag = [&](const int score) -> uint32_t* { return reinterpret_cast<uint32_t*>(red + (BANDED ? 22 + (score & 1) : 7 + 8 * (score & 1))); };
   // (the banded search keeps the book in registers in every tier: all waves of a workgroup derive the same windows, each keeps
   // its own copy -- no LDS round trip, no barrier for the book: loop_banded.inc)
   constexpr int BOOK_NW = BANDED ? 1 : NW;

@@ -62,6 +62,10 @@ typedef struct {
                               4 MiB; through round 4: 4096)                                                                        */
     int emit_pairs;        /* lane-per-alignment CIGAR replay with the sequences staged in LDS: alignments per wavefront
                               (8..64; 0: automatic -- as many as keep the most lanes resident per CU)                          */
+    int verify_counters;   /* test hook: a call that starts WITHOUT zeroing the device's counter block -- because the call before it
+                              claims to have left it zeroed (no kernel touched a counter, or a memset was queued behind the last read)
+                              -- reads the block back first and fails if a word of it is not zero: the invariant that skipping the
+                              memset rests on, checked instead of assumed                                            */
 } wfagpu_amd_tuning_t;
 
 typedef struct {

@@ -114,3 +114,40 @@ def test_small_batch_of_long_reads_tries_the_widest_lds_budget_first():
         assert np.array_equal(s, so) and c == co
     finally:
         al.close()
+
+
+def test_calls_that_skip_the_counter_memset_find_the_counters_clean():
+    """A call ends with its device counters zeroed -- no kernel touched them (the one-kernel call of short reads keeps its sums in
+    pinned host memory), or a memset was queued behind its last read -- and the next call starts without a memset.  That rests on every
+    path that touches a counter saying so (`ct_clean`, wfa_host.hip).  tuning.verify_counters reads the block back at the start of such
+    a call and fails the call if a byte is set: sequences of calls that cross the paths -- score-only on tier 5 (clean without a
+    memset), with CIGARs, with pairs flagged for the byte-compare class, with budget misses, the ordinary tiers, a penalty set tier 5
+    does not take -- all find it clean, and give the checker's scores."""
+    rng = random.Random(77)
+    buf, meta = wfagpu.generate_pairs(20000, 150, 0.02, seed=5)
+    pairs = wfagpu.pairs_from_layout(buf, meta)
+    dirty = list(pairs)
+    for i in range(0, len(dirty), 997):
+        p, t = dirty[i]
+        dirty[i] = (p[:10] + b"N" + p[11:], t)
+    hard, mh = wfagpu.generate_pairs(200, 150, 0.15, seed=6)      # beyond any tuned budget: re-runs, escalations
+    mixed = pairs[:19800] + wfagpu.pairs_from_layout(hard, mh)
+    sets = [wfagpu.layout_pairs(x) for x in (pairs, dirty, mixed)]
+    truth = {}
+    al = wfagpu.DeviceAligner(0, verify_counters=1)
+    try:
+        batches = [al.upload(b, m) for b, m in sets]
+        plan = [(0, (2, 3, 1), False), (0, (2, 3, 1), False), (0, (2, 3, 1), True), (1, (2, 3, 1), False), (0, (2, 3, 1), False),
+                (2, (2, 3, 1), False), (0, (5, 3, 2), False), (0, (9, 2, 1), False), (2, (2, 3, 1), True), (0, (2, 3, 1), False), (1, (5, 3, 2), True),
+                (0, (2, 3, 1), False)]
+        al.hint_same_stream(True)
+        for which, pen, cigar in plan:
+            s, c = al.align(batches[which], pen, max_error=45 * max(1, pen[0] // 2), compute_cigar=cigar)      # (raises if the hook fails the call)
+            key = (which, pen)
+            if key not in truth:
+                truth[key] = oracle_lib.oracle_batch(sets[which][0], sets[which][1], pen, cigar=True, nthreads=16)[:2]
+            assert np.array_equal(s, truth[key][0]), (which, pen, cigar)
+            if cigar:
+                assert c == truth[key][1], (which, pen)
+    finally:
+        al.close()

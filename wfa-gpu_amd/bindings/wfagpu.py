@@ -48,7 +48,7 @@ class Aligner(C.Structure):  # wfagpu_aligner_t
 class Tuning(C.Structure):  # wfagpu_amd_tuning_t: all zero = the defaults
     _fields_ = [("min_tier", C.c_int), ("careful_only", C.c_int), ("force_band", C.c_int), ("no_auto_budget", C.c_int),
                 ("max_blocks_per_cu", C.c_int), ("t0_min_blocks", C.c_int), ("waves_per_simd", C.c_int), ("trace_mode", C.c_int),
-                ("timed_barriers", C.c_int), ("no_short_cigar", C.c_int), ("no_fused_pack", C.c_int), ("kernel_walk", C.c_int), ("exact_two_waves", C.c_int), ("band_tier", C.c_int), ("no_host_parts", C.c_int), ("short_iterations", C.c_int), ("arena_chunk_cap", C.c_int), ("emit_pairs", C.c_int)]
+                ("timed_barriers", C.c_int), ("no_short_cigar", C.c_int), ("no_fused_pack", C.c_int), ("kernel_walk", C.c_int), ("exact_two_waves", C.c_int), ("band_tier", C.c_int), ("no_host_parts", C.c_int), ("short_iterations", C.c_int), ("arena_chunk_cap", C.c_int), ("emit_pairs", C.c_int), ("verify_counters", C.c_int)]
 
 
 class Config(C.Structure):  # wfagpu_amd_config_t

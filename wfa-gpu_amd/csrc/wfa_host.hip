@@ -823,6 +823,14 @@ extern "C" int wfagpu_amd_align_device(wfagpu_amd_ctx_t* c, const wfagpu_amd_bat
   // its results, executed while the host prepares the next call -- instead of in front of the next call's first kernel: a launch of
   // ~3 us and the gap behind it, of a 150 us step of 100k short reads)
   if (!c->counters_zeroed) HIP_TRY(hipMemsetAsync(c->counters.p, 0, CT_BYTES + 8 * 64, st));
+  else if (c->tuning.verify_counters) {
+    // (test hook: the call before this one said that it left the counters -- the u64 slots and the eight claim counters -- zeroed)
+    HIP_TRY(hipMemcpyAsync(c->h_counters, c->counters.p, CT_BYTES + 8 * 64, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const unsigned char* hb = reinterpret_cast<const unsigned char*>(c->h_counters);
+    for (size_t i = 0; i < CT_BYTES + 8 * 64; ++i)
+      if (hb[i]) { fprintf(stderr, "[!] ERROR: the device's counter block was left dirty by the call before (byte %zu)\n", i); return -1; }
+  }
   c->counters_zeroed = false;
   c->ct_used = 0;
   // (ev_start -- the start of the call on the device -- is the start stamp of the FIRST kernel of the call, carried by its own dispatch

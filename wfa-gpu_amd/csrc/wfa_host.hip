@@ -616,6 +616,10 @@ bool plan_tier(const wfagpu_amd_ctx* c, WfaAlignParams& p, int max_score, unsign
     if (t == 0 && !raw) {
       const int forced = c->tuning.waves_per_simd;
       for (int w : {4, 6, 7, 8}) if (4 * w >= nb - 1) { wpe = w; break; }
+      // (gap extensions > 1: the general lean loop carries more scalar state than the e == 1 loop; compiled for 8 waves per SIMD -- 64
+      // vector registers, the scalar spills go through them -- it runs slower with 31-32 rings per CU than the 7-wave build does with 28:
+      // 1M x 1 kbp under (3,1,4) 27.85 against 25.3 ms, 500k x 400 bp under (5,3,2) 7.0 against 6.5 ms: scratch/wpe_probe.py)
+      if (p.e != 1 && wpe == 8) wpe = 7;
       if (forced == 4 || forced == 6 || forced == 7 || forced == 8) wpe = forced;
       if (wpe != 8) nb = std::min(nb, wfa_align_max_blocks_per_cu(t, bt, raw, false, lds, wpe));
       if (nb < 1) continue;

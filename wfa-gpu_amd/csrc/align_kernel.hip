@@ -33,7 +33,8 @@
 //     lane base + immediates (bases formed once per score), break ties with one signed max over
 //     (offset << 16 | origin bits), give NULL cells a run length of 0 through v_med3 instead of selecting, extend
 //     without exec mask (first 16-base step straight-line) and take the run limit from an LDS row; its per-score part
-//     has closed-form limits (e == 1), in-place state, one loop exit, and touches the row book only when it leaves.
+//     has closed-form limits (e == 1; for e > 1 a superset of WFA2's limits carried by two counters), in-place state, one loop
+//     exit, and touches the row book only when it leaves.
 //     Instruction issue (vector pipe 89 % busy on the headline workload, scalar pipe 71 %) is what this
 //     kernel is bound by; the lean loop exists to issue fewer instructions per cell and per score.
 //   * NW == 1: no barrier anywhere in the score loop (LDS operations of one wavefront execute in
@@ -49,9 +50,10 @@
 //     as the exact search; the band moves by at most two diagonals per score.
 //   * extend(): two 32-bit LDS words per sequence, v_alignbit_b32 to the base position, XOR,
 //     count-trailing-zeros: 16 bases per iteration (4 bytes in the byte-compare instantiation).
-//   * For CIGARs each cell emits ONE origin byte (64 consecutive bytes per wavefront store) into a
-//     bump-allocated arena; a per-alignment row table (8 bytes per score) locates the rows.  No
-//     O(max_error^2) per-alignment reservation and nothing to memset between alignments.
+//   * For CIGARs each cell emits ONE origin byte into a bump-allocated arena.  The one-wave exact tier (round 6): into a block
+//     of 64-byte TILES of 4 scores x 16 diagonals that the alignment claims once (TILED, below: the backward walk touches half
+//     the cache lines, a score sizes / claims / records nothing); the other tiers: one row per score (64 consecutive bytes per
+//     wavefront store) behind a per-alignment row table (8 bytes per score).  Nothing to memset between alignments.
 //
 // Files: this one holds the kernel's skeleton -- LDS layout, work claiming, per-alignment set-up (window, staging, ring reset,
 // score 0), the ring state shared by all score loops, the epilogue -- and the launchers.  The score loops and the cells are
@@ -59,11 +61,10 @@
 //   align/cells_hot.inc       the lean cells of the 16-bit LDS tiers: the hot loop of the library
 //   align/cells_generic.inc   the cells as WFA2 has them (careful loop, HBM-ring tiers, banded search after a jump)
 //   align/loop_lean_e1.inc    lean score loop, gap extension 1, closed-form limits
-//   align/loop_lean_any.inc   lean score loop, any gap extension
+//   align/loop_lean_any.inc   lean score loop, gap extension > 1: superset limits from two counters (round 6)
 //   align/loop_lean_hbm.inc   lean score loop of the tiers whose ring lives in HBM
 //   align/loop_careful.inc    the careful score step (WFA2 to the letter)
 //   align/band_window.inc, align/loop_banded.inc   the adaptive band: the reference's window rule, the banded search
-//   align/walk_epilogue.inc   the one-wave tiers walk a finished alignment back themselves (tiles through the freed ring LDS)
 #include <type_traits>
 
 #include "wfa_device.h"

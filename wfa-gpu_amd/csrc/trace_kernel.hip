@@ -10,8 +10,8 @@
 //
 // Two mappings, chosen by the host driver per pass:
 //   * short alignments (64 pairs of packed sequences fit a wavefront's share of LDS): ONE LANE per alignment.
-//     wfa_walk_kernel follows the origin bytes written by the align kernel backwards (the alignment's row table
-//     locates the rows of scores s-x / s-o-e / s-e) and pushes one byte per edit operation; wfa_emit_kernel replays the
+//     wfa_walk_kernel follows the origin bytes written by the align kernel backwards (through the alignment's block of tiles,
+//     or its row table: bt_block below) and pushes one byte per edit operation; wfa_emit_kernel replays the
 //     operations forwards, re-deriving every match run as a longest-common-prefix on the packed sequences -- identical
 //     to the extension the forward pass did, so no offsets had to be stored -- into an upper-bound slot of a scratch
 //     (big passes; wfa_text_compact_kernel then packs the texts densely) or, for small passes, twice: once to size the

@@ -7,9 +7,16 @@
 //                    base i of a sequence in bits [2*(i%16)+1 : 2*(i%16)]
 //                    (little-endian inside the word so one v_alignbit_b32
 //                    yields the 16 bases starting at any position).
-//   * Backtrace arena: per alignment a row table (8 bytes per score) and rows
-//                    of one origin byte per diagonal, bump-allocated in
-//                    16-byte units (no per-alignment worst-case reservation).
+//   * Backtrace arena: one origin byte per wavefront cell, bump-allocated in
+//                    16-byte units.  Two layouts, told apart by the first word
+//                    of a pair's block (bt_final_row[pair]):
+//                    - TILES (the one-wave exact tier, round 6): 64-byte header
+//                      {WFA_ROW_NONE, wlo, tile columns, budget}, then 64-byte
+//                      tiles of 4 scores x 16 diagonals at a fixed pitch: tile
+//                      (s >> 2, (k - wlo) >> 4), byte (s & 3) * 16 + ((k - wlo) & 15);
+//                    - ROWS (every other tier): a row table [score] = {unit of
+//                      the row, lo} (8 bytes per score) and one row of origin
+//                      bytes per score, byte j = diagonal lo + j.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -61,9 +68,9 @@ enum : uint8_t { OP_X = 1, OP_I = 2, OP_D = 3, OP_EXT_AFTER = 0x10 };
 #define WFA_RING_ROW_PAD 64
 #define WFA_ARENA_ROW_SLACK 4u
 
-// Backtrace arena, 16-byte units.  Per alignment: a row table [score] = {unit of the row, lo} (8 bytes
+// Backtrace arena, 16-byte units.  Per alignment: a block of tiles, or a row table [score] = {unit of the row, lo} (8 bytes
 // per score up to the score budget) followed, wherever the block's bump allocator puts them, by one
-// row of origin bytes per score (byte j = diagonal lo + j).
+// row of origin bytes per score (byte j = diagonal lo + j): the two layouts at the top of this file.
 struct WfaAlignParams {
   const uint32_t* packed;        // packed sequences (word base); RAW kernels: the ASCII buffer
   const char* ascii;             // non-null (packed kernels only): the sequences are still ASCII -- pack them while they are staged: the words go
@@ -108,11 +115,8 @@ struct WfaAlignParams {
   unsigned long long arena_units;        // capacity in 16-byte units
   unsigned long long* arena_top;         // bump pointer (units)
   uint32_t chunk_units;          // refill granularity
-  uint32_t* bt_final_row;        // [pair] out: unit offset of the pair's row table (WFA_ROW_NONE once the kernel has walked the alignment itself)
-  // The one-wave LDS tiers walk a finished alignment back at once (round 5): its origin rows and row table are still in this
-  // XCD's L2 / the memory-side cache, the ring's LDS is free for the tiles, and the op list goes into the workgroup's own arena
-  // chunk -- no wfa_walk_kernel re-reading 4.6 GB from HBM 25 ms later (the reference walks at the end of its kernel too:
-  // lib/kernels/sequence_alignment_kernel.cu:659-683).  1: do it (the host has checked that ring LDS holds tile + op list).
+  uint32_t* bt_final_row;        // [pair] out: unit offset of the pair's block of tiles / row table
+  // (round 5's option -- the one-wave tiers walking a finished alignment back themselves, a measured loss -- is gone: always 0)
   int walk_in_kernel;
   unsigned long long* cigar_off; // [pair] out (walk_in_kernel): WFA_OPS_IN_ARENA | byte offset of the op list in the arena
   uint32_t* cigar_len;           // [pair] out (walk_in_kernel): number of operations

@@ -6,8 +6,8 @@
 // is paid per alignment.  Here a group of L = 16 (or 32) lanes is one alignment, lane j of the group is diagonal wlo + j for
 // the WHOLE alignment (the exact diagonal window of the pair's score budget must fit the group: the same window argument as
 // in align_kernel.hip), and the wavefront history a cell needs -- M of the last D = max(x, o+e) <= 8 scores, I and D of the
-// last one (e == 1) -- lives in registers of the lane itself: M[s-x][k] is a register, M[s-o-e][k-1], I[s-1][k-1],
-// M[s-o-e][k+1], D[s-1][k+1] are DPP row shifts (v_mov_b32_dpp row_shr:1 / row_shl:1: a "row" of the DPP network is 16
+// last one (e == 1) or of the last D (e = 2..4, round 6: short_kernel_e2/3/4.hip) -- lives in registers of the lane itself:
+// M[s-x][k] is a register, M[s-o-e][k-1], I[s-e][k-1], M[s-o-e][k+1], D[s-e][k+1] are DPP row shifts (v_mov_b32_dpp row_shr:1 / row_shl:1: a "row" of the DPP network is 16
 // lanes = one group; the lanes a shift cannot feed keep NULL) of the neighbours' registers.  No LDS ring, no row limits, no
 // ring invariant, no barrier; LDS only holds the packed sequences of the G = 64 / L pairs for the extend.  The score loop is
 // unrolled over the ring depth so that every register index is a compile-time constant.

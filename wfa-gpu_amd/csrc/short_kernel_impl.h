@@ -24,8 +24,9 @@ template <int L> __device__ __forceinline__ int from_above(int v, int j) {
 
 // X = mismatch, OE = gap open + extend, E = gap extend.  L lanes per alignment.  The history a cell reads -- M of the last
 // D = max(X, OE) scores -- is a ring of D registers per lane; the score loop is unrolled D times so that every ring index is a
-// compile-time constant (round 3 had the two instantiations of the benchmark penalties; now every set with e == 1 and
-// max(x, o + e) <= 8 after the common-factor reduction: 64 x 2 kernels, picked from a table).
+// compile-time constant (round 3 had the two instantiations of the benchmark penalties; round 4 every set with e == 1 and
+// max(x, o + e) <= 8 after the common-factor reduction; round 6 gap extensions to 4: 26 (o + e, e) x 8 x sets, picked from tables,
+// one translation unit per gap extension).
 // BT (round 4): with CIGARs.  Every cell also leaves its origin byte (wfa_device.h: source of M with WFA2's priority on equal
 // offsets -- mismatch, then deletion, then insertion --, gap extension over gap open) in a row of L bytes per score; the rows
 // collect in LDS and go out, with the row table, when the alignment is done, into a slot of the arena the work item owns

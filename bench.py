@@ -61,6 +61,9 @@ WORKLOADS = {
     # reference's global ring, lib/kernels/sequence_distance_kernel.cu:214-249) on configs[4]'s pairs: tuning.min_tier = 3 (profiling leg)
     "cfg5t3": dict(pairs=1024, length=30_000, error=0.10, cigar=True, max_error=9000, band=None, steps=10, tuning={"min_tier": 3}, pairs_like="cfg5",
                    desc="1024 ONT-shaped 30 kbp pairs, 10% error, exact, -e 9000, score+CIGAR, forced onto the HBM-ring tier (tuning.min_tier = 3)"),
+    # the sixteen-wave LDS tier (tier 2: what the re-runs of a long-read batch's budget misses take), configs[3]'s pairs forced onto it
+    "cfg4t2": dict(pairs=16_384, length=10_000, error=0.03, cigar=True, max_error=3000, band=None, steps=20, tuning={"min_tier": 2}, pairs_like="cfg4",
+                   desc="16k HiFi-shaped 10 kbp pairs, 3% error, exact, score+CIGAR, forced onto the sixteen-wave LDS tier (tuning.min_tier = 2)"),
     # the reference's kernels take any penalties (lib/kernels/sequence_distance_kernel.cu:57-160) and its own tests run (5,3,2),
     # (3,5,2) and (3,1,4) (tests/test_api.c:59-219, tests/test-aligner.sh:11-48): configs[2] / configs[1] under those sets
     "cfg3_x5o3e2": dict(pairs=1_000_000, length=1000, error=0.05, cigar=True, max_error=600, band=None, steps=50, pen=(5, 3, 2), pairs_like="cfg3",

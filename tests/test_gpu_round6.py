@@ -151,3 +151,19 @@ def test_calls_that_skip_the_counter_memset_find_the_counters_clean():
                 assert c == truth[key][1], (which, pen)
     finally:
         al.close()
+
+
+def test_cli_reads_a_pipe_like_a_file(tmp_path):
+    """`-i <(cat pairs.seq)` -- a process substitution: a FIFO, st_size 0 -- gives the output of `-i pairs.seq` (the mapped
+    reader returned zero pairs for such inputs; the reference's getline reader takes them, utils/sequence_reader.c:137-227), and the
+    tool says what it waited for in front of its wall clock."""
+    import subprocess
+    cli = os.path.join(ROOT, "wfa-gpu_amd", "bin", "wfa.affine.gpu")
+    seq = os.path.join(ROOT, "tests", "golden", "wfa.utest.seq")
+    out_file, out_pipe = str(tmp_path / "file.alg"), str(tmp_path / "pipe.alg")
+    r1 = subprocess.run([cli, "-i", seq, "-x", "-o", out_file], capture_output=True, text=True, timeout=300)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    r2 = subprocess.run(["bash", "-c", f'"{cli}" -i <(cat "{seq}") -x -o "{out_pipe}"'], capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    assert open(out_file).read() == open(out_pipe).read() and len(open(out_file).read().splitlines()) == 305
+    assert "Alignment computed. Wall time:" in r2.stdout and "Device bring-up waited for before the clock:" in r2.stdout
